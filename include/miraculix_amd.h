@@ -1,0 +1,107 @@
+/* miraculix_amd.h -- C ABI of the MI355X-native compressed-genotype GEMM engine.
+ *
+ * Part 1 is the drop-in boundary: exactly the unmangled C symbols the reference's language bindings
+ * bind (dlopen + ccall in src/bindings/Julia/*.jl, bind(C) in src/bindings/Fortran/mod5codesapi.f90).
+ * Each declaration cites the reference interface it replaces (paths relative to the reference repo).
+ * Part 2 are additive entry points (prefix mxa_) for device-resident operands, SNP-sharded multi-GPU
+ * use, on-device .bed staging helpers and measurement; the reference has no counterpart for them.
+ *
+ * All matrices are column-major fp64.  Plain pointers and sizes only.
+ */
+#ifndef MIRACULIX_AMD_H
+#define MIRACULIX_AMD_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ Part 1: reference ABI */
+
+/* replaces src/miraculix/5codesAPI.c:43-70 (prototype src/miraculix/5codes.h:137-153; doc
+ * docs/genotype_matrix_multiplication.md:5-17; Fortran binding src/bindings/Fortran/mod5codesapi.f90:22-40).
+ * Process-global options.  This engine is GPU-only: use_gpu == 0 is a fatal error (stderr + exit), as are the
+ * combinations the reference rejects for its GPU path (5codesChar.cc:192-193): use_miraculix_freq != 0,
+ * ignore_missings == 0, do_normalize != 0.  cores, floatLoop, meanSubstract, variant have no GPU meaning and are
+ * accepted and ignored (src/miraculix/GPUapi.h:38). */
+void setOptions_compressed(int use_gpu, int cores, int floatLoop, int meanSubstract, int ignore_missings,
+                           int do_not_center, int do_normalize, int use_miraculix_freq, int variant,
+                           int print_details);
+
+/* replaces src/miraculix/5codesAPI.c:80-96 -> plink2gpu (src/cuda/dgemm_compressed_cuda.cu:43-170).
+ * plink: SNP-major bed payload without the 3 header bytes, snps rows of ceil(indiv/4) bytes;
+ * plink_transposed: indiv rows of ceil(snps/4) bytes; f: snps allele frequencies (required when centring);
+ * max_n: largest n later passed to dgemm_compressed (buffers grow if exceeded).  The data is copied: the caller
+ * may free its buffers afterwards.  Either matrix pointer may also be a device pointer.  On failure
+ * *compressed is left NULL and a message is printed (reference: print + handle unset). */
+void plink2compressed(char *plink, char *plink_transposed, int snps, int indiv, double *f, int max_n,
+                      void **compressed);
+
+/* replaces src/miraculix/5codesAPI.c:98-110 -> dgemm_compressed_gpu (src/cuda/dgemm_compressed_cuda.cu:218-489).
+ * trans[0] in {N,n}: C(indiv x n) = (Z - 2*1*f^T) * B(snps x n); {T,t,Y,y}: C(snps x n) = (Z - 2*1*f^T)^T * B(indiv x n);
+ * anything else: exit(99) (5codesAPI.c:73-77).  Centring is governed by do_not_center.  Ldb/Ldc are honoured
+ * (the reference GPU path ignores them, its CPU path honours them and zero-fills the padding rows of C;
+ * so does this).  B and C may each be host or device pointers.  Synchronous. */
+void dgemm_compressed(char *trans, void *compressed, int n, double *B, int Ldb, double *C, int Ldc);
+
+/* replaces src/miraculix/5codesAPI.c:159-161 -> freegpu (src/cuda/dgemm_compressed_cuda.cu:176-213).
+ * Releases all device memory and sets *compressed = NULL (the reference leaves the caller's pointer dangling). */
+void free_compressed(void **compressed);
+
+/* replaces src/miraculix/5codesAPI.c:37-39.  Returns the allele frequencies stored with the object. */
+void get_compressed_freq(void *compressed, double *f);
+
+/* replaces src/cuda/snp_multiply_cuda.cu:375-382 (prototype src/cuda/snp_multiply_cuda.h:113-114; Julia binding
+ * src/bindings/Julia/crossproduct.jl:54-58, which passes the bool as Cint).
+ * ans(indiv x indiv, column-major doubles, full symmetric) = X * X^T where X has `indiv` rows of ceil(snps/4) bytes
+ * of 2-bit values; positional meaning as in the reference: `snps` = packed (inner) dimension, `indiv` = output
+ * dimension.  is_plink_format applies the reference's byte table first (00->0, 10->1, 11->2, any byte holding a
+ * missing 01 pair -> 0xFF).  Exact int32 accumulation.  snp_matrix and ans may be host or device pointers.
+ * Returns 0 on success, 1 on failure. */
+int snp_multiply_gpu(unsigned char *snp_matrix, int snps, int indiv, double *ans, bool is_plink_format);
+
+/* ------------------------------------------------------------------ Part 2: additive entry points */
+
+/* last error of the calling process: 0 = none.  Message valid until the next failing call. */
+int mxa_last_error(void);
+const char *mxa_last_error_string(void);
+
+/* number of visible HIP devices, or -1 if the runtime cannot be initialised */
+int mxa_device_count(void);
+
+/* SNP-sharded staging for one-process-per-GPU use: like plink2compressed, but this object holds only SNPs
+ * [snp_begin, snp_end) of the full matrix.  plink points at the FULL SNP-major payload (row pitch ceil(indiv/4));
+ * plink_transposed at the FULL individual-major payload (row pitch ceil(snps_total/4)); f at the FULL frequency
+ * vector.  snp_begin must be a multiple of 4 so that packed bytes split cleanly.
+ * For 'N' the caller passes rows [snp_begin, snp_end) of B and sum-reduces C over the shards
+ * (the centring term is a partial sum too and rides along); for 'T' C holds rows [snp_begin, snp_end). */
+void mxa_plink2compressed_shard(char *plink, char *plink_transposed, int snps_total, int indiv, int snp_begin,
+                                int snp_end, double *f, int max_n, void **compressed);
+
+/* dgemm_compressed with 64-bit leading dimensions on an explicit HIP stream (NULL = the object's own stream),
+ * device pointers only, asynchronous when sync == 0.  Returns 0 / 1. */
+int mxa_dgemm_compressed_device(char trans, void *compressed, int n, const double *dB, long ldb, double *dC,
+                                long ldc, void *hip_stream, int sync);
+
+/* on-device .bed staging helpers (reference counterparts live in the bindings:
+ * transpose_genotype_matrix src/bindings/Julia/compressed_operations.jl:45-66, popcount frequencies
+ * src/bindings/Julia/read_plink.jl:199-203).  Pointers may be host or device. */
+int mxa_transpose_2bit(const unsigned char *in, long rows, long cols, unsigned char *out);
+int mxa_allele_freq(const unsigned char *plink, long snps, long indiv, double *f);
+
+/* measurement: HIP-event timing of the dominant kernel on the stream it is launched on.
+ * mxa_profile_reset() clears the counters; after some dgemm_compressed / snp_multiply_gpu calls
+ * mxa_profile_get() returns the number of dominant-kernel launches and their summed duration in ms. */
+void mxa_profile_reset(void);
+void mxa_profile_get(int *launches, double *total_ms);
+
+/* geometry of the last dgemm_compressed call (for roofline accounting): rows, inner dim, n, split count */
+void mxa_last_geometry(long *m, long *k, int *n, int *splits, int *a_tile, int *c_tile);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRACULIX_AMD_H */

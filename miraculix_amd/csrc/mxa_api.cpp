@@ -1,0 +1,420 @@
+// mxa_api.cpp -- host side of the C ABI (include/miraculix_amd.h): options singleton, PLINK .bed staging,
+// per-call orchestration.  Mirrors the reference's L3/L2 layers (src/miraculix/5codesAPI.c,
+// src/miraculix/5codesChar.cc:165-449) and the host part of src/cuda/dgemm_compressed_cuda.cu, re-designed so that
+// nothing is allocated, created or destroyed per multiply and operands may already live in HBM.
+//
+// No CPU fallback: every compute entry needs a HIP device and fails loudly without one.
+#include "../../include/miraculix_amd.h"
+#include "mxa_internal.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace mxa {
+
+// ------------------------------------------------------------------------------------------------ state
+static int g_err = 0;
+static char g_errmsg[512] = "";
+
+Options &options() { static Options o; return o; }
+Profile &profile() { static Profile p; return p; }
+Geometry &last_geometry() { static Geometry g; return g; }
+static bool g_profile_on = true;
+
+int env_print_level() {  // reference: cuda_utils.cu:44-52, env PRINT_LEVEL
+  const char *e = getenv("PRINT_LEVEL");
+  return e ? atoi(e) : 0;
+}
+
+void set_error(int code, const char *fmt, ...) {
+  g_err = code;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_errmsg, sizeof(g_errmsg), fmt, ap);
+  va_end(ap);
+  fprintf(stderr, "miraculix_amd: %s\n", g_errmsg);
+}
+
+bool check_hip(hipError_t e, const char *func, int line) {
+  if (e == hipSuccess) return true;
+  // wording follows the reference's checkError (cuda_utils.cu:83-90)
+  set_error(100 + (int)e, "Internal error in function %s at line %d: %s", func, line, hipGetErrorString(e));
+  return false;
+}
+
+void debug_info(const char *fmt, ...) {
+  if (env_print_level() <= 0 && options().print_level <= 0) return;
+  va_list ap;
+  va_start(ap, fmt);
+  printf("\t ");
+  vprintf(fmt, ap);
+  printf("\n");
+  va_end(ap);
+}
+
+static Handle *as_handle(void *p, const char *who) {
+  Handle *h = reinterpret_cast<Handle *>(p);
+  if (!h || h->magic != kMagic) {
+    set_error(2, "%s: invalid or uninitialised compressed object", who);
+    return nullptr;
+  }
+  return h;
+}
+
+static bool is_device_ptr(const void *p) {
+  if (!p) return false;
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// device selection: env CUDA_DEVICE is honoured like the reference (cuda_utils.cu:187-247) but visibility variables
+// need not be set; HIP_DEVICE takes precedence.
+static int select_device() {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    set_error(10, "no HIP device available (hipGetDeviceCount: %s). This engine is GPU-only.", hipGetErrorString(e));
+    return -1;
+  }
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  int dev = cur;
+  const char *d = getenv("HIP_DEVICE");
+  if (!d) d = getenv("CUDA_DEVICE");
+  if (d) dev = atoi(d);
+  if (dev < 0 || dev >= count) {
+    set_error(11, "The requested device %d is not visible to the HIP runtime (%d devices).", dev, count);
+    return -1;
+  }
+  if (!check_hip(hipSetDevice(dev), __func__, __LINE__)) return -1;
+  return dev;
+}
+
+static int grow(double **p, size_t *cap, size_t need_elems) {
+  if (*cap >= need_elems) return 0;
+  if (*p) { MXA_HIP(hipFree(*p)); *p = nullptr; *cap = 0; }
+  MXA_HIP(hipMalloc(reinterpret_cast<void **>(p), need_elems * sizeof(double)));
+  *cap = need_elems;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ staging
+// Allocate the padded device layout for `rows` x `k` genotypes and fill it from raw PLINK rows (host or device).
+static int stage_matrix(PackedMatrix &M, const uint8_t *src, size_t src_pitch, long rows, long k, hipStream_t s) {
+  M.rows = rows; M.k = k;
+  M.rows_pad = (rows + kRowAlign - 1) / kRowAlign * kRowAlign;
+  M.k_pad = (k + kSlabK - 1) / kSlabK * kSlabK;
+  M.pitch = (size_t)M.k_pad / 4;
+  const size_t bytes = (size_t)M.rows_pad * M.pitch;
+  MXA_HIP(hipMalloc(reinterpret_cast<void **>(&M.d), bytes));
+  MXA_HIP(hipMemsetAsync(M.d, 0, bytes, s));
+  const long row_bytes = (k + 3) / 4;
+  if (is_device_ptr(src)) {
+    if (launch_recode(src, src_pitch, 0, rows, k, 0, M, s)) return 1;
+    MXA_HIP(hipStreamSynchronize(s));
+    return 0;
+  }
+  // host source: stream row chunks through a device bounce buffer (compacting the pitch), recode on device
+  const size_t chunk_bytes = (size_t)256 << 20;
+  long chunk_rows = std::max<long>(1, (long)(chunk_bytes / (size_t)std::max<long>(1, row_bytes)));
+  chunk_rows = std::min(chunk_rows, rows);
+  uint8_t *bounce = nullptr;
+  MXA_HIP(hipMalloc(reinterpret_cast<void **>(&bounce), (size_t)chunk_rows * row_bytes));
+  int rc = 0;
+  for (long r0 = 0; r0 < rows && !rc; r0 += chunk_rows) {
+    const long nr = std::min(chunk_rows, rows - r0);
+    hipError_t e;
+    if ((size_t)row_bytes == src_pitch) e = hipMemcpyAsync(bounce, src + (size_t)r0 * src_pitch, (size_t)nr * row_bytes, hipMemcpyHostToDevice, s);
+    else e = hipMemcpy2DAsync(bounce, row_bytes, src + (size_t)r0 * src_pitch, src_pitch, row_bytes, nr, hipMemcpyHostToDevice, s);
+    if (!check_hip(e, __func__, __LINE__)) { rc = 1; break; }
+    rc = launch_recode(bounce, row_bytes, r0, nr, k, 0, M, s);
+    if (!rc && !check_hip(hipStreamSynchronize(s), __func__, __LINE__)) rc = 1;
+  }
+  (void)hipFree(bounce);
+  return rc;
+}
+
+static void destroy_handle(Handle *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  void *ptrs[] = {h->snp_major.d, h->ind_major.d, h->d_f, h->ws.d_Bstage, h->ws.d_Cstage, h->ws.d_Bp, h->ws.d_P, h->ws.d_colpart};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  free(h->h_f);
+  h->magic = 0;
+  delete h;
+}
+
+static int ensure_workspace(Handle *h, int n) {
+  // sized for the larger of the two products, like the reference's size_buffer (dgemm_compressed_cuda.cu:77)
+  Workspace &w = h->ws;
+  const long kmax_pad = std::max(h->snp_major.k_pad, h->ind_major.k_pad);
+  GemmPlan pn = plan_gemm(h->indiv, h->ind_major.k_pad, n), pt = plan_gemm(h->snps, h->snp_major.k_pad, n);
+  const size_t bp = (size_t)kmax_pad * std::max(pn.n_pad, pt.n_pad);
+  const size_t pp = std::max((size_t)pn.splits * pn.n_pad * pn.m_pad, (size_t)pt.splits * pt.n_pad * pt.m_pad);
+  if (grow(&w.d_Bp, &w.cap_Bp, bp)) return 1;
+  if (grow(&w.d_P, &w.cap_P, pp)) return 1;
+  if (grow(&w.d_colpart, &w.cap_colpart, (size_t)n * (64 * 2 + 2) + 16)) return 1;
+  return 0;
+}
+
+static int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink_t, size_t plink_t_pitch, long snps,
+                         long indiv, const double *f, int max_n, void **out) {
+  if (out) *out = nullptr;
+  if (!out) { set_error(1, "plink2compressed: compressed is NULL"); return 1; }
+  if (!plink || !plink_t) { set_error(1, "plink2compressed: both plink and plink_transposed are required on the GPU path"); return 1; }
+  if (snps <= 0 || indiv <= 0) { set_error(1, "plink2compressed: snps and indiv must be positive"); return 1; }
+  Options &o = options();
+  if (!o.set) {  // reference default before any user call: gpu when compiled with CUDA, centred (5codesChar.cc:127-143)
+    o.gpu = true; o.centered = true; o.set = true;
+  }
+  const int dev = select_device();
+  if (dev < 0) return 1;
+  if (env_print_level() > 0 || o.print_level > 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) printf("miraculix_amd - dgemm_compressed: using device %s (device no %d).\n", prop.name, dev);
+  }
+  // memory pre-flight like checkDevMemory (cuda_utils.cu:162-185)
+  size_t free_b = 0, total_b = 0;
+  MXA_HIP(hipMemGetInfo(&free_b, &total_b));
+  const size_t need = (size_t)((snps + kRowAlign) * ((indiv + kSlabK) / 4)) + (size_t)((indiv + kRowAlign) * ((snps + kSlabK) / 4)) +
+                      (size_t)3 * sizeof(double) * (size_t)std::max(snps, indiv) * (size_t)std::max(max_n, 1);
+  if (need > free_b) {
+    set_error(12, "Not enough device memory available. Required %zu GB, free %zu GB, total on device %zu GB", need >> 30, free_b >> 30, total_b >> 30);
+    return 1;
+  }
+  Handle *h = new Handle();
+  h->device = dev; h->snps = snps; h->indiv = indiv; h->max_n = std::max(max_n, 1);
+  if (!check_hip(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), __func__, __LINE__)) { destroy_handle(h); return 1; }
+  if (stage_matrix(h->snp_major, plink, plink_pitch, snps, indiv, h->stream) ||
+      stage_matrix(h->ind_major, plink_t, plink_t_pitch, indiv, snps, h->stream)) { destroy_handle(h); return 1; }
+  if (!check_hip(hipMalloc(reinterpret_cast<void **>(&h->d_f), sizeof(double) * snps), __func__, __LINE__)) { destroy_handle(h); return 1; }
+  h->h_f = (double *)calloc((size_t)snps, sizeof(double));
+  if (f) {
+    hipError_t e = hipMemcpy(h->d_f, f, sizeof(double) * snps, is_device_ptr(f) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+    if (!check_hip(e, __func__, __LINE__)) { destroy_handle(h); return 1; }
+    e = hipMemcpy(h->h_f, h->d_f, sizeof(double) * snps, hipMemcpyDeviceToHost);
+    if (!check_hip(e, __func__, __LINE__)) { destroy_handle(h); return 1; }
+    h->has_f = true;
+  } else {
+    (void)hipMemset(h->d_f, 0, sizeof(double) * snps);
+  }
+  if (ensure_workspace(h, h->max_n)) { destroy_handle(h); return 1; }
+  *out = h;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ multiply
+static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, hipStream_t s) {
+  const PackedMatrix &G = trans ? h->snp_major : h->ind_major;   // reference picks d_plink for 'T' (dgemm_compressed_cuda.cu:270)
+  const long m = G.rows, k = G.k;
+  const bool centered = options().centered;
+  if (centered && !h->has_f) { set_error(6, "dgemm_compressed: centring requested but no allele frequencies were supplied to plink2compressed"); return 1; }
+  if (ldb < k || ldc < m) { set_error(7, "dgemm_compressed: leading dimension too small (ldb %ld < %ld or ldc %ld < %ld)", ldb, k, ldc, m); return 1; }
+  if (n > h->max_n) { h->max_n = n; }
+  if (ensure_workspace(h, n)) return 1;
+  Workspace &w = h->ws;
+  GemmPlan p = plan_gemm(m, G.k_pad, n);
+  Geometry &geo = last_geometry();
+  geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c;
+  double *d_sumB = w.d_colpart + (size_t)n * 128, *d_sumfB = d_sumB + n;
+  if (launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, s)) return 1;
+  if (centered && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (g_profile_on) {
+    MXA_HIP(hipEventCreate(&e0)); MXA_HIP(hipEventCreate(&e1));
+    MXA_HIP(hipEventRecord(e0, s));
+  }
+  int rc = launch_gemm(G, w.d_Bp, w.d_P, p, s);
+  if (g_profile_on && !rc) MXA_HIP(hipEventRecord(e1, s));
+  if (!rc) rc = launch_finish(w.d_P, p, m, n, dC, ldc, trans ? 1 : 0, centered, d_sumB, d_sumfB, h->d_f, s);
+  if (g_profile_on) {
+    if (!rc) {
+      MXA_HIP(hipEventSynchronize(e1));
+      float ms = 0.f;
+      MXA_HIP(hipEventElapsedTime(&ms, e0, e1));
+      profile().launches += 1; profile().total_ms += ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
+  return rc;
+}
+
+static int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, double *C, long ldc) {
+  MXA_HIP(hipSetDevice(h->device));
+  const PackedMatrix &G = trans ? h->snp_major : h->ind_major;
+  const long m = G.rows, k = G.k;
+  if (n <= 0) return 0;
+  if (!B || !C) { set_error(1, "dgemm_compressed: B and C must not be NULL"); return 1; }
+  if (ldb < k || ldc < m) { set_error(7, "dgemm_compressed: leading dimension too small (ldb %ld < %ld or ldc %ld < %ld)", ldb, k, ldc, m); return 1; }
+  hipStream_t s = h->stream;
+  const bool b_dev = is_device_ptr(B), c_dev = is_device_ptr(C);
+  const double *dB = B; long dldb = ldb;
+  double *dC = C; long dldc = ldc;
+  Workspace &w = h->ws;
+  if (!b_dev) {
+    if (grow(&w.d_Bstage, &w.cap_Bstage, (size_t)k * n)) return 1;
+    if (ldb == k) MXA_HIP(hipMemcpyAsync(w.d_Bstage, B, sizeof(double) * (size_t)k * n, hipMemcpyHostToDevice, s));
+    else MXA_HIP(hipMemcpy2DAsync(w.d_Bstage, sizeof(double) * k, B, sizeof(double) * ldb, sizeof(double) * k, n, hipMemcpyHostToDevice, s));
+    dB = w.d_Bstage; dldb = k;
+  }
+  if (!c_dev) {
+    if (grow(&w.d_Cstage, &w.cap_Cstage, (size_t)ldc * n)) return 1;
+    dC = w.d_Cstage; dldc = ldc;
+  }
+  if (gemm_device(h, trans, n, dB, dldb, dC, dldc, s)) return 1;
+  if (!c_dev) MXA_HIP(hipMemcpyAsync(C, dC, sizeof(double) * (size_t)ldc * n, hipMemcpyDeviceToHost, s));
+  MXA_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+}  // namespace mxa
+
+using namespace mxa;
+
+// ================================================================================================ C ABI
+extern "C" {
+
+void setOptions_compressed(int use_gpu, int cores, int floatLoop, int meanSubstract, int ignore_missings, int do_not_center,
+                           int do_normalize, int use_miraculix_freq, int variant, int print_details) {
+  (void)cores; (void)floatLoop; (void)meanSubstract; (void)variant;
+  if (print_details > 0 || env_print_level() > 0) printf("get started\n");  // the reference prints this unconditionally (5codesAPI.c:56)
+  if (!use_gpu) {
+    fprintf(stderr, "miraculix_amd: setOptions_compressed(use_gpu=0): this library is the MI355X engine only; the CPU 5codes engine is "
+                    "not part of it. Load the reference library for CPU runs.\n");
+    exit(EXIT_FAILURE);
+  }
+  // same fatal combination as the reference (5codesChar.cc:192-193, ERR0 -> fprintf(stderr)+exit)
+  if (use_miraculix_freq || !ignore_missings || do_normalize) {
+    fprintf(stderr, "in case of 'gpu' the Fortran frequency must always be used; missings/centering/normalizing cannot treated.\n");
+    exit(EXIT_FAILURE);
+  }
+  Options &o = options();
+  o.gpu = true;
+  o.centered = !do_not_center;
+  o.print_level = print_details;
+  o.set = true;
+}
+
+void plink2compressed(char *plink, char *plink_transposed, int snps, int indiv, double *f, int max_n, void **compressed) {
+  const size_t ps = ((size_t)indiv + 3) / 4, pi = ((size_t)snps + 3) / 4;
+  (void)create_handle(reinterpret_cast<const uint8_t *>(plink), ps, reinterpret_cast<const uint8_t *>(plink_transposed), pi, snps, indiv, f,
+                      max_n, compressed);
+}
+
+void mxa_plink2compressed_shard(char *plink, char *plink_transposed, int snps_total, int indiv, int snp_begin, int snp_end, double *f,
+                                int max_n, void **compressed) {
+  if (compressed) *compressed = nullptr;
+  if (snp_begin < 0 || snp_end > snps_total || snp_begin >= snp_end || (snp_begin & 3)) {
+    set_error(1, "mxa_plink2compressed_shard: need 0 <= snp_begin < snp_end <= snps_total and snp_begin %% 4 == 0");
+    return;
+  }
+  const size_t ps = ((size_t)indiv + 3) / 4, pi = ((size_t)snps_total + 3) / 4;
+  const uint8_t *p = reinterpret_cast<const uint8_t *>(plink) + (size_t)snp_begin * ps;
+  const uint8_t *pt = reinterpret_cast<const uint8_t *>(plink_transposed) + (size_t)snp_begin / 4;
+  (void)create_handle(p, ps, pt, pi, snp_end - snp_begin, indiv, f ? f + snp_begin : nullptr, max_n, compressed);
+}
+
+static int trans_flag(const char *trans) {  // 5codesAPI.c:73-77
+  if (*trans == 'T' || *trans == 't' || *trans == 'Y' || *trans == 'y') return 1;
+  if (*trans != 'N' && *trans != 'n') exit(99);
+  return 0;
+}
+
+void dgemm_compressed(char *trans, void *compressed, int n, double *B, int Ldb, double *C, int Ldc) {
+  const int t = trans_flag(trans);
+  Handle *h = as_handle(compressed, "dgemm_compressed");
+  if (!h) return;
+  (void)gemm_any(h, t != 0, n, B, Ldb, C, Ldc);
+}
+
+int mxa_dgemm_compressed_device(char trans, void *compressed, int n, const double *dB, long ldb, double *dC, long ldc, void *hip_stream,
+                                int sync) {
+  const int t = trans_flag(&trans);
+  Handle *h = as_handle(compressed, "mxa_dgemm_compressed_device");
+  if (!h) return 1;
+  if (n <= 0) return 0;
+  MXA_HIP(hipSetDevice(h->device));
+  hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->stream;
+  if (gemm_device(h, t != 0, n, dB, ldb, dC, ldc, s)) return 1;
+  if (sync) MXA_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+void free_compressed(void **compressed) {
+  if (!compressed || !*compressed) return;
+  Handle *h = as_handle(*compressed, "free_compressed");
+  if (h) destroy_handle(h);
+  *compressed = nullptr;
+}
+
+void get_compressed_freq(void *compressed, double *f) {
+  Handle *h = as_handle(compressed, "get_compressed_freq");
+  if (!h || !f) return;
+  memcpy(f, h->h_f, sizeof(double) * (size_t)h->snps);
+}
+
+int mxa_last_error(void) { return g_err; }
+const char *mxa_last_error_string(void) { return g_errmsg; }
+
+int mxa_device_count(void) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return c;
+}
+
+void mxa_profile_reset(void) { profile() = Profile(); }
+void mxa_profile_get(int *launches, double *total_ms) {
+  if (launches) *launches = profile().launches;
+  if (total_ms) *total_ms = profile().total_ms;
+}
+void mxa_last_geometry(long *m, long *k, int *n, int *splits, int *a_tile, int *c_tile) {
+  const Geometry &g = last_geometry();
+  if (m) *m = g.m; if (k) *k = g.k; if (n) *n = g.n; if (splits) *splits = g.splits; if (a_tile) *a_tile = g.a; if (c_tile) *c_tile = g.c;
+}
+
+// ---- staging helpers
+int mxa_transpose_2bit(const unsigned char *in, long rows, long cols, unsigned char *out) {
+  if (!in || !out || rows <= 0 || cols <= 0) { set_error(1, "mxa_transpose_2bit: bad arguments"); return 1; }
+  if (select_device() < 0) return 1;
+  const size_t nin = (size_t)rows * ((cols + 3) / 4), nout = (size_t)cols * ((rows + 3) / 4);
+  const bool in_dev = is_device_ptr(in), out_dev = is_device_ptr(out);
+  uint8_t *d_in = const_cast<uint8_t *>(in), *d_out = out;
+  int rc = 0;
+  if (!in_dev) { MXA_HIP(hipMalloc((void **)&d_in, nin)); if (!check_hip(hipMemcpy(d_in, in, nin, hipMemcpyHostToDevice), __func__, __LINE__)) rc = 1; }
+  if (!out_dev && !rc) { if (!check_hip(hipMalloc((void **)&d_out, nout), __func__, __LINE__)) rc = 1; }
+  if (!rc) rc = launch_transpose_2bit(d_in, rows, cols, d_out, nullptr);
+  if (!rc && !check_hip(hipDeviceSynchronize(), __func__, __LINE__)) rc = 1;
+  if (!rc && !out_dev && !check_hip(hipMemcpy(out, d_out, nout, hipMemcpyDeviceToHost), __func__, __LINE__)) rc = 1;
+  if (!in_dev && d_in) (void)hipFree(d_in);
+  if (!out_dev && d_out) (void)hipFree(d_out);
+  return rc;
+}
+
+int mxa_allele_freq(const unsigned char *plink, long snps, long indiv, double *f) {
+  if (!plink || !f || snps <= 0 || indiv <= 0) { set_error(1, "mxa_allele_freq: bad arguments"); return 1; }
+  if (select_device() < 0) return 1;
+  const size_t nin = (size_t)snps * ((indiv + 3) / 4);
+  const bool in_dev = is_device_ptr(plink), out_dev = is_device_ptr(f);
+  uint8_t *d_in = const_cast<uint8_t *>(plink);
+  double *d_f = f;
+  int rc = 0;
+  if (!in_dev) { MXA_HIP(hipMalloc((void **)&d_in, nin)); if (!check_hip(hipMemcpy(d_in, plink, nin, hipMemcpyHostToDevice), __func__, __LINE__)) rc = 1; }
+  if (!out_dev && !rc) { if (!check_hip(hipMalloc((void **)&d_f, sizeof(double) * snps), __func__, __LINE__)) rc = 1; }
+  if (!rc) rc = launch_allele_freq(d_in, snps, indiv, d_f, nullptr);
+  if (!rc && !check_hip(hipDeviceSynchronize(), __func__, __LINE__)) rc = 1;
+  if (!rc && !out_dev && !check_hip(hipMemcpy(f, d_f, sizeof(double) * snps, hipMemcpyDeviceToHost), __func__, __LINE__)) rc = 1;
+  if (!in_dev && d_in) (void)hipFree(d_in);
+  if (!out_dev && d_f) (void)hipFree(d_f);
+  return rc;
+}
+
+}  // extern "C"

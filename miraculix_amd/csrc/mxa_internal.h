@@ -1,0 +1,93 @@
+// mxa_internal.h -- private types shared by the host side (api/staging) and the kernel launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace mxa {
+
+// ---- geometry constants of the fp64 MFMA kernel (see DESIGN.md "dgemm kernel")
+constexpr int kWaves = 4;          // waves per workgroup
+constexpr int kKStep = 16;         // genotypes consumed by one v_mfma_f64_4x4x4_4b_f64 (4 blocks x K=4)
+constexpr int kSlabSteps = 8;      // K-steps per LDS slab
+constexpr int kSlabK = kKStep * kSlabSteps;   // 128 genotypes = 32 packed bytes per row per slab
+constexpr int kSlabBytes = kSlabK / 4;
+constexpr int kRowAlign = 256;     // packed matrices are padded to a multiple of this many rows
+
+struct Options {
+  bool gpu = true;
+  bool centered = true;      // genetics.centered = !do_not_center (5codesAPI.c:59-68)
+  int print_level = 0;       // env PRINT_LEVEL / print_details
+  bool set = false;
+};
+Options &options();
+int env_print_level();
+
+// One packed, recoded genotype matrix resident in HBM: `rows` rows of `k` genotypes, 2 bits each holding the
+// allele count z in {0,1,2} (PLINK code 01 "missing" already mapped to 0), row pitch `pitch` bytes (multiple of
+// kSlabBytes, zero padded), rows padded with zero rows up to rows_pad.
+struct PackedMatrix {
+  uint8_t *d = nullptr;
+  long rows = 0, k = 0;
+  long rows_pad = 0, k_pad = 0;
+  size_t pitch = 0;
+};
+
+struct Workspace {
+  double *d_Bstage = nullptr; size_t cap_Bstage = 0;   // host B staged here
+  double *d_Cstage = nullptr; size_t cap_Cstage = 0;   // result staged here when C is a host pointer
+  double *d_Bp = nullptr;     size_t cap_Bp = 0;       // B in MFMA fragment order
+  double *d_P = nullptr;      size_t cap_P = 0;        // split-K partial slabs
+  double *d_colpart = nullptr; size_t cap_colpart = 0; // column-sum partials + sums
+};
+
+constexpr uint32_t kMagic = 0x4d584131u;  // "MXA1"
+
+struct Handle {
+  uint32_t magic = kMagic;
+  int device = 0;
+  long snps = 0, indiv = 0;
+  PackedMatrix snp_major;    // rows = snps,  k = indiv   (used by 'T')
+  PackedMatrix ind_major;    // rows = indiv, k = snps    (used by 'N')
+  double *d_f = nullptr;     // snps
+  double *h_f = nullptr;
+  bool has_f = false;
+  int max_n = 0;
+  Workspace ws;
+  hipStream_t stream = nullptr;
+};
+
+struct Profile {
+  int launches = 0;
+  double total_ms = 0.0;
+};
+Profile &profile();
+
+struct Geometry { long m = 0, k = 0; int n = 0, splits = 0, a = 0, c = 0; };
+Geometry &last_geometry();
+
+// ---- error handling: print + remember (reference: cuda_utils.cu:83-90 prints "Internal error in function ...")
+void set_error(int code, const char *fmt, ...);
+bool check_hip(hipError_t e, const char *func, int line);
+#define MXA_HIP(x) do { if (!::mxa::check_hip((x), __func__, __LINE__)) return 1; } while (0)
+void debug_info(const char *fmt, ...);
+
+// ---- kernel launchers (mxa_kernels.hip)
+// recode raw PLINK rows (src pitch arbitrary) into the padded z-coded device layout
+int launch_recode(const uint8_t *d_src, size_t src_pitch, long row0, long nrows, long k, long k_bit_offset,
+                  PackedMatrix &dst, hipStream_t s);
+int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k_pad, int n_pad, hipStream_t s);
+int launch_colsums(const double *dB, long ldb, long k, int n, const double *d_f /*nullable*/, double *d_part,
+                   double *d_sumB, double *d_sumfB, hipStream_t s);
+struct GemmPlan { int a, c, nchunks, n_pad, splits, slabs_per_split, slabs_total, rowblocks; long m_pad; };
+GemmPlan plan_gemm(long m, long k_pad, int n);
+int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, hipStream_t s);
+int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC, long ldc, int mode_trans,
+                  bool centered, const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s);
+int launch_transpose_2bit(const uint8_t *d_in, long rows, long cols, uint8_t *d_out, hipStream_t s);
+int launch_allele_freq(const uint8_t *d_plink, long snps, long indiv, double *d_f, hipStream_t s);
+// crossproduct
+int launch_plink_lut(uint8_t *d, size_t nbytes, hipStream_t s);
+int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double *d_ans, hipStream_t s);
+
+}  // namespace mxa

@@ -1,0 +1,448 @@
+// mxa_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the compressed-genotype GEMM path.
+//
+//   k_recode        PLINK .bed bytes -> padded z-coded 2-bit rows (one-off staging pass, HBM-bound)
+//   k_pack_B        B (column-major, ldb) -> MFMA fragment order, zero padded (HBM-bound, once per call)
+//   k_colsum_*      deterministic column sums  sum_k B[k,j]  and  sum_k f_k B[k,j]  (centring coefficients)
+//   k_gemm          the hot loop: 2-bit genotypes x fp64 on v_mfma_f64_4x4x4_4b_f64 (fp64-MFMA-bound)
+//   k_finish        fixed-order split-K reduction + rank-1 centring + store with ldc
+//   k_transpose_2bit / k_allele_freq   on-device staging helpers
+//
+// What they replace in the reference: the CUTLASS SIMT u2 x f64 GEMM (src/cuda/dgemm_compressed_cuda.cu:328-385,
+// microkernel src/cuda/dgemm_compressed_cuda.h:232-269), the cublasDgeam transpose (:392-404), the
+// Dgemv + n x Daxpy centring epilogue (:421-463) and the per-call memset/2D-memcpy padding of B (:296-317).
+//
+// gfx950 only; wave64; no CUDA compatibility layer.
+#include "mxa_internal.h"
+#include <algorithm>
+#include <cstdio>
+
+namespace mxa {
+
+// =====================================================================================================
+// staging: recode
+// =====================================================================================================
+// PLINK code c -> allele count z = max(c-1,0): 00->00, 01->00 (missing), 10->01, 11->10, SWAR on 16 fields.
+__device__ __forceinline__ uint32_t recode16(uint32_t w) {
+  const uint32_t H = (w >> 1) & 0x55555555u, L = w & 0x55555555u;
+  return ((H & L) << 1) | (H & ~L);
+}
+
+__global__ void __launch_bounds__(256) k_recode(const uint8_t *__restrict__ src, size_t src_pitch, long src_row_bytes,
+                                                long nrows, long k, uint8_t *__restrict__ dst, size_t dst_pitch,
+                                                long dst_row0) {
+  const long dwords_per_row = (long)(dst_pitch >> 2);
+  const long total = nrows * dwords_per_row;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long r = idx / dwords_per_row, d = idx - r * dwords_per_row;
+    const long b = d * 4;
+    const uint8_t *p = src + (size_t)r * src_pitch + b;
+    uint32_t w = 0;
+    if (b + 3 < src_row_bytes) {
+      w = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+    } else {
+      for (int u = 0; u < 4; u++)
+        if (b + u < src_row_bytes) w |= (uint32_t)p[u] << (8 * u);
+    }
+    w = recode16(w);
+    long valid = k - 16 * d;  // genotypes of this dword that exist
+    if (valid <= 0) w = 0;
+    else if (valid < 16) w &= (1u << (2 * valid)) - 1u;
+    *reinterpret_cast<uint32_t *>(dst + (size_t)(dst_row0 + r) * dst_pitch + b) = w;
+  }
+}
+
+int launch_recode(const uint8_t *d_src, size_t src_pitch, long row0, long nrows, long k, long /*unused*/,
+                  PackedMatrix &dst, hipStream_t s) {
+  if (nrows <= 0) return 0;
+  const long total = nrows * (long)(dst.pitch >> 2);
+  const int grid = (int)std::min<long>((total + 255) / 256, 256L * 32);
+  hipLaunchKernelGGL(k_recode, dim3(grid), dim3(256), 0, s, d_src, src_pitch, (k + 3) / 4, nrows, k, dst.d, dst.pitch, row0);
+  MXA_HIP(hipGetLastError());
+  return 0;
+}
+
+// =====================================================================================================
+// B -> fragment order
+// =====================================================================================================
+// Bp[S][h][l], S = K-step of 16, h = group of 4 columns, l = lane 0..63 with j = l&3 (column in group),
+// kk = l>>2 (row in K-step): element B[16S+kk][4h+j], zero outside k x n.  One v_mfma_f64_4x4x4_4b_f64 takes the 64
+// doubles of (S,h) as its B operand, lane l <- Bp[S][h][l] (lane map measured on gfx950: B lane = j + 4*blk + 16*k,
+// we assign genotype row 16S + (blk + 4*k) = 16S + (l>>2) to it; tools/mfma_f64_probe2.hip).
+__global__ void __launch_bounds__(256) k_pack_B(const double *__restrict__ B, long ldb, long k, int n,
+                                                double *__restrict__ Bp, long total, int H) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int l = (int)(idx & 63);
+    const long sh = idx >> 6;
+    const int h = (int)(sh % H);
+    const long S = sh / H;
+    const long row = S * 16 + (l >> 2);
+    const int col = 4 * h + (l & 3);
+    double v = 0.0;
+    if (row < k && col < n) v = B[row + (long)col * ldb];
+    Bp[idx] = v;
+  }
+}
+
+int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k_pad, int n_pad, hipStream_t s) {
+  const int H = n_pad / 4;
+  const long total = (k_pad / 16) * (long)H * 64;
+  const int grid = (int)std::min<long>((total + 255) / 256, 256L * 64);
+  hipLaunchKernelGGL(k_pack_B, dim3(grid), dim3(256), 0, s, dB, ldb, k, n, dBp, total, H);
+  MXA_HIP(hipGetLastError());
+  return 0;
+}
+
+// =====================================================================================================
+// deterministic column sums
+// =====================================================================================================
+constexpr int kColChunks = 64;
+
+__global__ void __launch_bounds__(256) k_colsum_partial(const double *__restrict__ B, long ldb, long k,
+                                                        const double *__restrict__ f, double *__restrict__ part) {
+  // grid (kColChunks, n): block sums rows [c0, c1) of column j; fixed thread->row assignment and fixed tree
+  const int j = blockIdx.y, c = blockIdx.x;
+  const long per = (k + kColChunks - 1) / kColChunks;
+  const long c0 = c * per, c1 = std::min<long>(k, c0 + per);
+  double s1 = 0.0, s2 = 0.0;
+  for (long r = c0 + threadIdx.x; r < c1; r += 256) {
+    const double b = B[r + (long)j * ldb];
+    s1 += b;
+    if (f) s2 = fma(f[r], b, s2);
+  }
+  __shared__ double sh1[256], sh2[256];
+  sh1[threadIdx.x] = s1; sh2[threadIdx.x] = s2;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { sh1[threadIdx.x] += sh1[threadIdx.x + w]; sh2[threadIdx.x] += sh2[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[((size_t)j * kColChunks + c) * 2 + 0] = sh1[0];
+    part[((size_t)j * kColChunks + c) * 2 + 1] = sh2[0];
+  }
+}
+
+__global__ void k_colsum_final(const double *__restrict__ part, int n, double *__restrict__ sumB, double *__restrict__ sumfB) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int c = 0; c < kColChunks; c++) { s1 += part[((size_t)j * kColChunks + c) * 2]; s2 += part[((size_t)j * kColChunks + c) * 2 + 1]; }
+  sumB[j] = s1; sumfB[j] = s2;
+}
+
+int launch_colsums(const double *dB, long ldb, long k, int n, const double *d_f, double *d_part, double *d_sumB,
+                   double *d_sumfB, hipStream_t s) {
+  hipLaunchKernelGGL(k_colsum_partial, dim3(kColChunks, n), dim3(256), 0, s, dB, ldb, k, d_f, d_part);
+  hipLaunchKernelGGL(k_colsum_final, dim3((n + 63) / 64), dim3(64), 0, s, d_part, n, d_sumB, d_sumfB);
+  MXA_HIP(hipGetLastError());
+  return 0;
+}
+
+// =====================================================================================================
+// the hot loop
+// =====================================================================================================
+// Work decomposition.  C(m x n) = G(m x k, 2-bit) * B(k x n).  A workgroup (4 waves) owns 4*A*4 rows x 4*C columns
+// for one K range; wave w owns rows [w*4A, (w+1)*4A).  Per K-step of 16 genotypes a wave issues A*C
+// v_mfma_f64_4x4x4_4b_f64:  acc[g][h] (4 rows x 4 cols, K split over the instruction's 4 blocks)
+//   += Ablk(4 rows x 16 k) * Bblk(16 k x 4 cols).
+// The 16x16x4 f64 MFMA issues at ~61 % of the fp64 peak on gfx950 (47.8 of 78.6 TFLOP/s measured), the 4-block
+// 4x4x4 form at 96 % (75.8 TFLOP/s): tools/mfma_f64_probe*.hip, profiles/r01_mfma_f64_probe.txt.
+// Lane maps (measured): A lane = i + 4*blk + 16*kq (row i, K index blk + 4*kq =: lane>>2), B lane = j + 4*blk + 16*kq,
+// D lane = j + 4*blk + 16*i.  The 4 blocks hold partial sums over disjoint K subsets; they are added once, after
+// the K loop, by two cross-lane adds.
+//
+// Data path.  Everything global comes in by LDS-DMA (global_load_lds_dwordx4): per slab of 128 genotypes the B
+// fragments (8 K-steps x C groups x 512 B, lane-linear, so they stream straight in) and the packed genotype rows
+// (32 B per row).  Two LDS buffers; one vmcnt(0)+barrier per slab.  In the compute phase a wave only issues
+// ds_read_b64, 4 integer VALU per genotype fragment (VALU time is NOT hidden beside the fp64 MFMA: the DP pipe is
+// shared) and MFMAs.
+using gptr_t = const __attribute__((address_space(1))) void *;
+using lptr_t = __attribute__((address_space(3))) void *;
+
+__device__ __forceinline__ void dma16(const void *g, void *l) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+template <int A, int C>
+struct GemmCfg {
+  static constexpr int kRowsWave = 4 * A;
+  static constexpr int kRowsWG = kWaves * kRowsWave;
+  static constexpr int kBBytes = kSlabSteps * C * 512;      // B fragments of one slab
+  static constexpr int kABytes = kRowsWG * kSlabBytes;      // packed rows of one slab
+  static constexpr int kBufBytes = kBBytes + kABytes;
+  static constexpr int kLds = 2 * kBufBytes;
+  static constexpr int kBUnits = kBBytes / 1024;            // 1 KiB wave-instruction units
+  static constexpr int kAUnits = kABytes / 1024;
+  static_assert(C % 2 == 0, "C must be even (1 KiB DMA units)");
+  static_assert(kABytes % 1024 == 0, "A tile must be a whole number of DMA units");
+};
+
+template <int A, int C>
+__global__ void __launch_bounds__(256, 2)
+k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ Bp, int H, double *__restrict__ P,
+       long m_pad, int n_pad, int rowblocks, int nchunks, int slabs_total, int slabs_per_split) {
+  using Cfg = GemmCfg<A, C>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int bid = blockIdx.x;
+  const int rb = bid % rowblocks; bid /= rowblocks;
+  const int nc = bid % nchunks;
+  const int sp = bid / nchunks;
+  const int slab0 = sp * slabs_per_split;
+  const int slab1 = min(slab0 + slabs_per_split, slabs_total);
+  const long row0 = (long)rb * Cfg::kRowsWG;
+
+  // ---- DMA issue for one slab into buffer `buf`
+  auto issue = [&](int slab, int buf) {
+    char *base = smem + buf * Cfg::kBufBytes;
+    // B fragments: per K-step ks a contiguous run of C*512 bytes at Bp[(slab*8+ks)*H + nc*C][0]
+#pragma unroll
+    for (int u = wave; u < Cfg::kBUnits; u += kWaves) {
+      const int ks = u / (C / 2), part = u % (C / 2);
+      const char *src = reinterpret_cast<const char *>(Bp) +
+                        (((size_t)(slab * kSlabSteps + ks) * H + (size_t)nc * C) * 512) + part * 1024 + lane * 16;
+      dma16(src, base + u * 1024);
+    }
+    // packed genotype rows: unit = 32 rows x 32 B; lane -> row lane/2, half lane&1
+#pragma unroll
+    for (int u = wave; u < Cfg::kAUnits; u += kWaves) {
+      const long r = row0 + u * 32 + (lane >> 1);
+      const char *src = reinterpret_cast<const char *>(G) + (size_t)r * pitch + (size_t)slab * kSlabBytes + (lane & 1) * 16;
+      dma16(src, base + Cfg::kBBytes + u * 1024);
+    }
+  };
+
+  double acc[A][C];
+#pragma unroll
+  for (int g = 0; g < A; g++)
+#pragma unroll
+    for (int h = 0; h < C; h++) acc[g][h] = 0.0;
+
+  const int sh = 2 * (lane >> 2);                                 // field of this lane inside a 16-genotype dword
+  const int a_off = (wave * Cfg::kRowsWave + (lane & 3)) * kSlabBytes;  // + g*4 rows -> + g*4*32 bytes
+  const int b_off = lane * 8;
+
+  if (slab0 < slab1) issue(slab0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int slab = slab0; slab < slab1; slab++) {
+    const int buf = (slab - slab0) & 1;
+    if (slab + 1 < slab1) issue(slab + 1, buf ^ 1);
+    const char *bbase = smem + buf * Cfg::kBufBytes + b_off;
+    const char *abase = smem + buf * Cfg::kBufBytes + Cfg::kBBytes + a_off;
+#pragma unroll
+    for (int ks2 = 0; ks2 < kSlabSteps / 2; ks2++) {
+      uint2 aw[A];
+#pragma unroll
+      for (int g = 0; g < A; g++) aw[g] = *reinterpret_cast<const uint2 *>(abase + g * 4 * kSlabBytes + ks2 * 8);
+#pragma unroll
+      for (int kk = 0; kk < 2; kk++) {
+        const int ks = 2 * ks2 + kk;
+        double bf[C];
+#pragma unroll
+        for (int h = 0; h < C; h++) bf[h] = *reinterpret_cast<const double *>(bbase + (ks * C + h) * 512);
+#pragma unroll
+        for (int g = 0; g < A; g++) {
+          const uint32_t w = kk ? aw[g].y : aw[g].x;
+          const uint32_t z = (w >> sh) & 3u;                       // v_bfe_u32
+          // exact fp64 of z in {0,1,2}: high word 0 / 0x3FF00000 / 0x40000000, low word 0
+          uint32_t hi = (z << 20) + 0x3FE00000u;
+          hi = z ? hi : 0u;
+          const double af = __hiloint2double((int)hi, 0);
+#pragma unroll
+          for (int h = 0; h < C; h++) acc[g][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(af, bf[h], acc[g][h], 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: add the 4 K-blocks (lane bits 2..3), then lane (j, blk, i) stores column group hq+blk
+  const int j = lane & 3, blk = (lane >> 2) & 3, i = lane >> 4;
+  double *Pbase = P + (size_t)sp * n_pad * m_pad;
+#pragma unroll
+  for (int g = 0; g < A; g++) {
+    const long row = row0 + wave * Cfg::kRowsWave + g * 4 + i;
+#pragma unroll
+    for (int hq = 0; hq < C; hq += 4) {
+      double v[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        double x = (hq + t < C) ? acc[g][hq + t] : 0.0;
+        x += __shfl_xor(x, 4);
+        x += __shfl_xor(x, 8);
+        v[t] = x;
+      }
+      const double out = blk == 0 ? v[0] : blk == 1 ? v[1] : blk == 2 ? v[2] : v[3];
+      if (hq + blk < C) {
+        const int col = 4 * (nc * C + hq + blk) + j;
+        Pbase[(size_t)col * m_pad + row] = out;
+      }
+    }
+  }
+}
+
+GemmPlan plan_gemm(long m, long k_pad, int n) {
+  GemmPlan p{};
+  // tile choice by n: C column groups of 4 per wave pass, A row groups of 4 per wave (A*C = 64 accumulators)
+  if (n <= 8) { p.c = 2; p.a = 16; }
+  else if (n <= 16) { p.c = 4; p.a = 16; }
+  else { p.c = 8; p.a = 8; }
+  const int cols_chunk = 4 * p.c;
+  p.nchunks = (n + cols_chunk - 1) / cols_chunk;
+  p.n_pad = p.nchunks * cols_chunk;
+  const int rows_wg = kWaves * 4 * p.a;
+  p.rowblocks = (int)((m + rows_wg - 1) / rows_wg);
+  p.m_pad = (long)p.rowblocks * rows_wg;
+  p.slabs_total = (int)(k_pad / kSlabK);
+  // aim for >= ~24 rounds of 512 resident workgroups so the tail round is small; keep >= 8 slabs per unit
+  const long units = (long)p.rowblocks * p.nchunks;
+  long want = (12288 + units - 1) / units;
+  long max_splits = std::max<long>(1, p.slabs_total / 8);
+  long splits = std::max<long>(1, std::min<long>(want, max_splits));
+  p.slabs_per_split = (int)((p.slabs_total + splits - 1) / splits);
+  p.splits = (p.slabs_total + p.slabs_per_split - 1) / p.slabs_per_split;
+  if (p.splits < 1) p.splits = 1;
+  return p;
+}
+
+template <int A, int C>
+static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, hipStream_t s) {
+  using Cfg = GemmCfg<A, C>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm<A, C>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds));
+    attr_set = true;
+  }
+  const long grid = (long)p.rowblocks * p.nchunks * p.splits;
+  if (grid > 0x7fffffffL) { set_error(3, "grid too large"); return 1; }
+  hipLaunchKernelGGL((k_gemm<A, C>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBp, p.n_pad / 4, dP,
+                     p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, p.slabs_per_split);
+  MXA_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, hipStream_t s) {
+  // host-side shape checks: the kernel reads rows [0, m_pad) x [0, slabs_total*32) bytes and Bp[(k_pad/16)][H][64]
+  if (p.m_pad > G.rows_pad || (size_t)p.slabs_total * kSlabBytes > G.pitch) {
+    set_error(4, "internal: packed matrix smaller than the launch plan (m_pad %ld > %ld or k bytes %ld > pitch %zu)", p.m_pad,
+              G.rows_pad, (long)p.slabs_total * kSlabBytes, G.pitch);
+    return 1;
+  }
+  if (p.a == 16 && p.c == 2) return launch_gemm_t<16, 2>(G, dBp, dP, p, s);
+  if (p.a == 16 && p.c == 4) return launch_gemm_t<16, 4>(G, dBp, dP, p, s);
+  if (p.a == 8 && p.c == 8) return launch_gemm_t<8, 8>(G, dBp, dP, p, s);
+  set_error(5, "internal: no kernel for tile a=%d c=%d", p.a, p.c);
+  return 1;
+}
+
+// =====================================================================================================
+// finish: split-K reduction (ascending split order) + centring + ldc store
+// =====================================================================================================
+// 'N' (mode_trans=0): C[i,j] = sum_s P + (-2 * sum_k f_k B[k,j])            (x=f, y=1: dgemm_compressed_cuda.cu:426-459)
+// 'T' (mode_trans=1): C[s,j] = sum_s P + (-2 * sum_i B[i,j]) * f_s           (x=1, y=f)
+// rows m..ldc-1 of every column are zero-filled like the reference CPU path does (5codesIntern.h:67).
+__global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, long m_pad, int n_pad, int splits, long m, int n,
+                                                double *__restrict__ Cout, long ldc, int mode_trans, int centered,
+                                                const double *__restrict__ sumB, const double *__restrict__ sumfB,
+                                                const double *__restrict__ f) {
+  const int j = blockIdx.y;
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= ldc) return;
+  double v = 0.0;
+  if (r < m) {
+    for (int s = 0; s < splits; s++) v += P[((size_t)s * n_pad + j) * m_pad + r];
+    if (centered) {
+      if (mode_trans) v = fma(-2.0 * sumB[j], f[r], v);
+      else v += -2.0 * sumfB[j];
+    }
+  }
+  Cout[r + (long)j * ldc] = v;
+}
+
+int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC, long ldc, int mode_trans, bool centered,
+                  const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s) {
+  dim3 grid((unsigned)((ldc + 255) / 256), n);
+  hipLaunchKernelGGL(k_finish, grid, dim3(256), 0, s, dP, p.m_pad, p.n_pad, p.splits, m, n, dC, ldc, mode_trans, centered ? 1 : 0,
+                     d_sumB, d_sumfB, d_f);
+  MXA_HIP(hipGetLastError());
+  return 0;
+}
+
+// =====================================================================================================
+// staging helpers: 2-bit transpose, allele frequencies (raw PLINK codes in, raw codes out)
+// =====================================================================================================
+// 64 x 64 genotype tiles through LDS.  in: `rows` rows of ceil(cols/4) bytes; out: `cols` rows of ceil(rows/4) bytes.
+__global__ void __launch_bounds__(256) k_transpose_2bit(const uint8_t *__restrict__ in, long rows, long cols,
+                                                        uint8_t *__restrict__ out) {
+  __shared__ uint8_t tile[64][17];
+  const long bin = (cols + 3) / 4, bout = (rows + 3) / 4;
+  const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+  {
+    const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
+    for (int u = 0; u < 4; u++) {
+      const long byte = c0 / 4 + part * 4 + u;
+      uint8_t v = 0;
+      if (r0 + r < rows && byte < bin) v = in[(size_t)(r0 + r) * bin + byte];
+      tile[r][part * 4 + u] = v;
+    }
+  }
+  __syncthreads();
+  {
+    const int c = threadIdx.x >> 2, q = threadIdx.x & 3;  // output row c0+c, output bytes 4q..4q+3 of this tile
+    if (c0 + c < cols) {
+      for (int ob = 0; ob < 4; ob++) {
+        const long obyte = r0 / 4 + 4 * q + ob;
+        if (obyte >= bout) break;
+        uint32_t v = 0;
+        for (int u = 0; u < 4; u++) {
+          const int r = 16 * q + 4 * ob + u;
+          uint32_t code = (tile[r][c >> 2] >> (2 * (c & 3))) & 3u;
+          if (r0 + r >= rows) code = 0;
+          v |= code << (2 * u);
+        }
+        out[(size_t)(c0 + c) * bout + obyte] = (uint8_t)v;
+      }
+    }
+  }
+}
+
+int launch_transpose_2bit(const uint8_t *d_in, long rows, long cols, uint8_t *d_out, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return 0;
+  dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
+  hipLaunchKernelGGL(k_transpose_2bit, grid, dim3(256), 0, s, d_in, rows, cols, d_out);
+  MXA_HIP(hipGetLastError());
+  return 0;
+}
+
+// f_s = (sum of allele counts of SNP s, missing counted 0) / (2*indiv); one wave per SNP row
+__global__ void __launch_bounds__(256) k_allele_freq(const uint8_t *__restrict__ plink, long snps, long indiv, double *__restrict__ f) {
+  const long s = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (s >= snps) return;
+  const long bps = (indiv + 3) / 4;
+  const uint8_t *row = plink + (size_t)s * bps;
+  unsigned long long cnt = 0;
+  for (long b = lane; b < bps; b += 64) {
+    uint32_t w = row[b];
+    long valid = indiv - 4 * b;
+    if (valid < 4) w &= (1u << (2 * valid)) - 1u;
+    const uint32_t z = recode16(w);
+    cnt += (z & 3u) + ((z >> 2) & 3u) + ((z >> 4) & 3u) + ((z >> 6) & 3u);
+  }
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if (lane == 0) f[s] = (double)cnt / (2.0 * (double)indiv);
+}
+
+int launch_allele_freq(const uint8_t *d_plink, long snps, long indiv, double *d_f, hipStream_t s) {
+  if (snps <= 0) return 0;
+  hipLaunchKernelGGL(k_allele_freq, dim3((unsigned)((snps + 3) / 4)), dim3(256), 0, s, d_plink, snps, indiv, d_f);
+  MXA_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace mxa

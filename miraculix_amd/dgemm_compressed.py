@@ -1,0 +1,106 @@
+"""Host-side mirror of the reference's Julia module `miraculix.dgemm_compressed`
+(src/bindings/Julia/dgemm_compressed.jl:26-156): same function names, argument meaning and error behaviour, over the
+same C ABI.  Matrices are column-major like Julia's: a numpy array is converted with np.asfortranarray, a torch
+tensor (host or cuda:k) must be 2-D; it is used in place when its memory is column-major (B.t() contiguous)."""
+import ctypes
+
+import numpy as np
+
+from . import lib as _lib
+
+
+def set_options(use_gpu=False, cores=0, not_center=False, variant=0, verbose=1):
+    """dgemm_compressed.jl:42-58.  use_gpu=False is a fatal error in this GPU-only engine (see include/miraculix_amd.h)."""
+    L = _lib.check_library_handle()
+    floatLoop, meanSubstract, ignore_missings, normalize, use_miraculix_freq = 0, 0, 1, 0, 0
+    L.setOptions_compressed(int(use_gpu), int(cores), floatLoop, meanSubstract, ignore_missings, int(not_center), normalize, use_miraculix_freq, int(variant), int(verbose))
+
+
+def check_dimensions(plink, snps, indiv):
+    """miraculix.jl check_dimensions: rows of ceil(indiv/4) bytes, one row per SNP (row-major here)."""
+    nbytes = int(np.prod(plink.shape))
+    if nbytes != snps * ((indiv + 3) // 4):
+        raise ValueError(f"Matrix has wrong dimensions: {tuple(plink.shape)} for snps={snps} indiv={indiv}")
+
+
+def check_storage_object(obj_ref):
+    if obj_ref is None or not obj_ref.value:
+        raise RuntimeError("The storage object points to an uninitialized pointer.")
+
+
+def init_compressed(plink, plink_transposed, snps, indiv, freq, max_ncol):
+    """dgemm_compressed.jl:82-93.  plink: snps rows x ceil(indiv/4) bytes, plink_transposed: indiv rows x ceil(snps/4) bytes
+    (uint8, C-contiguous numpy arrays or torch uint8 tensors, host or device).  Returns the opaque object reference."""
+    obj_ref = ctypes.c_void_p(None)
+    check_dimensions(plink, snps, indiv)
+    check_dimensions(plink_transposed, indiv, snps)
+    L = _lib.check_library_handle()
+    if not _lib.is_torch_tensor(freq):
+        freq = np.ascontiguousarray(freq, dtype=np.float64)
+    L.plink2compressed(_lib.ptr(plink), _lib.ptr(plink_transposed), int(snps), int(indiv), _lib.ptr(freq), int(max_ncol), ctypes.byref(obj_ref))
+    if not obj_ref.value:
+        raise RuntimeError("plink2compressed failed: " + _lib.last_error()[1])
+    return obj_ref
+
+
+def init_compressed_shard(plink, plink_transposed, snps_total, indiv, snp_begin, snp_end, freq, max_ncol):
+    """SNP-sharded variant (mxa_plink2compressed_shard): this object holds SNPs [snp_begin, snp_end) only."""
+    obj_ref = ctypes.c_void_p(None)
+    L = _lib.check_library_handle()
+    if not _lib.is_torch_tensor(freq):
+        freq = np.ascontiguousarray(freq, dtype=np.float64)
+    L.mxa_plink2compressed_shard(_lib.ptr(plink), _lib.ptr(plink_transposed), int(snps_total), int(indiv), int(snp_begin), int(snp_end), _lib.ptr(freq), int(max_ncol), ctypes.byref(obj_ref))
+    if not obj_ref.value:
+        raise RuntimeError("mxa_plink2compressed_shard failed: " + _lib.last_error()[1])
+    return obj_ref
+
+
+def _colmajor(B):
+    """returns (object to keep alive, leading dimension) with column-major storage"""
+    if _lib.is_torch_tensor(B):
+        if B.dim() != 2:
+            raise ValueError("B must be 2-D")
+        if B.shape[1] == 1 and B.stride(0) == 1:
+            return B, B.shape[0]
+        if B.stride(0) == 1 and B.stride(1) >= B.shape[0]:
+            return B, B.stride(1)
+        Bc = B.t().contiguous().t()
+        return Bc, Bc.stride(1) if Bc.shape[1] > 1 else Bc.shape[0]
+    Bf = np.asfortranarray(B, dtype=np.float64)
+    return Bf, Bf.shape[0]
+
+
+def dgemm_compressed_main(transpose, obj_ref, B, snps, indiv, out=None):
+    """dgemm_compressed.jl:114-135.  B: (snps x n) for transpose=False, (indiv x n) for transpose=True.
+    Returns C (indiv x n resp. snps x n): numpy Fortran-ordered for numpy input, torch (column-major) on B's device for
+    torch input.  `out` optionally supplies the (column-major) result buffer."""
+    trans = b"T" if transpose else b"N"
+    n_row, n_col = B.shape
+    if n_row != (indiv if transpose else snps):
+        raise ValueError(f"Matrix B is not compatible with genotype matrix of {snps} SNPs and {indiv} individuals when operation = {trans.decode()} ")
+    check_storage_object(obj_ref)
+    Bc, ldb = _colmajor(B)
+    m = snps if transpose else indiv
+    if out is not None:
+        C = out
+    elif _lib.is_torch_tensor(B):
+        import torch
+        C = torch.zeros((n_col, m), dtype=torch.float64, device=B.device).t()
+    else:
+        C = np.zeros((m, n_col), dtype=np.float64, order="F")
+    Cc, ldc = _colmajor(C)
+    if Cc is not C:
+        raise ValueError("out must be column-major")
+    L = _lib.check_library_handle()
+    L.dgemm_compressed(trans, obj_ref, int(n_col), _lib.ptr(Bc), int(ldb), _lib.ptr(C), int(ldc))
+    err = L.mxa_last_error()
+    if err:
+        raise RuntimeError("dgemm_compressed failed: " + _lib.last_error()[1])
+    return C
+
+
+def free_compressed(obj_ref):
+    """dgemm_compressed.jl:149-156"""
+    check_storage_object(obj_ref)
+    L = _lib.check_library_handle()
+    L.free_compressed(ctypes.byref(obj_ref))

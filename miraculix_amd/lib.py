@@ -1,0 +1,82 @@
+"""Loading of the C-ABI shared library (mirrors src/bindings/Julia/miraculix.jl:60-110: set_library_path /
+load_shared_library / check_library_handle).  There is no fallback: a missing library is an error."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_DEFAULT = os.path.join(_HERE, "lib", "libmiraculix_amd.so")
+_LIBRARY_PATH = [os.environ.get("MIRACULIX_AMD_LIBRARY", _DEFAULT)]
+_LIBRARY_HANDLE = [None]
+
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+
+
+def set_library_path(path):
+    _LIBRARY_PATH[0] = path
+    _LIBRARY_HANDLE[0] = None
+
+
+def load_shared_library():
+    path = _LIBRARY_PATH[0]
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"miraculix_amd: shared library {path} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C miraculix_amd/csrc`. There is no CPU fallback."
+        )
+    L = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    L.setOptions_compressed.argtypes = [ctypes.c_int] * 10
+    L.setOptions_compressed.restype = None
+    L.plink2compressed.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    L.plink2compressed.restype = None
+    L.mxa_plink2compressed_shard.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    L.mxa_plink2compressed_shard.restype = None
+    L.dgemm_compressed.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    L.dgemm_compressed.restype = None
+    L.mxa_dgemm_compressed_device.argtypes = [ctypes.c_char, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_int]
+    L.mxa_dgemm_compressed_device.restype = ctypes.c_int
+    L.free_compressed.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+    L.free_compressed.restype = None
+    L.get_compressed_freq.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.get_compressed_freq.restype = None
+    L.snp_multiply_gpu.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_bool]
+    L.snp_multiply_gpu.restype = ctypes.c_int
+    L.mxa_last_error.restype = ctypes.c_int
+    L.mxa_last_error_string.restype = ctypes.c_char_p
+    L.mxa_device_count.restype = ctypes.c_int
+    L.mxa_transpose_2bit.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_void_p]
+    L.mxa_transpose_2bit.restype = ctypes.c_int
+    L.mxa_allele_freq.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_void_p]
+    L.mxa_allele_freq.restype = ctypes.c_int
+    L.mxa_profile_reset.restype = None
+    L.mxa_profile_get.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]
+    L.mxa_profile_get.restype = None
+    L.mxa_last_geometry.argtypes = [ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    L.mxa_last_geometry.restype = None
+    _LIBRARY_HANDLE[0] = L
+    return L
+
+
+def check_library_handle():
+    """miraculix.jl:29-35 -- error if the library has not been loaded; here it is loaded on first use."""
+    if _LIBRARY_HANDLE[0] is None:
+        load_shared_library()
+    return _LIBRARY_HANDLE[0]
+
+
+def last_error():
+    L = check_library_handle()
+    return L.mxa_last_error(), (L.mxa_last_error_string() or b"").decode()
+
+
+def is_torch_tensor(x):
+    return type(x).__module__.startswith("torch")
+
+
+def ptr(x):
+    """address of a numpy array or a torch tensor (host or device); None -> NULL"""
+    if x is None:
+        return None
+    if is_torch_tensor(x):
+        return ctypes.c_void_p(x.data_ptr())
+    return ctypes.c_void_p(x.ctypes.data)

@@ -1,0 +1,61 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the oracle on the same seeded inputs.
+Mirrors tests/dgemm_compressed/test.jl:88-104 and test_5codesapi{,_t}.f90 of the reference (random B with n=10/15,
+dense (G - 2f) B oracle, max-abs comparison) with a much tighter, stated tolerance."""
+import numpy as np
+import pytest
+
+from _util import Oracle, make_B, make_problem
+
+pytestmark = pytest.mark.gpu
+
+# fp64 tolerance of the path (stated): max|C - C_ref| <= 1e-11 * max|C_ref|
+RTOL = 1e-11
+
+
+@pytest.fixture(scope="module")
+def mx():
+    import miraculix_amd as m
+    m.load_shared_library()
+    return m
+
+
+def _run(mx, prob, trans, B, centered, ldc=None):
+    dg = mx.dgemm_compressed
+    dg.set_options(use_gpu=True, not_center=not centered, verbose=0)
+    obj = dg.init_compressed(prob["plink"], prob["plink_t"], prob["snps"], prob["indiv"], prob["f"], B.shape[0])
+    try:
+        k = prob["indiv"] if trans else prob["snps"]
+        Bcm = np.asfortranarray(B[:, :k].T)  # (k x n) column-major
+        C = dg.dgemm_compressed_main(bool(trans), obj, Bcm, prob["snps"], prob["indiv"])
+    finally:
+        dg.free_compressed(obj)
+    assert obj.value is None
+    return C
+
+
+@pytest.mark.parametrize("snps,indiv,n", [(1000, 500, 1), (1003, 501, 5), (2000, 1000, 7), (777, 1301, 10), (4100, 515, 15), (3001, 2050, 32), (1500, 700, 40)])
+@pytest.mark.parametrize("trans", [0, 1])
+@pytest.mark.parametrize("centered", [0, 1])
+def test_dgemm_vs_oracle(mx, snps, indiv, n, trans, centered):
+    o = Oracle()
+    prob = make_problem(snps, indiv, n, seed=42 + snps)
+    k = indiv if trans else snps
+    m = snps if trans else indiv
+    B = make_B(k, n, seed=43)
+    ref = o.dgemm_dense(trans, prob, B, centered)[:, :m]
+    C = _run(mx, prob, trans, B, centered)
+    assert C.shape == (m, n)
+    err = np.abs(C.T - ref).max() / np.abs(ref).max()
+    assert err <= RTOL, err
+
+
+def test_missing_codes_are_zero_then_centred(mx):
+    o = Oracle()
+    prob = make_problem(1203, 610, 8, seed=7, missing_frac=0.1)
+    for trans in (0, 1):
+        k = prob["indiv"] if trans else prob["snps"]
+        m = prob["snps"] if trans else prob["indiv"]
+        B = make_B(k, 8, seed=5)
+        ref = o.dgemm_dense(trans, prob, B, 1)[:, :m]
+        C = _run(mx, prob, trans, B, 1)
+        assert np.abs(C.T - ref).max() / np.abs(ref).max() <= RTOL
