@@ -7,4 +7,7 @@ the tests and bench.py exactly as the reference's tests use the Julia modules.  
 """
 from . import lib  # noqa: F401
 from . import dgemm_compressed  # noqa: F401
+from . import crossproduct  # noqa: F401
+from . import compressed_operations  # noqa: F401
+from . import read_plink  # noqa: F401
 from .lib import load_shared_library, set_library_path, check_library_handle  # noqa: F401

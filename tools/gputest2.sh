@@ -1,0 +1,3 @@
+set -e
+cd $GRAFT_REPO_ROOT
+timeout -k 10 800 python -m pytest tests -x -q -m gpu 2>&1 | tail -30
