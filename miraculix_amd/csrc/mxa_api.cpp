@@ -226,6 +226,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   Geometry &geo = last_geometry();
   geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c;
   double *d_sumB = w.d_colpart + (size_t)n * 128, *d_sumfB = d_sumB + n;
+  static const int mode = [] { const char *e = getenv("MXA_GEMM_MODE"); return e ? atoi(e) : 0; }();
   if (launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, s)) return 1;
   if (centered && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -233,7 +234,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     MXA_HIP(hipEventCreate(&e0)); MXA_HIP(hipEventCreate(&e1));
     MXA_HIP(hipEventRecord(e0, s));
   }
-  int rc = launch_gemm(G, w.d_Bp, w.d_P, p, s);
+  int rc = launch_gemm(G, w.d_Bp, w.d_P, p, mode, s);
   if (g_profile_on && !rc) MXA_HIP(hipEventRecord(e1, s));
   if (!rc) rc = launch_finish(w.d_P, p, m, n, dC, ldc, trans ? 1 : 0, centered, d_sumB, d_sumfB, h->d_f, s);
   if (g_profile_on) {

@@ -15,6 +15,8 @@
 #include "mxa_internal.h"
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 namespace mxa {
 
@@ -162,6 +164,12 @@ using lptr_t = __attribute__((address_space(3))) void *;
 __device__ __forceinline__ void dma16(const void *g, void *l) {
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
 }
+// LDS-DMA with a wave-uniform 64-bit base in SGPRs, a per-lane 32-bit byte offset and a wave-uniform LDS byte address
+// (M0).  Written as asm so that the per-slab address arithmetic stays on the scalar unit; hipcc does not count this
+// load: the kernel waits with its own s_waitcnt vmcnt(0) before the barrier that precedes the first ds_read of the data.
+__device__ __forceinline__ void dma16_s(const void *sbase, uint32_t voff, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory");
+}
 
 template <int A, int C>
 struct GemmCfg {
@@ -177,10 +185,21 @@ struct GemmCfg {
   static_assert(kABytes % 1024 == 0, "A tile must be a whole number of DMA units");
 };
 
-template <int A, int C>
+// Conversion of a 2-bit allele count z (lane's field of the packed word) to the fp64 MFMA operand, exact in both modes:
+//   MODE 0 (shipped): v_bfe_u32 + v_cvt_f64_u32 -- 2 VALU per fragment, all A fragments of a K-step converted first, then
+//                     the A*C MFMAs back to back (pinned with sched_barrier).
+//   MODE 1 (kept for A/B measurement): v_bfe_u32, v_lshl_add_u32, v_cmp, v_cndmask building the high word by integer ops
+//                     -- 4 VALU per fragment, interleaved with the MFMAs by the compiler.
+// Why it matters: on gfx950 every VALU instruction in an fp64-MFMA stream costs 6-13 cycles of MFMA time, wherever it
+// is placed and whether or not an MFMA depends on it (tools/mfma_f64_probe5.hip, profiles/r01_mfma_f64_probe.txt): the
+// VALU instruction count per MFMA is the lever, not latency hiding.  Measured on MI355X, 200k x 50k x 32:
+// MODE 1 63.6 TFLOP/s, MODE 0 69.7 TFLOP/s; with the LDS-DMA addresses computed on the VALU instead of the scalar
+// unit MODE 0 drops to 65.5.
+template <int A, int C, int MODE, bool DIAG = false>
 __global__ void __launch_bounds__(256, 2)
 k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ Bp, int H, double *__restrict__ P,
-       long m_pad, int n_pad, int rowblocks, int nchunks, int slabs_total, int slabs_per_split) {
+       long m_pad, int n_pad, int rowblocks, int nchunks, int slabs_total, int slabs_per_split,
+       unsigned long long *__restrict__ diag = nullptr) {
   using Cfg = GemmCfg<A, C>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -194,23 +213,32 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
   const int slab1 = min(slab0 + slabs_per_split, slabs_total);
   const long row0 = (long)rb * Cfg::kRowsWG;
 
-  // ---- DMA issue for one slab into buffer `buf`
+  // ---- DMA issue for one slab into buffer `buf`.  Every source address is (wave-uniform 64-bit base) + (per-lane 32-bit
+  // offset that never changes), so the per-slab address arithmetic is scalar: VALU instructions are expensive beside the
+  // fp64 MFMA stream (see MODE comment above).
+  const uint32_t b_lane = lane * 16;
+  const uint32_t a_lane = (uint32_t)(lane >> 1) * (uint32_t)pitch + (lane & 1) * 16;
+  const char *Bp_u = reinterpret_cast<const char *>(Bp) + (size_t)nc * C * 512;
+  const char *G_u = reinterpret_cast<const char *>(G) + (size_t)row0 * pitch;
+  const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
   auto issue = [&](int slab, int buf) {
-    char *base = smem + buf * Cfg::kBufBytes;
+    const uint32_t base = lds0 + buf * Cfg::kBufBytes;
     // B fragments: per K-step ks a contiguous run of C*512 bytes at Bp[(slab*8+ks)*H + nc*C][0]
+    const char *bslab = Bp_u + (size_t)slab * ((size_t)kSlabSteps * H * 512);
 #pragma unroll
-    for (int u = wave; u < Cfg::kBUnits; u += kWaves) {
-      const int ks = u / (C / 2), part = u % (C / 2);
-      const char *src = reinterpret_cast<const char *>(Bp) +
-                        (((size_t)(slab * kSlabSteps + ks) * H + (size_t)nc * C) * 512) + part * 1024 + lane * 16;
-      dma16(src, base + u * 1024);
+    for (int i = 0; i < (Cfg::kBUnits + kWaves - 1) / kWaves; i++) {
+      const int u = wave + i * kWaves;
+      if (Cfg::kBUnits % kWaves == 0 || u < Cfg::kBUnits) {
+        const int ks = u / (C / 2), part = u % (C / 2);
+        dma16_s(bslab + (size_t)ks * H * 512 + part * 1024, b_lane, base + u * 1024);
+      }
     }
     // packed genotype rows: unit = 32 rows x 32 B; lane -> row lane/2, half lane&1
+    const char *aslab = G_u + (size_t)slab * kSlabBytes;
 #pragma unroll
-    for (int u = wave; u < Cfg::kAUnits; u += kWaves) {
-      const long r = row0 + u * 32 + (lane >> 1);
-      const char *src = reinterpret_cast<const char *>(G) + (size_t)r * pitch + (size_t)slab * kSlabBytes + (lane & 1) * 16;
-      dma16(src, base + Cfg::kBBytes + u * 1024);
+    for (int i = 0; i < (Cfg::kAUnits + kWaves - 1) / kWaves; i++) {
+      const int u = wave + i * kWaves;
+      if (Cfg::kAUnits % kWaves == 0 || u < Cfg::kAUnits) dma16_s(aslab + (size_t)(u * 32) * pitch, a_lane, base + Cfg::kBBytes + u * 1024);
     }
   };
 
@@ -227,6 +255,9 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
   if (slab0 < slab1) issue(slab0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  // DIAG build only (never the shipped instantiation): shader-clock and 100 MHz real-time stamps around the K loop
+  unsigned long long t0 = 0, r0 = 0;
+  if (DIAG) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
 
   for (int slab = slab0; slab < slab1; slab++) {
     const int buf = (slab - slab0) & 1;
@@ -244,16 +275,26 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
         double bf[C];
 #pragma unroll
         for (int h = 0; h < C; h++) bf[h] = *reinterpret_cast<const double *>(bbase + (ks * C + h) * 512);
+        if (MODE == 0) {
+          double af[A];
 #pragma unroll
-        for (int g = 0; g < A; g++) {
-          const uint32_t w = kk ? aw[g].y : aw[g].x;
-          const uint32_t z = (w >> sh) & 3u;                       // v_bfe_u32
-          // exact fp64 of z in {0,1,2}: high word 0 / 0x3FF00000 / 0x40000000, low word 0
-          uint32_t hi = (z << 20) + 0x3FE00000u;
-          hi = z ? hi : 0u;
-          const double af = __hiloint2double((int)hi, 0);
+          for (int g = 0; g < A; g++) af[g] = (double)__builtin_amdgcn_ubfe(kk ? aw[g].y : aw[g].x, sh, 2);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int h = 0; h < C; h++) acc[g][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(af, bf[h], acc[g][h], 0, 0, 0);
+          for (int g = 0; g < A; g++)
+#pragma unroll
+            for (int h = 0; h < C; h++) acc[g][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[g], bf[h], acc[g][h], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+          for (int g = 0; g < A; g++) {
+            const uint32_t z = __builtin_amdgcn_ubfe(kk ? aw[g].y : aw[g].x, sh, 2);
+            uint32_t hi = (z << 20) + 0x3FE00000u;   // 1.0 -> 0x3FF00000, 2.0 -> 0x40000000
+            hi = z ? hi : 0u;
+            const double af = __hiloint2double((int)hi, 0);
+#pragma unroll
+            for (int h = 0; h < C; h++) acc[g][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(af, bf[h], acc[g][h], 0, 0, 0);
+          }
         }
       }
     }
@@ -261,6 +302,10 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
     __syncthreads();
   }
 
+  if (DIAG) {
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && diag) { diag[2 * (size_t)blockIdx.x] = t1 - t0; diag[2 * (size_t)blockIdx.x + 1] = r1 - r0; }
+  }
   // ---- epilogue: add the 4 K-blocks (lane bits 2..3), then lane (j, blk, i) stores column group hq+blk
   const int j = lane & 3, blk = (lane >> 2) & 3, i = lane >> 4;
   double *Pbase = P + (size_t)sp * n_pad * m_pad;
@@ -310,32 +355,57 @@ GemmPlan plan_gemm(long m, long k_pad, int n) {
   return p;
 }
 
-template <int A, int C>
+template <int A, int C, int MODE>
 static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, hipStream_t s) {
   using Cfg = GemmCfg<A, C>;
   static bool attr_set = false;
   if (!attr_set) {
-    MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm<A, C>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds));
+    MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm<A, C, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds));
     attr_set = true;
   }
   const long grid = (long)p.rowblocks * p.nchunks * p.splits;
   if (grid > 0x7fffffffL) { set_error(3, "grid too large"); return 1; }
-  hipLaunchKernelGGL((k_gemm<A, C>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBp, p.n_pad / 4, dP,
-                     p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, p.slabs_per_split);
+  static const bool diag_on = getenv("MXA_DIAG") != nullptr;
+  if (diag_on && A == 8 && C == 8) {   // diagnostic instantiation: in-kernel clock + cycles per slab
+    static bool attr2 = false;
+    if (!attr2) { MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm<A, C, MODE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds)); attr2 = true; }
+    unsigned long long *d_diag = nullptr;
+    MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_diag), sizeof(unsigned long long) * 2 * grid));
+    hipLaunchKernelGGL((k_gemm<A, C, MODE, true>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBp, p.n_pad / 4, dP,
+                       p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, p.slabs_per_split, d_diag);
+    MXA_HIP(hipStreamSynchronize(s));
+    std::vector<unsigned long long> h(2 * grid);
+    MXA_HIP(hipMemcpy(h.data(), d_diag, sizeof(unsigned long long) * 2 * grid, hipMemcpyDeviceToHost));
+    std::vector<double> ghz, cyc;
+    for (long i = 0; i < grid; i++) if (h[2 * i + 1]) { ghz.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1); cyc.push_back((double)h[2 * i] / p.slabs_per_split); }
+    std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end());
+    if (!ghz.empty()) printf("MXA_DIAG k_gemm<%d,%d,%d>: grid %ld, in-kernel clock median %.3f GHz (min %.3f max %.3f); shader cycles per slab median %.0f (ideal %d)\n",
+                             A, C, MODE, grid, ghz[ghz.size() / 2], ghz.front(), ghz.back(), cyc[cyc.size() / 2], kSlabSteps * A * C * 16 * 2);
+    (void)hipFree(d_diag);
+    return 0;
+  }
+  hipLaunchKernelGGL((k_gemm<A, C, MODE>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBp, p.n_pad / 4, dP,
+                     p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, p.slabs_per_split, nullptr);
   MXA_HIP(hipGetLastError());
   return 0;
 }
 
-int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, hipStream_t s) {
+int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, int mode, hipStream_t s) {
   // host-side shape checks: the kernel reads rows [0, m_pad) x [0, slabs_total*32) bytes and Bp[(k_pad/16)][H][64]
   if (p.m_pad > G.rows_pad || (size_t)p.slabs_total * kSlabBytes > G.pitch) {
     set_error(4, "internal: packed matrix smaller than the launch plan (m_pad %ld > %ld or k bytes %ld > pitch %zu)", p.m_pad,
               G.rows_pad, (long)p.slabs_total * kSlabBytes, G.pitch);
     return 1;
   }
-  if (p.a == 16 && p.c == 2) return launch_gemm_t<16, 2>(G, dBp, dP, p, s);
-  if (p.a == 16 && p.c == 4) return launch_gemm_t<16, 4>(G, dBp, dP, p, s);
-  if (p.a == 8 && p.c == 8) return launch_gemm_t<8, 8>(G, dBp, dP, p, s);
+#define MXA_DISPATCH(AA, CC)                                              \
+  if (p.a == AA && p.c == CC) {                                           \
+    if (mode == 1) return launch_gemm_t<AA, CC, 1>(G, dBp, dP, p, s);     \
+    return launch_gemm_t<AA, CC, 0>(G, dBp, dP, p, s);                    \
+  }
+  MXA_DISPATCH(16, 2)
+  MXA_DISPATCH(16, 4)
+  MXA_DISPATCH(8, 8)
+#undef MXA_DISPATCH
   set_error(5, "internal: no kernel for tile a=%d c=%d", p.a, p.c);
   return 1;
 }
