@@ -1,0 +1,103 @@
+"""CPU checks of the drop-in boundary: the shared library loads and exports every symbol include/miraculix_amd.h
+declares; host-side option logic behaves like the reference's; no compute is attempted without a GPU and the
+compute entries fail loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "miraculix_amd.h")
+LIB = os.path.join(ROOT, "miraculix_amd", "lib", "libmiraculix_amd.so")
+
+
+@pytest.fixture(scope="module")
+def built():
+    if not os.path.exists(LIB):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "miraculix_amd", "csrc"), "-j4"])
+    return LIB
+
+
+def _declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(\w+)\s*\([^;{]*\)\s*;", text)))
+
+
+def test_header_declares_reference_abi():
+    syms = _declared_symbols()
+    for s in ["setOptions_compressed", "plink2compressed", "dgemm_compressed", "free_compressed", "get_compressed_freq", "snp_multiply_gpu"]:
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol(built):
+    L = ctypes.CDLL(built)
+    for s in _declared_symbols():
+        assert hasattr(L, s), f"{s} declared in include/miraculix_amd.h but not exported"
+
+
+def test_symbols_are_unmangled_c(built):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", built], text=True)
+    names = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    for s in _declared_symbols():
+        assert s in names
+
+
+def _run_py(code):
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=300)
+
+
+def test_use_gpu_zero_is_fatal(built):
+    """GPU-only engine: setOptions_compressed(use_gpu=0, ...) must fail loudly, never fall back to a CPU path"""
+    r = _run_py("import miraculix_amd as m; m.dgemm_compressed.set_options(use_gpu=False)")
+    assert r.returncode != 0
+    assert "GPU" in r.stderr or "MI355X" in r.stderr
+
+
+def test_reference_fatal_option_combination(built):
+    """5codesChar.cc:192-193: gpu && (use_miraculix_freq || !ignore_missings || do_normalize) -> error + exit"""
+    code = ("import ctypes, miraculix_amd as m; L = m.load_shared_library(); "
+            "L.setOptions_compressed(1,0,0,0,{im},0,{norm},{mf},0,0)")
+    for im, norm, mf in [(0, 0, 0), (1, 1, 0), (1, 0, 1)]:
+        r = _run_py(code.format(im=im, norm=norm, mf=mf))
+        assert r.returncode != 0
+        assert "Fortran frequency" in r.stderr
+    r = _run_py(code.format(im=1, norm=0, mf=0))
+    assert r.returncode == 0
+
+
+def test_bad_trans_exits_99(built):
+    """5codesAPI.c:73-77: any trans other than N n T t Y y -> exit(99)"""
+    r = _run_py("import ctypes, miraculix_amd as m; L = m.load_shared_library(); L.dgemm_compressed(b'X', None, 1, None, 1, None, 1)")
+    assert r.returncode == 99
+
+
+def test_uninitialised_object_is_rejected(built):
+    import miraculix_amd as m
+    L = m.load_shared_library()
+    L.dgemm_compressed(b"N", None, 1, None, 1, None, 1)   # prints, sets the error, does not crash
+    assert L.mxa_last_error() != 0
+    with pytest.raises(RuntimeError):
+        m.dgemm_compressed.check_storage_object(ctypes.c_void_p(None))
+
+
+def test_plink2compressed_without_gpu_fails_loudly(built):
+    """on a machine without a HIP device the staging call must leave the handle NULL and report, not compute on the CPU"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = _run_py(
+        "import numpy as np, miraculix_amd as m\n"
+        "dg = m.dgemm_compressed; dg.set_options(use_gpu=True, verbose=0)\n"
+        "p = np.zeros((8, 1), np.uint8); pt = np.zeros((4, 2), np.uint8)\n"
+        "try:\n    dg.init_compressed(p, pt, 8, 4, np.zeros(8), 1)\n    print('NOFAIL')\nexcept RuntimeError as e:\n    print('RAISED', e)\n")
+    assert "RAISED" in r.stdout and "NOFAIL" not in r.stdout
+
+
+def test_missing_library_is_an_error(tmp_path):
+    r = _run_py(f"import miraculix_amd as m; m.set_library_path({str(tmp_path / 'nope.so')!r}); m.load_shared_library()")
+    assert r.returncode != 0 and "no cpu fallback" in r.stderr.lower()

@@ -59,3 +59,34 @@ def test_missing_codes_are_zero_then_centred(mx):
         ref = o.dgemm_dense(trans, prob, B, 1)[:, :m]
         C = _run(mx, prob, trans, B, 1)
         assert np.abs(C.T - ref).max() / np.abs(ref).max() <= RTOL
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_dgemm_vs_reference_golden(mx, idx):
+    """the HIP path against the outputs of the reference's own CPU library (tests/golden/dgemm_golden.npz), through the raw
+    C ABI with the fixtures' leading dimensions (padded ldb with poison, padded ldc zero-filled)"""
+    import ctypes
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dgemm_golden.npz"))
+    name = str(g["names"][idx])
+    snps, indiv, n, ldb_pad, ldc_pad = [int(x) for x in g[f"{name}/dims"]]
+    L = mx.check_library_handle()
+    dg = mx.dgemm_compressed
+    plink, plink_t, f = (np.ascontiguousarray(g[f"{name}/{k}"]) for k in ("plink", "plink_t", "f"))
+    for centered in (0, 1):
+        dg.set_options(use_gpu=True, not_center=not centered, verbose=0)
+        obj = dg.init_compressed(plink, plink_t, snps, indiv, f, n)
+        for trans in (0, 1):
+            k = indiv if trans else snps
+            m = snps if trans else indiv
+            B = np.ascontiguousarray(g[f"{name}/B{trans}"])
+            ref = g[f"{name}/C{trans}{centered}"]
+            C = np.full_like(ref, -777.0)
+            L.dgemm_compressed(b"T" if trans else b"N", obj, n, B.ctypes.data_as(ctypes.c_void_p), k + ldb_pad, C.ctypes.data_as(ctypes.c_void_p), m + ldc_pad)
+            assert L.mxa_last_error() == 0
+            assert np.abs(C - ref).max() <= RTOL * np.abs(ref).max(), (name, trans, centered)
+            assert np.all(C[:, m:] == 0.0)
+        fq = np.zeros(snps)
+        L.get_compressed_freq(obj, fq.ctypes.data_as(ctypes.c_void_p))
+        assert np.array_equal(fq, f)
+        dg.free_compressed(obj)
