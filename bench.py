@@ -95,8 +95,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     os.environ["HIP_DEVICE"] = str(local_rank)
-    if world > 1:
+    force_dist = os.environ.get("MXA_BENCH_FORCE_DIST") == "1"   # exercise the RCCL path with a 1-rank group
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
     import miraculix_amd as mx
@@ -116,6 +119,7 @@ def main():
     del plink, plink_t
     torch.cuda.empty_cache()
     op = ShardedGenotypeOperator(eng, snps, indiv)
+    op.force_collective = force_dist
 
     g = torch.Generator(device=device); g.manual_seed(43)
     B_N = torch.randn((n, snps), dtype=torch.float64, device=device, generator=g)[:, b:e].contiguous().t()   # snps_loc x n, column-major
@@ -130,7 +134,7 @@ def main():
             work.wait()
 
     def sync():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -143,7 +147,7 @@ def main():
         step()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -158,7 +162,17 @@ def main():
     avg_ms = total_ms.value / max(1, launches.value)
     achieved = flops_launch / (avg_ms * 1e-3) * 1e-12 if avg_ms > 0 else 0.0
 
-    # cheap in-run sanity check: adjoint identity  <x, Z y> == <Z^T x, y> on the two resident results' operands
+    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot share a
+    # pass, and bench.py cannot run under its own profiler): tools/pmc_traffic.py stores the per-launch figure measured on
+    # this exact workload under profiles/; it is reported only when the workload matches, else null.
+    traffic = None
+    try:
+        if world == 1 and (snps, indiv, n) == (1_000_000, 50_000, 32):
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+            if cands:
+                traffic = round(json.load(open(os.path.join(ROOT, "profiles", cands[-1])))["traffic_bytes_per_launch_avg"] / 1e9, 3)
+    except Exception:
+        traffic = None
     if rank == 0:
         out = {
             "metric": "effective GFLOP/s for dgemm_compressed (2-bit SNP x fp64)",
@@ -169,14 +183,15 @@ def main():
                                    f"{'centred' if args.centered else 'uncentred'}, SNP-sharded over {world} GPU(s)",
                        "snps": snps, "indiv": indiv, "ncol": n, "parallelism": f"snp-shard{world}"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "GB per launch (rocprofv3 PMC, profiles/)",
+                         "algorithmic_bytes_per_launch_GB": round((snps_loc * ((indiv + 3) // 4) + 8.0 * (snps_loc + indiv) * n) / 1e9, 3),
                          "kernel": "k_gemm<8,8> (v_mfma_f64_4x4x4_4b_f64)", "launches": launches.value, "avg_launch_ms": round(avg_ms, 3)},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -47,13 +47,14 @@ class ShardedGenotypeOperator:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.snps_total, self.indiv = snps_total, indiv
         self.begin, self.end = shard_bounds(snps_total, self.world, self.rank)
+        self.force_collective = False   # bench/tests may set it to run the all-reduce in a 1-rank group
 
     def matmul_N(self, B_local, out=None, async_op=False):
         """B_local: rows [begin, end) of B (snps_local x n).  Returns the full C (indiv x n) on every rank
         (and the all-reduce work handle when async_op)."""
         C = self.engine.multiply(False, B_local, out=out)
         work = None
-        if self.world > 1:
+        if self.world > 1 or (dist.is_initialized() and self.force_collective):
             work = dist.all_reduce(C, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return (C, work) if async_op else C
 
