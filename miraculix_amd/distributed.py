@@ -55,7 +55,11 @@ class ShardedGenotypeOperator:
         C = self.engine.multiply(False, B_local, out=out)
         work = None
         if self.world > 1 or (dist.is_initialized() and self.force_collective):
-            work = dist.all_reduce(C, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            # C is column-major (a transposed view of a contiguous n x ld buffer): reduce the contiguous base
+            flat = C.t() if (C.dim() == 2 and not C.is_contiguous() and C.t().is_contiguous()) else C
+            if not flat.is_contiguous():
+                raise ValueError("matmul_N: result buffer must be column-major or row-major contiguous")
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return (C, work) if async_op else C
 
     def matmul_T(self, B, out=None):
