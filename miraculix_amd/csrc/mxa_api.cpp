@@ -193,7 +193,10 @@ static int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t
   }
   Handle *h = new Handle();
   h->device = dev; h->snps = snps; h->indiv = indiv; h->max_n = std::max(max_n, 1);
-  if (!check_hip(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), __func__, __LINE__)) { destroy_handle(h); return 1; }
+  // a BLOCKING stream: it orders itself against the legacy default stream, so device-resident B produced by work the caller
+  // enqueued on the default stream (e.g. PyTorch ops) is complete before k_pack_B reads it, and later default-stream work sees
+  // C.  Callers on other streams pass theirs to mxa_dgemm_compressed_device.
+  if (!check_hip(hipStreamCreateWithFlags(&h->stream, hipStreamDefault), __func__, __LINE__)) { destroy_handle(h); return 1; }
   if (stage_matrix(h->snp_major, plink, plink_pitch, snps, indiv, h->stream) ||
       stage_matrix(h->ind_major, plink_t, plink_t_pitch, indiv, snps, h->stream)) { destroy_handle(h); return 1; }
   if (!check_hip(hipMalloc(reinterpret_cast<void **>(&h->d_f), sizeof(double) * snps), __func__, __LINE__)) { destroy_handle(h); return 1; }

@@ -218,7 +218,7 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
   const size_t need = xbytes + (out_dev ? 0 : abytes) + (in_dev ? 0 : std::min<size_t>((size_t)rows * row_bytes, (size_t)256 << 20));
   if (need > free_b) { set_error(12, "snp_multiply_gpu: not enough device memory: required %zu GB, free %zu GB", need >> 30, free_b >> 30); return 1; }
   hipStream_t s = nullptr;
-  MXA_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  MXA_HIP(hipStreamCreateWithFlags(&s, hipStreamDefault));   // blocking: ordered against the caller's default-stream work
   uint8_t *d_X = nullptr, *bounce = nullptr;
   double *d_ans = out_dev ? ans : nullptr;
   int rc = 0;

@@ -1,0 +1,93 @@
+"""Parity at BASELINE.json's full single-GPU size (1M SNPs x 50k individuals) through size-independent properties, because the
+oracle cannot run there: exact checksums (B = ones reproduces integer row/column sums that the popcount kernel gives
+independently), the adjoint identity <x, Z y> = <Z^T x, y> tying the two stored orientations together, linearity, and
+agreement of a random row/column sample with the dense oracle.  Exercises 64-bit addressing (12.5 GB per orientation)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from _util import Oracle
+
+pytestmark = pytest.mark.gpu
+
+SNPS, INDIV, N = 1_000_000, 50_000, 32
+
+
+@pytest.fixture(scope="module")
+def big():
+    import torch
+    import miraculix_amd as mx
+    from bench import synth_plink_device
+    mx.load_shared_library()
+    dev = torch.device("cuda", 0)
+    plink = synth_plink_device(torch, SNPS, (INDIV + 3) // 4, 42, dev)
+    plink_t = mx.compressed_operations.transpose_genotype_matrix(plink, SNPS, INDIV)
+    f = mx.read_plink.calc_freq(plink, SNPS, INDIV)
+    dg = mx.dgemm_compressed
+    dg.set_options(use_gpu=True, not_center=True, verbose=0)
+    obj = dg.init_compressed(plink, plink_t, SNPS, INDIV, f, N)
+    yield dict(mx=mx, torch=torch, dev=dev, plink=plink, plink_t=plink_t, f=f, obj=obj, dg=dg)
+    dg.free_compressed(obj)
+
+
+def test_checksums_exact(big):
+    """B = 1: 'T' gives per-SNP allele counts = 2*indiv*f_s, 'N' gives per-individual allele counts; both are integers and
+    must match the independent popcount kernel exactly"""
+    torch, mx, dg = big["torch"], big["mx"], big["dg"]
+    ones_i = torch.ones((INDIV, 1), dtype=torch.float64, device=big["dev"])
+    ct = dg.dgemm_compressed_main(True, big["obj"], ones_i, SNPS, INDIV)          # snps x 1
+    counts_s = torch.round(big["f"] * (2.0 * INDIV))
+    assert torch.equal(ct[:, 0], counts_s)
+    ones_s = torch.ones((SNPS, 1), dtype=torch.float64, device=big["dev"])
+    cn = dg.dgemm_compressed_main(False, big["obj"], ones_s, SNPS, INDIV)         # indiv x 1
+    fi = mx.read_plink.calc_freq(big["plink_t"], INDIV, SNPS)                      # the transposed matrix read as "INDIV SNPs"
+    assert torch.equal(cn[:, 0], torch.round(fi * (2.0 * SNPS)))
+    assert float(cn.sum()) == float(ct.sum())
+
+
+def test_adjoint_identity_and_linearity(big):
+    torch, dg = big["torch"], big["dg"]
+    g = torch.Generator(device=big["dev"]); g.manual_seed(3)
+    Y = torch.randn((N, SNPS), dtype=torch.float64, device=big["dev"], generator=g).t()      # snps x n
+    X = torch.randn((N, INDIV), dtype=torch.float64, device=big["dev"], generator=g).t()     # indiv x n
+    ZY = dg.dgemm_compressed_main(False, big["obj"], Y, SNPS, INDIV)                          # indiv x n
+    ZtX = dg.dgemm_compressed_main(True, big["obj"], X, SNPS, INDIV)                          # snps x n
+    lhs = (X * ZY).sum(dim=0)
+    rhs = (ZtX * Y).sum(dim=0)
+    assert float(((lhs - rhs).abs() / lhs.abs().clamp_min(1.0)).max()) <= 1e-10
+    # linearity: Z (Y + 3 Y2) = Z Y + 3 Z Y2
+    Y2 = torch.randn((N, SNPS), dtype=torch.float64, device=big["dev"], generator=g).t()
+    ZY2 = dg.dgemm_compressed_main(False, big["obj"], Y2, SNPS, INDIV)
+    ZS = dg.dgemm_compressed_main(False, big["obj"], (Y + 3.0 * Y2).t().contiguous().t(), SNPS, INDIV)
+    assert float((ZS - (ZY + 3.0 * ZY2)).abs().max()) <= 1e-11 * float(ZS.abs().max())
+    # bitwise reproducible (fixed split-K order, no atomics)
+    ZY_again = dg.dgemm_compressed_main(False, big["obj"], Y, SNPS, INDIV)
+    assert torch.equal(ZY, ZY_again)
+
+
+def test_sampled_rows_vs_dense_oracle(big):
+    """64 individuals and 64 SNPs of the full-size results against the long-double dense oracle on the extracted sub-matrices"""
+    torch, dg = big["torch"], big["dg"]
+    o = Oracle()
+    g = torch.Generator(device=big["dev"]); g.manual_seed(5)
+    rng = np.random.default_rng(1)
+    # 'N': rows = individuals; oracle needs those individuals' full SNP rows -> build a 64-individual problem
+    ii = np.sort(rng.choice(INDIV, 64, replace=False))
+    Y = torch.randn((4, SNPS), dtype=torch.float64, device=big["dev"], generator=g).t()
+    ZY = dg.dgemm_compressed_main(False, big["obj"], Y, SNPS, INDIV)
+    rows = big["plink_t"][torch.from_numpy(ii).to(big["dev"])].cpu().numpy()                 # 64 x ceil(snps/4)
+    sub_plink = o.transpose_2bit(np.ascontiguousarray(rows), 64, SNPS)                        # snps x 16 bytes
+    prob = dict(snps=SNPS, indiv=64, plink=sub_plink, plink_t=rows, f=np.zeros(SNPS))
+    ref = o.dgemm_dense(0, prob, np.ascontiguousarray(Y.t().cpu().numpy()), 0)               # 4 x 64
+    got = ZY[torch.from_numpy(ii).to(big["dev"])].t().cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-11 * np.abs(ref).max()
+    # 'T': rows = SNPs
+    ss = np.sort(rng.choice(SNPS, 64, replace=False))
+    X = torch.randn((4, INDIV), dtype=torch.float64, device=big["dev"], generator=g).t()
+    ZtX = dg.dgemm_compressed_main(True, big["obj"], X, SNPS, INDIV)
+    srows = big["plink"][torch.from_numpy(ss).to(big["dev"])].cpu().numpy()                   # 64 x ceil(indiv/4)
+    prob = dict(snps=64, indiv=INDIV, plink=np.ascontiguousarray(srows), plink_t=None, f=np.zeros(64))
+    ref = o.dgemm_dense(1, prob, np.ascontiguousarray(X.t().cpu().numpy()), 0)
+    got = ZtX[torch.from_numpy(ss).to(big["dev"])].t().cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-11 * np.abs(ref).max()
