@@ -159,7 +159,9 @@ static int ensure_workspace(Handle *h, int n) {
   const long kmax_pad = std::max(h->snp_major.k_pad, h->ind_major.k_pad);
   GemmPlan pn = plan_gemm(h->indiv, h->ind_major.k_pad, n), pt = plan_gemm(h->snps, h->snp_major.k_pad, n);
   const size_t bp = (size_t)kmax_pad * std::max(pn.n_pad, pt.n_pad);
-  const size_t pp = std::max((size_t)pn.splits * pn.n_pad * pn.m_pad, (size_t)pt.splits * pt.n_pad * pt.m_pad);
+  GemmPlan ln = plan_lut(h->indiv, h->ind_major.k_pad, std::min(n, 4)), lt = plan_lut(h->snps, h->snp_major.k_pad, std::min(n, 4));
+  const size_t pp = std::max(std::max((size_t)pn.splits * pn.n_pad * pn.m_pad, (size_t)pt.splits * pt.n_pad * pt.m_pad),
+                             std::max((size_t)ln.splits * ln.n_pad * ln.m_pad, (size_t)lt.splits * lt.n_pad * lt.m_pad));
   if (grow(&w.d_Bp, &w.cap_Bp, bp)) return 1;
   if (grow(&w.d_P, &w.cap_P, pp)) return 1;
   if (grow(&w.d_colpart, &w.cap_colpart, (size_t)n * (64 * 2 + 2) + 16)) return 1;
@@ -225,19 +227,21 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   if (n > h->max_n) { h->max_n = n; }
   if (ensure_workspace(h, n)) return 1;
   Workspace &w = h->ws;
-  GemmPlan p = plan_gemm(m, G.k_pad, n);
+  static const int lut_max_n = [] { const char *e = getenv("MXA_LUT_MAX_N"); return e ? atoi(e) : 2; }();
+  const bool use_lut = n <= lut_max_n && n <= 4;
+  GemmPlan p = use_lut ? plan_lut(m, G.k_pad, n) : plan_gemm(m, G.k_pad, n);
   Geometry &geo = last_geometry();
   geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c;
   double *d_sumB = w.d_colpart + (size_t)n * 128, *d_sumfB = d_sumB + n;
   static const int mode = [] { const char *e = getenv("MXA_GEMM_MODE"); return e ? atoi(e) : 0; }();
-  if (launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, s)) return 1;
+  if (!use_lut && launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, s)) return 1;
   if (centered && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (g_profile_on) {
     MXA_HIP(hipEventCreate(&e0)); MXA_HIP(hipEventCreate(&e1));
     MXA_HIP(hipEventRecord(e0, s));
   }
-  int rc = launch_gemm(G, w.d_Bp, w.d_P, p, mode, s);
+  int rc = use_lut ? launch_lut(G, dB, ldb, n, w.d_P, p, s) : launch_gemm(G, w.d_Bp, w.d_P, p, mode, s);
   if (g_profile_on && !rc) MXA_HIP(hipEventRecord(e1, s));
   if (!rc) rc = launch_finish(w.d_P, p, m, n, dC, ldc, trans ? 1 : 0, centered, d_sumB, d_sumfB, h->d_f, s);
   if (g_profile_on) {

@@ -155,6 +155,112 @@ k_crossprod(const uint8_t *__restrict__ X, size_t pitch, int stages, const int2 
     }
 }
 
+// ---- v2: 4 waves, one per SIMD, wave tile 128 x 128 (16 accumulator tiles = 256 registers), 3-deep LDS-DMA ring with a
+// counted vmcnt.  Per K-step of 32 genotypes a wave unpacks 8 fragments (56 VALU) for 16 MFMAs (512 MFMA cycles), half the
+// VALU density of v1 (6 fragments per 8 MFMAs), which is what limited v1 (tools/perf_crossprod.py: 43-54 % of the int8 peak).
+constexpr int kX2Waves = 4;
+constexpr int kX2Bufs = 3;
+constexpr int kX2Lds = kX2Bufs * kXBufBytes;      // 48 KiB
+
+__device__ __forceinline__ void xdma16_s(const void *sbase, uint32_t voff, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory");
+}
+
+__global__ void __launch_bounds__(256, 1)
+k_crossprod2(const uint8_t *__restrict__ X, size_t pitch, int stages, const int2 *__restrict__ tiles, long n, double *__restrict__ ans) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wi = wave >> 1, wj = wave & 1;      // wave tile: rows [128*wi, +128) of the I block x rows [128*wj, +128) of the J block
+  const int2 t = tiles[blockIdx.x];
+  const long i0 = (long)t.x * kXT, j0 = (long)t.y * kXT;
+  const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
+  const uint32_t v_lane = (uint32_t)(lane >> 1) * (uint32_t)pitch + (lane & 1) * 16;
+  const char *Xb = reinterpret_cast<const char *>(X);
+
+  // 16 units of 1 KiB per stage (8 per operand), 4 per wave: unit u = wave + 4*i
+  auto issue = [&](int stage, int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int u = wave + 4 * i;
+      const int op = u >> 3, uu = u & 7;
+      const long row = (op ? j0 : i0) + uu * 32;
+      xdma16_s(Xb + (size_t)row * pitch + (size_t)stage * kXStageBytes, v_lane, lds0 + buf * kXBufBytes + op * kXOpBytes + uu * 1024);
+    }
+  };
+
+  v16i acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0;
+
+  const int a_off = (wi * 128 + (lane & 31)) * kXStageBytes + (lane >> 5) * 16;
+  const int b_off = kXOpBytes + (wj * 128 + (lane & 31)) * kXStageBytes + (lane >> 5) * 16;
+
+  issue(0, 0);
+  if (stages > 1) issue(1, 1);
+  if (stages > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int buf = 0;
+  for (int s = 0; s < stages; s++) {
+    if (s + 2 < stages) issue(s + 2, buf == 0 ? 2 : buf - 1 == 0 ? 0 : 1);   // (buf + 2) % 3
+    const char *base = smem + buf * kXBufBytes;
+    uint4 aw[4], bw[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) aw[a] = *reinterpret_cast<const uint4 *>(base + a_off + a * 32 * kXStageBytes);
+#pragma unroll
+    for (int b = 0; b < 4; b++) bw[b] = *reinterpret_cast<const uint4 *>(base + b_off + b * 32 * kXStageBytes);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      v4i bf[4];
+#pragma unroll
+      for (int b = 0; b < 4; b++) bf[b] = unpack16(ks == 0 ? bw[b].x : ks == 1 ? bw[b].y : ks == 2 ? bw[b].z : bw[b].w);
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        const v4i af = unpack16(ks == 0 ? aw[a].x : ks == 1 ? aw[a].y : ks == 2 ? aw[a].z : aw[a].w);
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    // stage s+1 must have landed before anyone reads it; stage s+2 (4 DMAs of this wave) may stay in flight
+    if (s + 2 < stages) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    buf = buf == 2 ? 0 : buf + 1;
+  }
+
+  // epilogue.  32x32 C/D map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); element (gi, gj) = M[gi][gj].
+  // Direct image: ans[gj + gi*n], lanes run along gj (256-byte segments).  Mirror image ans[gi + gj*n]: the tile is transposed
+  // through a per-wave LDS scratch (row stride 33 doubles: conflict-free both ways) so its lanes run along gi as well.
+  double *scratch = reinterpret_cast<double *>(smem) + wave * (32 * 33);   // the DMA ring is dead after the last barrier
+  const int col = lane & 31, hh = lane >> 5, rq = 4 * hh;
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const long gi_base = i0 + wi * 128 + a * 32, gj_base = j0 + wj * 128 + b * 32;
+      const long gj = gj_base + col;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + rq;
+        const double v = (double)acc[a][b][r];
+        if (gi_base + row < n && gj < n) ans[(size_t)gj + (size_t)(gi_base + row) * n] = v;
+        scratch[row * 33 + col] = v;
+      }
+      if (t.x != t.y) {
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+          const int cc = 2 * it + hh;                       // column of the tile = gj offset; lanes (lane&31) run along gi
+          const double v = scratch[col * 33 + cc];
+          const long gi = gi_base + col, gjj = gj_base + cc;
+          if (gi < n && gjj < n) ans[(size_t)gi + (size_t)gjj * n] = v;
+        }
+      }
+    }
+}
+
 int launch_plink_lut(uint8_t *d, size_t nbytes, hipStream_t s) {
   const size_t nd = nbytes / 4;
   const int grid = (int)std::min<size_t>((nd + 255) / 256, 256 * 32);
@@ -183,6 +289,12 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
   hipEvent_t e0, e1;
   MXA_HIP(hipEventCreate(&e0)); MXA_HIP(hipEventCreate(&e1));
   MXA_HIP(hipEventRecord(e0, s));
+  static const int xver = [] { const char *e = getenv("MXA_XPROD_VER"); return e ? atoi(e) : 2; }();
+  if (xver == 2) {
+    static bool attr2 = false;
+    if (!attr2) { MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_crossprod2), hipFuncAttributeMaxDynamicSharedMemorySize, kX2Lds)); attr2 = true; }
+    hipLaunchKernelGGL(k_crossprod2, dim3((unsigned)tiles.size()), dim3(256), kX2Lds, s, d_X, pitch, stages, d_tiles, rows, d_ans);
+  } else
   hipLaunchKernelGGL(k_crossprod, dim3((unsigned)tiles.size()), dim3(512), kXLds, s, d_X, pitch, stages, d_tiles, rows, d_ans);
   MXA_HIP(hipGetLastError());
   MXA_HIP(hipEventRecord(e1, s));

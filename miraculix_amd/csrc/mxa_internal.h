@@ -82,6 +82,8 @@ int launch_colsums(const double *dB, long ldb, long k, int n, const double *d_f 
 struct GemmPlan { int a, c, nchunks, n_pad, splits, slabs_per_split, slabs_total, rowblocks; long m_pad; };
 GemmPlan plan_gemm(long m, long k_pad, int n);
 int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, int mode, hipStream_t s);
+GemmPlan plan_lut(long m, long k_pad, int n);
+int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double *dP, const GemmPlan &p, hipStream_t s);
 int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC, long ldc, int mode_trans,
                   bool centered, const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s);
 int launch_transpose_2bit(const uint8_t *d_in, long rows, long cols, uint8_t *d_out, hipStream_t s);

@@ -411,6 +411,171 @@ int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const Gemm
 }
 
 // =====================================================================================================
+// small-n path (n <= 4): pair-table lookup-add, HBM-bound
+// =====================================================================================================
+// For n = 1 (the CG / GBLUP iteration of config 5) the MFMA tile wastes 7 of 8 columns and sits 5x off the HBM roofline
+// (8 flop per packed byte).  This kernel follows the idea of the reference's CPU "5codes" engine instead
+// (src/miraculix/5codesIntern.h:130-266: a table of partial dot products per group of genotypes, one lookup + one add per
+// group) in a GPU shape: per slab of KS genotypes the workgroup builds, in LDS, one 16-entry table per genotype PAIR
+// (entry v = z0(v)*b[2p] + z1(v)*b[2p+1], one rounding) and every lane walks ITS OWN ROW's nibbles: all 64 lanes of a wave
+// look into the same 128-byte table, whose 9 reachable entries sit in distinct banks, so every ds_read is conflict-free.
+// Per pair and lane: v_bfe_u32 + v_lshlrev (index), ds_read, NV x v_add_f64.  Rows arrive by LDS-DMA with lane <-> row in
+// a chunk-major image [16-byte chunk][row], so the row read is a conflict-free ds_read_b128.
+template <int NV, int KS>
+struct LutCfg {
+  static constexpr int kRows = 256;                       // rows per workgroup, one per lane
+  static constexpr int kChunks = KS / 64;                 // 16-byte chunks per row per slab
+  static constexpr int kRowBytes = kRows * KS / 4;        // packed rows of one slab
+  static constexpr int kTabBytes = (KS / 2) * 16 * 8 * NV;
+  static constexpr int kBufBytes = kRowBytes + kTabBytes;
+  static constexpr int kLds = 2 * kBufBytes;
+};
+
+template <int NV, int KS>
+__global__ void __launch_bounds__(256)
+k_lut(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B, long ldb, long k, int n, double *__restrict__ P,
+      long m_pad, int rowblocks, int slabs_total, int slabs_per_split) {
+  using Cfg = LutCfg<NV, KS>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rb = blockIdx.x % rowblocks, sp = blockIdx.x / rowblocks;
+  const int slab0 = sp * slabs_per_split, slab1 = min(slab0 + slabs_per_split, slabs_total);
+  const long row0 = (long)rb * Cfg::kRows;
+  const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
+  const uint32_t r_lane = (uint32_t)lane * (uint32_t)pitch;
+  const char *G_u = reinterpret_cast<const char *>(G) + (size_t)(row0 + wave * 64) * pitch;
+
+  auto issue_rows = [&](int slab, int buf) {
+    const char *src = G_u + (size_t)slab * (KS / 4);
+#pragma unroll
+    for (int c = 0; c < Cfg::kChunks; c++) dma16_s(src + c * 16, r_lane, lds0 + buf * Cfg::kBufBytes + (c * Cfg::kRows + wave * 64) * 16);
+  };
+  // thread t < KS builds 8 entries of pair table p = t>>1: v = (t&1)*8 + e.  The two B values of the pair are loaded one
+  // slab ahead into registers (global latency hides behind a slab of lookups), the table is written one slab ahead.
+  static_assert(KS / 2 <= 128, "one build pass");
+  const bool builder = (tid >> 1) < KS / 2;
+  auto load_b = [&](int slab, double (&b0)[NV], double (&b1)[NV]) {
+    const long kk = (long)slab * KS + 2 * (tid >> 1);
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      b0[j] = (builder && j < n && kk < k) ? B[kk + (long)j * ldb] : 0.0;
+      b1[j] = (builder && j < n && kk + 1 < k) ? B[kk + 1 + (long)j * ldb] : 0.0;
+    }
+  };
+  auto build = [&](int buf, const double (&b0)[NV], const double (&b1)[NV]) {
+    if (!builder) return;
+    double *tab = reinterpret_cast<double *>(smem + buf * Cfg::kBufBytes + Cfg::kRowBytes);
+    const int p = tid >> 1;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int v = (tid & 1) * 8 + e;
+      const double z0 = (double)(v & 3), z1 = (double)(v >> 2);
+#pragma unroll
+      for (int j = 0; j < NV; j++) tab[((size_t)p * 16 + v) * NV + j] = fma(z1, b1[j], z0 * b0[j]);
+    }
+  };
+
+  double acc[4][NV];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int j = 0; j < NV; j++) acc[a][j] = 0.0;
+
+  double bc0[NV], bc1[NV], bn0[NV], bn1[NV];
+  if (slab0 < slab1) {
+    issue_rows(slab0, 0);
+    load_b(slab0, bc0, bc1);
+    build(0, bc0, bc1);
+    if (slab0 + 1 < slab1) load_b(slab0 + 1, bc0, bc1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int slab = slab0; slab < slab1; slab++) {
+    const int buf = (slab - slab0) & 1;
+    if (slab + 1 < slab1) {
+      issue_rows(slab + 1, buf ^ 1);
+      if (slab + 2 < slab1) load_b(slab + 2, bn0, bn1);
+      build(buf ^ 1, bc0, bc1);
+#pragma unroll
+      for (int j = 0; j < NV; j++) { bc0[j] = bn0[j]; bc1[j] = bn1[j]; }
+    }
+    const char *rows = smem + buf * Cfg::kBufBytes + tid * 16;
+    // LDS byte address of the table region of this buffer (128-byte aligned, so the entry index can be OR-ed in)
+    const uint32_t tab = lds0 + buf * Cfg::kBufBytes + Cfg::kRowBytes;
+#pragma unroll
+    for (int c = 0; c < Cfg::kChunks; c++) {
+      const uint4 w4 = *reinterpret_cast<const uint4 *>(rows + c * Cfg::kRows * 16);
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        const uint32_t w = d == 0 ? w4.x : d == 1 ? w4.y : d == 2 ? w4.z : w4.w;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          // v_bfe_u32 + v_lshl_or_b32: address = table region | (nibble * entry size); the pair's table is the immediate offset
+          const uint32_t idx = __builtin_amdgcn_ubfe(w, 4 * q, 4);
+          uint32_t addr;   // asm keeps the 2-instruction form (hipcc otherwise rewrites it into shift + and + or)
+          if (NV == 1) asm("v_lshl_or_b32 %0, %1, 3, %2" : "=v"(addr) : "v"(idx), "v"(tab));
+          else if (NV == 2) asm("v_lshl_or_b32 %0, %1, 4, %2" : "=v"(addr) : "v"(idx), "v"(tab));
+          else asm("v_lshl_or_b32 %0, %1, 5, %2" : "=v"(addr) : "v"(idx), "v"(tab));
+          __builtin_assume((addr & (8 * NV - 1)) == 0);   // the asm hides the alignment: without this the read is split into dwords
+          using lds_cd = const __attribute__((address_space(3))) double;
+          lds_cd *e = (lds_cd *)(size_t)(addr + (c * 32 + d * 8 + q) * 16 * 8 * NV);
+#pragma unroll
+          for (int j = 0; j < NV; j++) acc[q & 3][j] += e[j];
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  double *Pbase = P + (size_t)sp * NV * m_pad;
+#pragma unroll
+  for (int j = 0; j < NV; j++) Pbase[(size_t)j * m_pad + row0 + tid] = (acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j]);
+}
+
+template <int NV, int KS>
+static int launch_lut_t(const PackedMatrix &G, const double *dB, long ldb, int n, double *dP, const GemmPlan &p, hipStream_t s) {
+  using Cfg = LutCfg<NV, KS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lut<NV, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds));
+    attr_set = true;
+  }
+  const long grid = (long)p.rowblocks * p.splits;
+  hipLaunchKernelGGL((k_lut<NV, KS>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dB, ldb, G.k, n, dP, p.m_pad, p.rowblocks,
+                     p.slabs_total, p.slabs_per_split);
+  MXA_HIP(hipGetLastError());
+  return 0;
+}
+
+constexpr int kLutKS = 128;   // genotypes per slab of the lookup kernel (= kSlabK, so the staged pitch fits)
+constexpr int kLutMaxN = 2;   // n <= 2 uses the lookup kernel (n = 4 measured slower than the MFMA (16,2) tile)
+
+GemmPlan plan_lut(long m, long k_pad, int n) {
+  GemmPlan p{};
+  p.a = 0; p.c = 0;
+  p.n_pad = n <= 1 ? 1 : n <= 2 ? 2 : 4;
+  p.nchunks = 1;
+  p.rowblocks = (int)((m + 255) / 256);
+  p.m_pad = (long)p.rowblocks * 256;
+  p.slabs_total = (int)(k_pad / kLutKS);
+  const long units = p.rowblocks;
+  long want = (8192 + units - 1) / units;
+  long max_splits = std::max<long>(1, p.slabs_total / 16);
+  long splits = std::max<long>(1, std::min<long>(want, max_splits));
+  p.slabs_per_split = (int)((p.slabs_total + splits - 1) / splits);
+  p.splits = (p.slabs_total + p.slabs_per_split - 1) / p.slabs_per_split;
+  return p;
+}
+
+int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double *dP, const GemmPlan &p, hipStream_t s) {
+  if (p.m_pad > G.rows_pad || (size_t)p.slabs_total * (kLutKS / 4) > G.pitch) { set_error(4, "internal: packed matrix smaller than the lookup plan"); return 1; }
+  if (p.n_pad == 1) return launch_lut_t<1, kLutKS>(G, dB, ldb, n, dP, p, s);
+  if (p.n_pad == 2) return launch_lut_t<2, kLutKS>(G, dB, ldb, n, dP, p, s);
+  return launch_lut_t<4, kLutKS>(G, dB, ldb, n, dP, p, s);
+}
+
+// =====================================================================================================
 // finish: split-K reduction (ascending split order) + centring + ldc store
 // =====================================================================================================
 // 'N' (mode_trans=0): C[i,j] = sum_s P + (-2 * sum_k f_k B[k,j])            (x=f, y=1: dgemm_compressed_cuda.cu:426-459)

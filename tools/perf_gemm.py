@@ -36,5 +36,7 @@ for trans in (False, True):
     L.mxa_profile_get(ctypes.byref(la), ctypes.byref(ms))
     avg = ms.value / la.value
     fl = 2.0 * snps * indiv * n
-    print(f"mode={os.environ.get('MXA_GEMM_MODE','0')} {'T' if trans else 'N'} snps={snps} indiv={indiv} n={n}: kernel {avg:.3f} ms = {fl/avg*1e-9:.2f} TFLOP/s; call wall {wall*1e3:.3f} ms = {fl/wall*1e-12:.2f} TFLOP/s", flush=True)
+    gm, gk, gn, gs, ga, gc = ctypes.c_long(), ctypes.c_long(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    L.mxa_last_geometry(ctypes.byref(gm), ctypes.byref(gk), ctypes.byref(gn), ctypes.byref(gs), ctypes.byref(ga), ctypes.byref(gc))
+    print(f"tile=({ga.value},{gc.value}) splits={gs.value} mode={os.environ.get('MXA_GEMM_MODE','0')} {'T' if trans else 'N'} snps={snps} indiv={indiv} n={n}: kernel {avg:.3f} ms = {fl/avg*1e-9:.2f} TFLOP/s; call wall {wall*1e3:.3f} ms = {fl/wall*1e-12:.2f} TFLOP/s", flush=True)
 dg.free_compressed(obj)
