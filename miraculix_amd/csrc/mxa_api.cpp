@@ -112,6 +112,7 @@ static int stage_matrix(PackedMatrix &M, const uint8_t *src, size_t src_pitch, l
   M.rows_pad = (rows + kRowAlign - 1) / kRowAlign * kRowAlign;
   M.k_pad = (k + kSlabK - 1) / kSlabK * kSlabK;
   M.pitch = (size_t)M.k_pad / 4;
+  M.nslabs = M.k_pad / kSlabK;
   const size_t bytes = (size_t)M.rows_pad * M.pitch;
   MXA_HIP(hipMalloc(reinterpret_cast<void **>(&M.d), bytes));
   MXA_HIP(hipMemsetAsync(M.d, 0, bytes, s));

@@ -12,7 +12,9 @@ constexpr int kKStep = 16;         // genotypes consumed by one v_mfma_f64_4x4x4
 constexpr int kSlabSteps = 8;      // K-steps per LDS slab
 constexpr int kSlabK = kKStep * kSlabSteps;   // 128 genotypes = 32 packed bytes per row per slab
 constexpr int kSlabBytes = kSlabK / 4;
-constexpr int kRowAlign = 256;     // packed matrices are padded to a multiple of this many rows
+constexpr int kRowAlign = 512;     // packed matrices are padded to a multiple of this many rows (two tiles: the lookup kernel's row block)
+constexpr int kTileRows = 256;     // rows per HBM tile
+constexpr int kTileBytes = kTileRows * kSlabBytes;   // 8 KiB
 
 struct Options {
   bool gpu = true;
@@ -24,13 +26,18 @@ Options &options();
 int env_print_level();
 
 // One packed, recoded genotype matrix resident in HBM: `rows` rows of `k` genotypes, 2 bits each holding the
-// allele count z in {0,1,2} (PLINK code 01 "missing" already mapped to 0), row pitch `pitch` bytes (multiple of
-// kSlabBytes, zero padded), rows padded with zero rows up to rows_pad.
+// allele count z in {0,1,2} (PLINK code 01 "missing" already mapped to 0), zero padded to rows_pad x k_pad.
+// TILED layout: the matrix is cut into tiles of kTileRows rows x one slab (kSlabK genotypes = kSlabBytes bytes per
+// row); a tile is stored as kTileRows consecutive 32-byte row pieces (8 KiB), tiles of one row block are consecutive
+// along K:   byte b of row r  ->  ((r / 256) * nslabs + b / 32) * 8192 + (r % 256) * 32 + b % 32.
+// Every slab a workgroup needs is then one contiguous 4-8 KiB run, so the LDS-DMA is lane-linear on both sides and HBM is
+// read in whole lines exactly once.  `pitch` = nslabs * kSlabBytes is the logical row length in bytes.
 struct PackedMatrix {
   uint8_t *d = nullptr;
   long rows = 0, k = 0;
   long rows_pad = 0, k_pad = 0;
   size_t pitch = 0;
+  long nslabs = 0;
 };
 
 struct Workspace {

@@ -31,7 +31,7 @@ __device__ __forceinline__ uint32_t recode16(uint32_t w) {
 
 __global__ void __launch_bounds__(256) k_recode(const uint8_t *__restrict__ src, size_t src_pitch, long src_row_bytes,
                                                 long nrows, long k, uint8_t *__restrict__ dst, size_t dst_pitch,
-                                                long dst_row0) {
+                                                long dst_row0, long nslabs) {
   const long dwords_per_row = (long)(dst_pitch >> 2);
   const long total = nrows * dwords_per_row;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -49,7 +49,10 @@ __global__ void __launch_bounds__(256) k_recode(const uint8_t *__restrict__ src,
     long valid = k - 16 * d;  // genotypes of this dword that exist
     if (valid <= 0) w = 0;
     else if (valid < 16) w &= (1u << (2 * valid)) - 1u;
-    *reinterpret_cast<uint32_t *>(dst + (size_t)(dst_row0 + r) * dst_pitch + b) = w;
+    // tiled layout (mxa_internal.h): byte b of row R -> ((R/256)*nslabs + b/32)*8192 + (R%256)*32 + b%32
+    const long R = dst_row0 + r;
+    const size_t off = ((size_t)(R / kTileRows) * nslabs + (size_t)(b / kSlabBytes)) * kTileBytes + (size_t)(R % kTileRows) * kSlabBytes + (b % kSlabBytes);
+    *reinterpret_cast<uint32_t *>(dst + off) = w;
   }
 }
 
@@ -58,7 +61,7 @@ int launch_recode(const uint8_t *d_src, size_t src_pitch, long row0, long nrows,
   if (nrows <= 0) return 0;
   const long total = nrows * (long)(dst.pitch >> 2);
   const int grid = (int)std::min<long>((total + 255) / 256, 256L * 32);
-  hipLaunchKernelGGL(k_recode, dim3(grid), dim3(256), 0, s, d_src, src_pitch, (k + 3) / 4, nrows, k, dst.d, dst.pitch, row0);
+  hipLaunchKernelGGL(k_recode, dim3(grid), dim3(256), 0, s, d_src, src_pitch, (k + 3) / 4, nrows, k, dst.d, dst.pitch, row0, dst.nslabs);
   MXA_HIP(hipGetLastError());
   return 0;
 }
@@ -217,9 +220,11 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
   // offset that never changes), so the per-slab address arithmetic is scalar: VALU instructions are expensive beside the
   // fp64 MFMA stream (see MODE comment above).
   const uint32_t b_lane = lane * 16;
-  const uint32_t a_lane = (uint32_t)(lane >> 1) * (uint32_t)pitch + (lane & 1) * 16;
+  const uint32_t a_lane = lane * 16;
   const char *Bp_u = reinterpret_cast<const char *>(Bp) + (size_t)nc * C * 512;
-  const char *G_u = reinterpret_cast<const char *>(G) + (size_t)row0 * pitch;
+  // tiled layout: the rows [row0, row0 + kRowsWG) of slab s are one contiguous run inside tile (row0/256, s)
+  const size_t nslabs_all = pitch / kSlabBytes;
+  const char *G_u = reinterpret_cast<const char *>(G) + (size_t)(row0 / kTileRows) * nslabs_all * kTileBytes + (size_t)(row0 % kTileRows) * kSlabBytes;
   const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
   auto issue = [&](int slab, int buf) {
     const uint32_t base = lds0 + buf * Cfg::kBufBytes;
@@ -233,12 +238,12 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
         dma16_s(bslab + (size_t)ks * H * 512 + part * 1024, b_lane, base + u * 1024);
       }
     }
-    // packed genotype rows: unit = 32 rows x 32 B; lane -> row lane/2, half lane&1
-    const char *aslab = G_u + (size_t)slab * kSlabBytes;
+    // packed genotype rows: unit = 32 rows x 32 B = 1 KiB, contiguous in the tiled layout
+    const char *aslab = G_u + (size_t)slab * kTileBytes;
 #pragma unroll
     for (int i = 0; i < (Cfg::kAUnits + kWaves - 1) / kWaves; i++) {
       const int u = wave + i * kWaves;
-      if (Cfg::kAUnits % kWaves == 0 || u < Cfg::kAUnits) dma16_s(aslab + (size_t)(u * 32) * pitch, a_lane, base + Cfg::kBBytes + u * 1024);
+      if (Cfg::kAUnits % kWaves == 0 || u < Cfg::kAUnits) dma16_s(aslab + u * 1024, a_lane, base + Cfg::kBBytes + u * 1024);
     }
   };
 
@@ -421,9 +426,10 @@ int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const Gemm
 // look into the same 128-byte table, whose 9 reachable entries sit in distinct banks, so every ds_read is conflict-free.
 // Per pair and lane: v_bfe_u32 + v_lshlrev (index), ds_read, NV x v_add_f64.  Rows arrive by LDS-DMA with lane <-> row in
 // a chunk-major image [16-byte chunk][row], so the row read is a conflict-free ds_read_b128.
-template <int NV, int KS>
+template <int NV, int KS, int WV>
 struct LutCfg {
-  static constexpr int kRows = 256;                       // rows per workgroup, one per lane
+  static constexpr int kThreads = 64 * WV;
+  static constexpr int kRows = kThreads;                  // rows per workgroup, one per lane
   static constexpr int kChunks = KS / 64;                 // 16-byte chunks per row per slab
   static constexpr int kRowBytes = kRows * KS / 4;        // packed rows of one slab
   static constexpr int kTabBytes = (KS / 2) * 16 * 8 * NV;
@@ -431,11 +437,11 @@ struct LutCfg {
   static constexpr int kLds = 2 * kBufBytes;
 };
 
-template <int NV, int KS>
-__global__ void __launch_bounds__(256)
+template <int NV, int KS, int WV>
+__global__ void __launch_bounds__(64 * WV)
 k_lut(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B, long ldb, long k, int n, double *__restrict__ P,
       long m_pad, int rowblocks, int slabs_total, int slabs_per_split) {
-  using Cfg = LutCfg<NV, KS>;
+  using Cfg = LutCfg<NV, KS, WV>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -443,37 +449,41 @@ k_lut(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B,
   const int slab0 = sp * slabs_per_split, slab1 = min(slab0 + slabs_per_split, slabs_total);
   const long row0 = (long)rb * Cfg::kRows;
   const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
-  const uint32_t r_lane = (uint32_t)lane * (uint32_t)pitch;
-  const char *G_u = reinterpret_cast<const char *>(G) + (size_t)(row0 + wave * 64) * pitch;
+  // tiled layout: tile (row0/256 + wave/4, slab) holds 256 rows x 32 B contiguously; lane <-> row, one 16-byte chunk per
+  // instruction, so the LDS image is chunk-major [chunk][row] (conflict-free ds_read_b128 per lane)
+  static_assert(KS == kSlabK, "the lookup kernel walks the staged slabs");
+  const uint32_t r_lane = (uint32_t)lane * kSlabBytes;
+  const char *G_u = reinterpret_cast<const char *>(G) + (size_t)(row0 / kTileRows + (wave >> 2)) * (pitch / kSlabBytes) * kTileBytes +
+                    (size_t)((wave & 3) * 64) * kSlabBytes;
 
   auto issue_rows = [&](int slab, int buf) {
-    const char *src = G_u + (size_t)slab * (KS / 4);
+    const char *src = G_u + (size_t)slab * kTileBytes;
 #pragma unroll
     for (int c = 0; c < Cfg::kChunks; c++) dma16_s(src + c * 16, r_lane, lds0 + buf * Cfg::kBufBytes + (c * Cfg::kRows + wave * 64) * 16);
   };
-  // thread t < KS builds 8 entries of pair table p = t>>1: v = (t&1)*8 + e.  The two B values of the pair are loaded one
-  // slab ahead into registers (global latency hides behind a slab of lookups), the table is written one slab ahead.
-  static_assert(KS / 2 <= 128, "one build pass");
-  const bool builder = (tid >> 1) < KS / 2;
-  auto load_b = [&](int slab, double (&b0)[NV], double (&b1)[NV]) {
-    const long kk = (long)slab * KS + 2 * (tid >> 1);
+  // Table build: the slab has KS/2 pair tables x 16 entries; thread t writes entries q = t + T*e (pair q>>4, nibble q&15), so a
+  // wave writes 64 consecutive entries (conflict-free ds_write).  The pair's two B values are loaded one slab ahead into
+  // registers (global latency hides behind a slab of lookups), the table is written one slab ahead of its use.
+  constexpr int kEnt = (KS / 2) * 16 / Cfg::kThreads;       // entries per thread per slab
+  static_assert((KS / 2) * 16 % Cfg::kThreads == 0, "whole entries per thread");
+  auto load_b = [&](int slab, double (&b0)[kEnt][NV], double (&b1)[kEnt][NV]) {
 #pragma unroll
-    for (int j = 0; j < NV; j++) {
-      b0[j] = (builder && j < n && kk < k) ? B[kk + (long)j * ldb] : 0.0;
-      b1[j] = (builder && j < n && kk + 1 < k) ? B[kk + 1 + (long)j * ldb] : 0.0;
+    for (int e = 0; e < kEnt; e++) {
+      const long kk = (long)slab * KS + 2 * ((tid + Cfg::kThreads * e) >> 4);
+#pragma unroll
+      for (int j = 0; j < NV; j++) {
+        b0[e][j] = (j < n && kk < k) ? B[kk + (long)j * ldb] : 0.0;
+        b1[e][j] = (j < n && kk + 1 < k) ? B[kk + 1 + (long)j * ldb] : 0.0;
+      }
     }
   };
-  auto build = [&](int buf, const double (&b0)[NV], const double (&b1)[NV]) {
-    if (!builder) return;
+  auto build = [&](int buf, const double (&b0)[kEnt][NV], const double (&b1)[kEnt][NV]) {
     double *tab = reinterpret_cast<double *>(smem + buf * Cfg::kBufBytes + Cfg::kRowBytes);
-    const int p = tid >> 1;
+    const double z0 = (double)(tid & 3), z1 = (double)((tid >> 2) & 3);
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-      const int v = (tid & 1) * 8 + e;
-      const double z0 = (double)(v & 3), z1 = (double)(v >> 2);
+    for (int e = 0; e < kEnt; e++)
 #pragma unroll
-      for (int j = 0; j < NV; j++) tab[((size_t)p * 16 + v) * NV + j] = fma(z1, b1[j], z0 * b0[j]);
-    }
+      for (int j = 0; j < NV; j++) tab[(size_t)(tid + Cfg::kThreads * e) * NV + j] = fma(z1, b1[e][j], z0 * b0[e][j]);
   };
 
   double acc[4][NV];
@@ -482,7 +492,7 @@ k_lut(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B,
 #pragma unroll
     for (int j = 0; j < NV; j++) acc[a][j] = 0.0;
 
-  double bc0[NV], bc1[NV], bn0[NV], bn1[NV];
+  double bc0[kEnt][NV], bc1[kEnt][NV], bn0[kEnt][NV], bn1[kEnt][NV];
   if (slab0 < slab1) {
     issue_rows(slab0, 0);
     load_b(slab0, bc0, bc1);
@@ -498,7 +508,9 @@ k_lut(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B,
       if (slab + 2 < slab1) load_b(slab + 2, bn0, bn1);
       build(buf ^ 1, bc0, bc1);
 #pragma unroll
-      for (int j = 0; j < NV; j++) { bc0[j] = bn0[j]; bc1[j] = bn1[j]; }
+      for (int e = 0; e < kEnt; e++)
+#pragma unroll
+        for (int j = 0; j < NV; j++) { bc0[e][j] = bn0[e][j]; bc1[e][j] = bn1[e][j]; }
     }
     const char *rows = smem + buf * Cfg::kBufBytes + tid * 16;
     // LDS byte address of the table region of this buffer (128-byte aligned, so the entry index can be OR-ed in)
@@ -533,17 +545,19 @@ k_lut(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B,
   for (int j = 0; j < NV; j++) Pbase[(size_t)j * m_pad + row0 + tid] = (acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j]);
 }
 
+constexpr int kLutWaves = 8;   // 512 lanes = 512 rows per workgroup share one set of tables
+
 template <int NV, int KS>
 static int launch_lut_t(const PackedMatrix &G, const double *dB, long ldb, int n, double *dP, const GemmPlan &p, hipStream_t s) {
-  using Cfg = LutCfg<NV, KS>;
+  using Cfg = LutCfg<NV, KS, kLutWaves>;
   static bool attr_set = false;
   if (!attr_set) {
-    MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lut<NV, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds));
+    MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lut<NV, KS, kLutWaves>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds));
     attr_set = true;
   }
   const long grid = (long)p.rowblocks * p.splits;
-  hipLaunchKernelGGL((k_lut<NV, KS>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dB, ldb, G.k, n, dP, p.m_pad, p.rowblocks,
-                     p.slabs_total, p.slabs_per_split);
+  hipLaunchKernelGGL((k_lut<NV, KS, kLutWaves>), dim3((unsigned)grid), dim3(Cfg::kThreads), Cfg::kLds, s, G.d, G.pitch, dB, ldb, G.k, n, dP, p.m_pad,
+                     p.rowblocks, p.slabs_total, p.slabs_per_split);
   MXA_HIP(hipGetLastError());
   return 0;
 }
@@ -556,11 +570,12 @@ GemmPlan plan_lut(long m, long k_pad, int n) {
   p.a = 0; p.c = 0;
   p.n_pad = n <= 1 ? 1 : n <= 2 ? 2 : 4;
   p.nchunks = 1;
-  p.rowblocks = (int)((m + 255) / 256);
-  p.m_pad = (long)p.rowblocks * 256;
+  p.rowblocks = (int)((m + 64 * kLutWaves - 1) / (64 * kLutWaves));
+  p.m_pad = (long)p.rowblocks * 64 * kLutWaves;
   p.slabs_total = (int)(k_pad / kLutKS);
   const long units = p.rowblocks;
-  long want = (8192 + units - 1) / units;
+  static const long target = [] { const char *e = getenv("MXA_LUT_UNITS"); return e ? atol(e) : 8192L; }();
+  long want = (target + units - 1) / units;
   long max_splits = std::max<long>(1, p.slabs_total / 16);
   long splits = std::max<long>(1, std::min<long>(want, max_splits));
   p.slabs_per_split = (int)((p.slabs_total + splits - 1) / splits);
