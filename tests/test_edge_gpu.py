@@ -1,0 +1,100 @@
+"""Edge cases of the C ABI on the GPU: tiny and ragged dimensions, n larger than max_n (workspace growth), wide n that
+spans several column chunks, repeated and interleaved calls on one object, two objects alive at once, switching centring
+between calls, n = 0."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from _util import Oracle, make_B, make_problem
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-11
+
+
+@pytest.fixture(scope="module")
+def mx():
+    import miraculix_amd as m
+    m.load_shared_library()
+    return m
+
+
+def _check(mx, o, obj, prob, trans, n, centered, seed=1):
+    k = prob["indiv"] if trans else prob["snps"]
+    m = prob["snps"] if trans else prob["indiv"]
+    B = make_B(k, n, seed=seed)
+    C = mx.dgemm_compressed.dgemm_compressed_main(bool(trans), obj, np.asfortranarray(B.T), prob["snps"], prob["indiv"])
+    ref = o.dgemm_dense(trans, prob, B, centered)[:, :m]
+    scale = max(np.abs(ref).max(), 1e-300)
+    assert np.abs(C.T - ref).max() <= RTOL * scale, (trans, n)
+
+
+@pytest.mark.parametrize("snps,indiv", [(1, 1), (3, 2), (5, 7), (127, 129), (128, 128), (129, 127), (513, 3), (2, 600)])
+def test_tiny_and_ragged_dims(mx, snps, indiv):
+    o = Oracle()
+    prob = make_problem(snps, indiv, 1, seed=snps * 31 + indiv)
+    dg = mx.dgemm_compressed
+    dg.set_options(use_gpu=True, not_center=False, verbose=0)
+    obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], 3)
+    for trans in (0, 1):
+        for n in (1, 3, 9):
+            _check(mx, o, obj, prob, trans, n, 1)
+    dg.free_compressed(obj)
+
+
+def test_workspace_growth_and_wide_n(mx):
+    o = Oracle()
+    prob = make_problem(700, 300, 1, seed=4)
+    dg = mx.dgemm_compressed
+    dg.set_options(use_gpu=True, not_center=False, verbose=0)
+    obj = dg.init_compressed(prob["plink"], prob["plink_t"], 700, 300, prob["f"], 1)   # max_n = 1
+    for n in (1, 2, 17, 33, 100, 5):                                                   # n > max_n grows buffers
+        for trans in (0, 1):
+            _check(mx, o, obj, prob, trans, n, 1, seed=n)
+    dg.free_compressed(obj)
+
+
+def test_two_objects_and_option_switch(mx):
+    o = Oracle()
+    pa, pb = make_problem(900, 400, 1, seed=1), make_problem(333, 1200, 1, seed=2)
+    dg = mx.dgemm_compressed
+    dg.set_options(use_gpu=True, not_center=False, verbose=0)
+    oa = dg.init_compressed(pa["plink"], pa["plink_t"], 900, 400, pa["f"], 8)
+    ob = dg.init_compressed(pb["plink"], pb["plink_t"], 333, 1200, pb["f"], 8)
+    for rep in range(3):
+        _check(mx, o, oa, pa, rep % 2, 8, 1, seed=rep)
+        _check(mx, o, ob, pb, (rep + 1) % 2, 4, 1, seed=rep + 10)
+    dg.set_options(use_gpu=True, not_center=True, verbose=0)     # centring is a process-global option read at call time
+    _check(mx, o, oa, pa, 0, 8, 0)
+    _check(mx, o, ob, pb, 1, 2, 0)
+    dg.free_compressed(oa)
+    _check(mx, o, ob, pb, 0, 1, 0)
+    dg.free_compressed(ob)
+
+
+def test_n_zero_and_double_free(mx):
+    prob = make_problem(100, 50, 1, seed=3)
+    dg = mx.dgemm_compressed
+    L = mx.check_library_handle()
+    dg.set_options(use_gpu=True, not_center=True, verbose=0)
+    obj = dg.init_compressed(prob["plink"], prob["plink_t"], 100, 50, prob["f"], 1)
+    L.dgemm_compressed(b"N", obj, 0, None, 100, None, 50)        # n = 0: nothing to do, no error
+    dg.free_compressed(obj)
+    assert obj.value is None
+    L.free_compressed(ctypes.byref(obj))                          # second free of a NULLed handle is a no-op
+    with pytest.raises(RuntimeError):
+        dg.free_compressed(obj)                                   # the binding layer reports the uninitialised pointer (tests/solve/test.jl:129)
+
+
+def test_uncentred_without_frequencies(mx):
+    """f may be omitted when centring is off (docs/genotype_matrix_multiplication.md: 'can be omitted with the options above')"""
+    o = Oracle()
+    prob = make_problem(640, 210, 1, seed=6)
+    L = mx.check_library_handle()
+    mx.dgemm_compressed.set_options(use_gpu=True, not_center=True, verbose=0)
+    obj = ctypes.c_void_p(None)
+    L.plink2compressed(prob["plink"].ctypes.data_as(ctypes.c_void_p), prob["plink_t"].ctypes.data_as(ctypes.c_void_p), 640, 210, None, 4, ctypes.byref(obj))
+    assert obj.value
+    _check(mx, o, obj, prob, 0, 4, 0)
+    _check(mx, o, obj, prob, 1, 4, 0)
+    mx.dgemm_compressed.free_compressed(obj)
