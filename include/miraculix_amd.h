@@ -92,6 +92,15 @@ int mxa_dgemm_compressed_device(char trans, void *compressed, int n, const doubl
 int mxa_transpose_2bit(const unsigned char *in, long rows, long cols, unsigned char *out);
 int mxa_allele_freq(const unsigned char *plink, long snps, long indiv, double *f);
 
+/* GRM and LD with the post-processing done on the device before the result leaves HBM (reference: host BLAS in
+ * src/bindings/Julia/crossproduct.jl:83-110 grm(), :128-152 ld(); maths docs/grm.md:5-12).
+ * mxa_grm: G(indiv x indiv) = P Z Z^T P^T [/ (2 sum f(1-f))], plink_transposed = indiv rows of ceil(snps/4) bytes.
+ * mxa_ld : R(snps x snps)  = D^-1/2 (Z^T Z - 4 indiv f f^T) D^-1/2,  plink = snps rows of ceil(indiv/4) bytes.
+ * Pointers may be host or device.  Return 0 / 1. */
+int mxa_grm(const unsigned char *plink_transposed, int snps, int indiv, double *G, int is_plink_format, int do_scale,
+            const double *allele_freq);
+int mxa_ld(const unsigned char *plink, int snps, int indiv, double *R, int is_plink_format, const double *allele_freq);
+
 /* measurement: HIP-event timing of the dominant kernel on the stream it is launched on.
  * mxa_profile_reset() clears the counters; after some dgemm_compressed / snp_multiply_gpu calls
  * mxa_profile_get() returns the number of dominant-kernel launches and their summed duration in ms. */

@@ -31,28 +31,41 @@ def snp_crossprod(plink, snps, indiv, is_snpmajor, is_plink_format=False, out=No
     return M
 
 
+def _result_like(plink, n):
+    if _lib.is_torch_tensor(plink):
+        import torch
+        return torch.zeros((n, n), dtype=torch.float64, device=plink.device)
+    return np.zeros((n, n), dtype=np.float64)
+
+
 def grm(plink_transposed, snps, indiv, is_plink_format=False, do_scale=True, allele_freq=None):
-    """crossproduct.jl:83-110; maths docs/grm.md:5-12.  G = P Z Z^T P^T / (2 sum f(1-f)) via rank-1 updates of M = Z Z^T."""
+    """crossproduct.jl:83-110; maths docs/grm.md:5-12.  G = P Z Z^T P^T / (2 sum f(1-f)): the crossproduct and the rank-1
+    centring / scaling all run on the device (C entry mxa_grm); only the finished G crosses PCIe when inputs are host arrays."""
     if do_scale and (allele_freq is None or len(allele_freq) != snps):
         raise ValueError(f"Allele frequencies need to be equal to length of SNPs {snps}.")
-    M = np.asarray(snp_crossprod(plink_transposed, snps, indiv, is_snpmajor=False, is_plink_format=is_plink_format))
-    col_sum = M.sum(axis=0)
-    M = M - np.outer(col_sum, np.ones(indiv)) / indiv - np.outer(np.ones(indiv), col_sum) / indiv
-    M += col_sum.sum() / indiv**2
-    if do_scale:
-        f = np.asarray(allele_freq, dtype=np.float64)
-        M /= 2.0 * np.sum(f * (1.0 - f))
-    return M
+    if int(np.prod(plink_transposed.shape)) != indiv * ((snps + 3) // 4):
+        raise ValueError(f"Matrix has wrong dimensions: {tuple(plink_transposed.shape)}")
+    L = _lib.check_library_handle()
+    G = _result_like(plink_transposed, indiv)
+    f = allele_freq
+    if f is not None and not _lib.is_torch_tensor(f):
+        f = np.ascontiguousarray(f, dtype=np.float64)
+    rc = L.mxa_grm(_lib.ptr(plink_transposed), int(snps), int(indiv), _lib.ptr(G), int(bool(is_plink_format)), int(bool(do_scale)), _lib.ptr(f))
+    if rc != 0:
+        raise RuntimeError("mxa_grm failed: " + _lib.last_error()[1])
+    return G
 
 
 def ld(plink, snps, indiv, is_plink_format=False, allele_freq=None):
-    """crossproduct.jl:128-152: R^2-type LD statistic from the SNP x SNP crossproduct."""
+    """crossproduct.jl:128-152: LD correlation from the SNP x SNP crossproduct, on the device (C entry mxa_ld)."""
     if allele_freq is None or len(allele_freq) != snps:
         raise ValueError(f"Allele frequencies need to be equal to length of SNPs {snps}.")
-    M = np.asarray(snp_crossprod(plink, snps, indiv, is_snpmajor=True, is_plink_format=is_plink_format)).copy()
-    f = np.asarray(allele_freq, dtype=np.float64)
-    M -= 4.0 * indiv * np.outer(f, f)
-    sigma = np.sqrt(np.diag(M))
-    M /= sigma[:, None]
-    M /= sigma[None, :]
-    return M
+    if int(np.prod(plink.shape)) != snps * ((indiv + 3) // 4):
+        raise ValueError(f"Matrix has wrong dimensions: {tuple(plink.shape)}")
+    L = _lib.check_library_handle()
+    R = _result_like(plink, snps)
+    f = allele_freq if _lib.is_torch_tensor(allele_freq) else np.ascontiguousarray(allele_freq, dtype=np.float64)
+    rc = L.mxa_ld(_lib.ptr(plink), int(snps), int(indiv), _lib.ptr(R), int(bool(is_plink_format)), _lib.ptr(f))
+    if rc != 0:
+        raise RuntimeError("mxa_ld failed: " + _lib.last_error()[1])
+    return R

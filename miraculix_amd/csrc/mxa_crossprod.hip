@@ -307,13 +307,90 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
   return 0;
 }
 
+// ---- GRM / LD post-processing on the device (reference: host BLAS in src/bindings/Julia/crossproduct.jl:83-152, maths docs/grm.md)
+// column sums of the symmetric n x n matrix, fixed-order tree per column
+__global__ void __launch_bounds__(256) k_sym_colsum(const double *__restrict__ M, long n, double *__restrict__ cs) {
+  const long j = blockIdx.x;
+  double s = 0.0;
+  for (long i = threadIdx.x; i < n; i += 256) s += M[(size_t)j * n + i];
+  __shared__ double sh[256];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
+  if (threadIdx.x == 0) cs[j] = sh[0];
+}
+// out[0] = sum_i v[i] * (w ? (1 - w[i]) * 2 : 1)   (single block, fixed order)
+__global__ void __launch_bounds__(1024) k_vec_reduce(const double *__restrict__ v, long n, int mode, double *__restrict__ out) {
+  double s = 0.0;
+  for (long i = threadIdx.x; i < n; i += 1024) s += mode ? 2.0 * v[i] * (1.0 - v[i]) : v[i];
+  __shared__ double sh[1024];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+// G = (M - cs 1^T / n - 1 cs^T / n + total / n^2) / c          (crossproduct.jl:96-107)
+__global__ void __launch_bounds__(256) k_grm_update(double *__restrict__ M, long n, const double *__restrict__ cs, const double *__restrict__ total,
+                                                    const double *__restrict__ c, int do_scale) {
+  const long j = blockIdx.y;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double inv_n = 1.0 / (double)n;
+  double v = M[(size_t)j * n + i];
+  v = v - cs[i] * inv_n;
+  v = v - cs[j] * inv_n;
+  v = v + total[0] / ((double)n * (double)n);
+  if (do_scale) v /= c[0];
+  M[(size_t)j * n + i] = v;
+}
+// LD: M <- M - 4 * indiv * f f^T ; sigma = sqrt(diag M) ; M <- M / sigma sigma^T      (crossproduct.jl:139-149)
+__global__ void __launch_bounds__(256) k_ld_center(double *__restrict__ M, long n, const double *__restrict__ f, double four_indiv) {
+  const long j = blockIdx.y;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  M[(size_t)j * n + i] = fma(-four_indiv * f[i], f[j], M[(size_t)j * n + i]);
+}
+__global__ void __launch_bounds__(256) k_diag_sqrt(const double *__restrict__ M, long n, double *__restrict__ sigma) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) sigma[i] = sqrt(M[(size_t)i * n + i]);
+}
+__global__ void __launch_bounds__(256) k_ld_scale(double *__restrict__ M, long n, const double *__restrict__ sigma) {
+  const long j = blockIdx.y;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  M[(size_t)j * n + i] = M[(size_t)j * n + i] / sigma[i] / sigma[j];
+}
+
+// post: 0 none, 1 GRM (do_scale as given, f = allele frequencies of length k), 2 LD (f of length rows, k = number of individuals)
+static int postprocess_device(double *d_M, long rows, long k, int post, int do_scale, const double *d_f, hipStream_t s) {
+  if (post == 0) return 0;
+  double *tmp = nullptr;
+  MXA_HIP(hipMalloc(reinterpret_cast<void **>(&tmp), sizeof(double) * (size_t)(rows + 4)));
+  dim3 g2((unsigned)((rows + 255) / 256), (unsigned)rows);
+  if (post == 1) {
+    hipLaunchKernelGGL(k_sym_colsum, dim3((unsigned)rows), dim3(256), 0, s, d_M, rows, tmp);
+    hipLaunchKernelGGL(k_vec_reduce, dim3(1), dim3(1024), 0, s, tmp, rows, 0, tmp + rows);
+    if (do_scale) hipLaunchKernelGGL(k_vec_reduce, dim3(1), dim3(1024), 0, s, d_f, k, 1, tmp + rows + 1);
+    hipLaunchKernelGGL(k_grm_update, g2, dim3(256), 0, s, d_M, rows, tmp, tmp + rows, tmp + rows + 1, do_scale);
+  } else {
+    hipLaunchKernelGGL(k_ld_center, g2, dim3(256), 0, s, d_M, rows, d_f, 4.0 * (double)k);
+    hipLaunchKernelGGL(k_diag_sqrt, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, d_M, rows, tmp);
+    hipLaunchKernelGGL(k_ld_scale, g2, dim3(256), 0, s, d_M, rows, tmp);
+  }
+  MXA_HIP(hipGetLastError());
+  MXA_HIP(hipStreamSynchronize(s));
+  (void)hipFree(tmp);
+  return 0;
+}
+
 static bool xp_is_device_ptr(const void *p) {
   hipPointerAttribute_t attr;
   if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
   return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
 }
 
-static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, double *ans, bool is_plink) {
+static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, double *ans, bool is_plink, int post = 0, int do_scale = 0,
+                         const double *freq = nullptr) {
   if (!snp_matrix || !ans || k <= 0 || rows <= 0) { set_error(1, "snp_multiply_gpu: bad arguments"); return 1; }
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); set_error(10, "snp_multiply_gpu: no HIP device available; this engine is GPU-only"); return 1; }
@@ -356,6 +433,16 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
   }
   if (!out_dev && fail(hipMalloc(reinterpret_cast<void **>(&d_ans), abytes), __LINE__)) goto done;
   rc = crossprod_device(d_X, k, rows, pitch, d_ans, s);
+  if (!rc && post) {
+    const long flen = post == 1 ? k : rows;
+    const double *d_f = freq;
+    double *f_tmp = nullptr;
+    if (freq && !xp_is_device_ptr(freq)) {
+      if (!fail(hipMalloc(reinterpret_cast<void **>(&f_tmp), sizeof(double) * flen), __LINE__) && !fail(hipMemcpyAsync(f_tmp, freq, sizeof(double) * flen, hipMemcpyHostToDevice, s), __LINE__)) d_f = f_tmp;
+    }
+    if (!rc) rc = postprocess_device(d_ans, rows, k, post, do_scale, d_f, s);
+    if (f_tmp) (void)hipFree(f_tmp);
+  }
   if (!rc && !out_dev) fail(hipMemcpyAsync(ans, d_ans, abytes, hipMemcpyDeviceToHost, s), __LINE__);
   if (!rc) fail(hipStreamSynchronize(s), __LINE__);
 done:
@@ -371,4 +458,14 @@ done:
 extern "C" int snp_multiply_gpu(unsigned char *snp_matrix, int snps, int indiv, double *ans, bool is_plink_format) {
   // positional meaning as in the reference: arg 2 = packed (inner) dimension, arg 3 = output dimension
   return mxa::crossprod_any(snp_matrix, snps, indiv, ans, is_plink_format);
+}
+
+extern "C" int mxa_grm(const unsigned char *plink_transposed, int snps, int indiv, double *G, int is_plink_format, int do_scale, const double *allele_freq) {
+  if (do_scale && !allele_freq) { mxa::set_error(1, "mxa_grm: allele frequencies are required when do_scale is set"); return 1; }
+  return mxa::crossprod_any(plink_transposed, snps, indiv, G, is_plink_format != 0, 1, do_scale, allele_freq);
+}
+
+extern "C" int mxa_ld(const unsigned char *plink, int snps, int indiv, double *R, int is_plink_format, const double *allele_freq) {
+  if (!allele_freq) { mxa::set_error(1, "mxa_ld: allele frequencies are required"); return 1; }
+  return mxa::crossprod_any(plink, indiv, snps, R, is_plink_format != 0, 2, 0, allele_freq);
 }

@@ -41,6 +41,10 @@ def load_shared_library():
     L.get_compressed_freq.restype = None
     L.snp_multiply_gpu.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_bool]
     L.snp_multiply_gpu.restype = ctypes.c_int
+    L.mxa_grm.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.mxa_grm.restype = ctypes.c_int
+    L.mxa_ld.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.mxa_ld.restype = ctypes.c_int
     L.mxa_last_error.restype = ctypes.c_int
     L.mxa_last_error_string.restype = ctypes.c_char_p
     L.mxa_device_count.restype = ctypes.c_int

@@ -67,3 +67,19 @@ def test_grm_and_ld(mx):
     Mld = Z.T @ Z - 4 * 400 * np.outer(f, f)
     s = np.sqrt(np.diag(Mld))
     assert np.abs(R - Mld / s[:, None] / s[None, :]).max() <= 1e-9
+
+
+def test_grm_device_resident(mx):
+    """mxa_grm with every operand in HBM (torch tensors): crossproduct + rank-1 centring + scaling never leave the device"""
+    import torch
+    dev = torch.device("cuda", 0)
+    prob = make_problem(2500, 333, 1, seed=4)
+    f = prob["f"]
+    G = mx.crossproduct.grm(torch.from_numpy(prob["plink_t"]).to(dev), 2500, 333, is_plink_format=True, do_scale=True, allele_freq=torch.from_numpy(f).to(dev))
+    assert G.is_cuda
+    Z = prob["Z"].astype(np.float64)
+    Zc = Z - Z.mean(axis=0, keepdims=True)
+    Gref = Zc @ Zc.T / (2 * np.sum(f * (1 - f)))
+    assert np.abs(G.cpu().numpy() - Gref).max() <= 1e-9 * np.abs(Gref).max()
+    G2 = mx.crossproduct.grm(prob["plink_t"], 2500, 333, is_plink_format=True, do_scale=False)
+    assert np.abs(G2 - Zc @ Zc.T).max() <= 1e-9 * np.abs(Zc @ Zc.T).max()
