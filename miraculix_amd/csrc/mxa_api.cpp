@@ -219,7 +219,7 @@ static int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t
 }
 
 // ------------------------------------------------------------------------------------------------ multiply
-static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, hipStream_t s) {
+static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, hipStream_t s, bool timing = true) {
   const PackedMatrix &G = trans ? h->snp_major : h->ind_major;   // reference picks d_plink for 'T' (dgemm_compressed_cuda.cu:270)
   const long m = G.rows, k = G.k;
   const bool centered = options().centered;
@@ -237,15 +237,16 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   static const int mode = [] { const char *e = getenv("MXA_GEMM_MODE"); return e ? atoi(e) : 0; }();
   if (!use_lut && launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, s)) return 1;
   if (centered && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
+  const bool prof = g_profile_on && timing;   // the asynchronous entry must not block on an event
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (g_profile_on) {
+  if (prof) {
     MXA_HIP(hipEventCreate(&e0)); MXA_HIP(hipEventCreate(&e1));
     MXA_HIP(hipEventRecord(e0, s));
   }
   int rc = use_lut ? launch_lut(G, dB, ldb, n, w.d_P, p, s) : launch_gemm(G, w.d_Bp, w.d_P, p, mode, s);
-  if (g_profile_on && !rc) MXA_HIP(hipEventRecord(e1, s));
+  if (prof && !rc) MXA_HIP(hipEventRecord(e1, s));
   if (!rc) rc = launch_finish(w.d_P, p, m, n, dC, ldc, trans ? 1 : 0, centered, d_sumB, d_sumfB, h->d_f, s);
-  if (g_profile_on) {
+  if (prof) {
     if (!rc) {
       MXA_HIP(hipEventSynchronize(e1));
       float ms = 0.f;
@@ -353,7 +354,7 @@ int mxa_dgemm_compressed_device(char trans, void *compressed, int n, const doubl
   if (n <= 0) return 0;
   MXA_HIP(hipSetDevice(h->device));
   hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->stream;
-  if (gemm_device(h, t != 0, n, dB, ldb, dC, ldc, s)) return 1;
+  if (gemm_device(h, t != 0, n, dB, ldb, dC, ldc, s, sync != 0)) return 1;
   if (sync) MXA_HIP(hipStreamSynchronize(s));
   return 0;
 }
