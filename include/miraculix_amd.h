@@ -92,6 +92,15 @@ int mxa_dgemm_compressed_device(char trans, void *compressed, int n, const doubl
 int mxa_transpose_2bit(const unsigned char *in, long rows, long cols, unsigned char *out);
 int mxa_allele_freq(const unsigned char *plink, long snps, long indiv, double *f);
 
+/* PLINK .bed staging owned by the library: reads the SNP-major .bed file `bed_path` (3-byte magic 6c 1b 01, then snps rows of
+ * ceil(indiv/4) bytes; reference reader: src/bindings/Julia/read_plink.jl:161-222), uploads it in chunks, builds the
+ * individual-major copy with the on-device 2-bit transpose and the allele frequencies with the on-device popcount
+ * (f_s = allele count / (2 indiv)), and returns the same kind of object as plink2compressed.  snps / indiv <= 0: taken
+ * from the line counts of the .bim / .fam files next to the .bed.  f_out (optional, host, snps doubles) receives the
+ * frequencies; snps_out / indiv_out (optional) the dimensions.  Returns 0 / 1; *compressed is NULL on failure. */
+int mxa_bed2compressed(const char *bed_path, int snps, int indiv, int max_n, void **compressed, double *f_out, int *snps_out,
+                       int *indiv_out);
+
 /* GRM and LD with the post-processing done on the device before the result leaves HBM (reference: host BLAS in
  * src/bindings/Julia/crossproduct.jl:83-110 grm(), :128-152 ld(); maths docs/grm.md:5-12).
  * mxa_grm: G(indiv x indiv) = P Z Z^T P^T [/ (2 sum f(1-f))], plink_transposed = indiv rows of ceil(snps/4) bytes.

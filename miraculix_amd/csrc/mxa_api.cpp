@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 namespace mxa {
@@ -389,6 +390,66 @@ void mxa_profile_get(int *launches, double *total_ms) {
 void mxa_last_geometry(long *m, long *k, int *n, int *splits, int *a_tile, int *c_tile) {
   const Geometry &g = last_geometry();
   if (m) *m = g.m; if (k) *k = g.k; if (n) *n = g.n; if (splits) *splits = g.splits; if (a_tile) *a_tile = g.a; if (c_tile) *c_tile = g.c;
+}
+
+// ---- .bed staging owned by the library
+static long count_lines(const char *path) {
+  FILE *fh = fopen(path, "rb");
+  if (!fh) return -1;
+  long n = 0; int c, last = '\n';
+  while ((c = fgetc(fh)) != EOF) { if (c == '\n') n++; last = c; }
+  if (last != '\n') n++;
+  fclose(fh);
+  return n;
+}
+
+int mxa_bed2compressed(const char *bed_path, int snps, int indiv, int max_n, void **compressed, double *f_out, int *snps_out, int *indiv_out) {
+  if (compressed) *compressed = nullptr;
+  if (!bed_path || !compressed) { set_error(1, "mxa_bed2compressed: bad arguments"); return 1; }
+  std::string base(bed_path);
+  if (base.size() > 4 && base.compare(base.size() - 4, 4, ".bed") == 0) base.resize(base.size() - 4);
+  if (snps <= 0) snps = (int)count_lines((base + ".bim").c_str());
+  if (indiv <= 0) indiv = (int)count_lines((base + ".fam").c_str());
+  if (snps <= 0 || indiv <= 0) { set_error(1, "mxa_bed2compressed: dimensions unknown (no .bim/.fam next to %s)", bed_path); return 1; }
+  FILE *fh = fopen((base + ".bed").c_str(), "rb");
+  if (!fh) { set_error(1, "mxa_bed2compressed: cannot open %s.bed", base.c_str()); return 1; }
+  unsigned char magic[3];
+  if (fread(magic, 1, 3, fh) != 3 || magic[0] != 0x6c || magic[1] != 0x1b || magic[2] != 0x01) {
+    fclose(fh);
+    set_error(1, "mxa_bed2compressed: %s.bed is not a SNP-major PLINK .bed file (magic bytes 6c 1b 01 expected)", base.c_str());
+    return 1;
+  }
+  if (select_device() < 0) { fclose(fh); return 1; }
+  const size_t bps = ((size_t)indiv + 3) / 4, bpi = ((size_t)snps + 3) / 4;
+  uint8_t *d_plink = nullptr, *d_plink_t = nullptr;
+  double *d_f = nullptr;
+  int rc = 0;
+  auto bad = [&](hipError_t e, int line) { if (e != hipSuccess) { check_hip(e, "mxa_bed2compressed", line); rc = 1; } return rc; };
+  std::vector<uint8_t> chunk;
+  if (bad(hipMalloc((void **)&d_plink, (size_t)snps * bps), __LINE__) || bad(hipMalloc((void **)&d_plink_t, (size_t)indiv * bpi), __LINE__) ||
+      bad(hipMalloc((void **)&d_f, sizeof(double) * snps), __LINE__)) goto out;
+  {
+    const size_t rows_per_chunk = std::max<size_t>(1, ((size_t)64 << 20) / bps);
+    chunk.resize(rows_per_chunk * bps);
+    for (size_t r0 = 0; r0 < (size_t)snps && !rc; r0 += rows_per_chunk) {
+      const size_t nr = std::min(rows_per_chunk, (size_t)snps - r0);
+      if (fread(chunk.data(), 1, nr * bps, fh) != nr * bps) { set_error(1, "mxa_bed2compressed: %s.bed is shorter than %d x ceil(%d/4) bytes", base.c_str(), snps, indiv); rc = 1; break; }
+      bad(hipMemcpy(d_plink + r0 * bps, chunk.data(), nr * bps, hipMemcpyHostToDevice), __LINE__);
+    }
+  }
+  if (!rc) rc = launch_transpose_2bit(d_plink, snps, indiv, d_plink_t, nullptr);
+  if (!rc) rc = launch_allele_freq(d_plink, snps, indiv, d_f, nullptr);
+  if (!rc) bad(hipDeviceSynchronize(), __LINE__);
+  if (!rc) rc = create_handle(d_plink, bps, d_plink_t, bpi, snps, indiv, d_f, max_n, compressed);
+  if (!rc && f_out) bad(hipMemcpy(f_out, d_f, sizeof(double) * snps, hipMemcpyDeviceToHost), __LINE__);
+  if (!rc) { if (snps_out) *snps_out = snps; if (indiv_out) *indiv_out = indiv; }
+out:
+  fclose(fh);
+  if (d_plink) (void)hipFree(d_plink);
+  if (d_plink_t) (void)hipFree(d_plink_t);
+  if (d_f) (void)hipFree(d_f);
+  if (rc && compressed && *compressed) free_compressed(compressed);
+  return rc;
 }
 
 // ---- staging helpers

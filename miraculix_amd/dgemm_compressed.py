@@ -43,6 +43,24 @@ def init_compressed(plink, plink_transposed, snps, indiv, freq, max_ncol):
     return obj_ref
 
 
+def init_compressed_from_bed(bed_path, max_ncol, snps=0, indiv=0):
+    """Stage straight from a PLINK .bed file (C entry mxa_bed2compressed: host C++ reads the file, the transposed copy and the
+    allele frequencies are produced on the device).  Returns (obj_ref, freq, snps, indiv)."""
+    L = _lib.check_library_handle()
+    obj_ref = ctypes.c_void_p(None)
+    s_out, i_out = ctypes.c_int(0), ctypes.c_int(0)
+    # frequencies: dimension may be unknown before the call -> query with a first pass over .bim if needed
+    if snps <= 0:
+        base = bed_path[:-4] if bed_path.endswith(".bed") else bed_path
+        with open(base + ".bim") as fh:
+            snps = sum(1 for _ in fh)
+    f = np.zeros(snps, dtype=np.float64)
+    rc = L.mxa_bed2compressed(bed_path.encode(), int(snps), int(indiv), int(max_ncol), ctypes.byref(obj_ref), _lib.ptr(f), ctypes.byref(s_out), ctypes.byref(i_out))
+    if rc != 0 or not obj_ref.value:
+        raise RuntimeError("mxa_bed2compressed failed: " + _lib.last_error()[1])
+    return obj_ref, f, s_out.value, i_out.value
+
+
 def init_compressed_shard(plink, plink_transposed, snps_total, indiv, snp_begin, snp_end, freq, max_ncol):
     """SNP-sharded variant (mxa_plink2compressed_shard): this object holds SNPs [snp_begin, snp_end) only."""
     obj_ref = ctypes.c_void_p(None)

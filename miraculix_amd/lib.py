@@ -41,6 +41,8 @@ def load_shared_library():
     L.get_compressed_freq.restype = None
     L.snp_multiply_gpu.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_bool]
     L.snp_multiply_gpu.restype = ctypes.c_int
+    L.mxa_bed2compressed.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    L.mxa_bed2compressed.restype = ctypes.c_int
     L.mxa_grm.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     L.mxa_grm.restype = ctypes.c_int
     L.mxa_ld.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]

@@ -101,3 +101,14 @@ def test_plink2compressed_without_gpu_fails_loudly(built):
 def test_missing_library_is_an_error(tmp_path):
     r = _run_py(f"import miraculix_amd as m; m.set_library_path({str(tmp_path / 'nope.so')!r}); m.load_shared_library()")
     assert r.returncode != 0 and "no cpu fallback" in r.stderr.lower()
+
+
+def test_bed_reader_rejects_bad_magic(built, tmp_path):
+    import miraculix_amd as m
+    L = m.load_shared_library()
+    p = tmp_path / "x.bed"
+    p.write_bytes(bytes([0x6C, 0x1B, 0x00]) + bytes(10))          # individual-major flag: not supported, like the reference reader
+    obj = ctypes.c_void_p(None)
+    rc = L.mxa_bed2compressed(str(p).encode(), 5, 8, 1, ctypes.byref(obj), None, None, None)
+    assert rc == 1 and not obj.value
+    assert "magic" in (L.mxa_last_error_string() or b"").decode()
