@@ -236,7 +236,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c;
   double *d_sumB = w.d_colpart + (size_t)n * 128, *d_sumfB = d_sumB + n;
   static const int mode = [] { const char *e = getenv("MXA_GEMM_MODE"); return e ? atoi(e) : 0; }();
-  if (!use_lut && launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, s)) return 1;
+  if (!use_lut && launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s)) return 1;
   if (centered && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
   const bool prof = g_profile_on && timing;   // the asynchronous entry must not block on an event
   hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -83,7 +83,7 @@ void debug_info(const char *fmt, ...);
 // recode raw PLINK rows (src pitch arbitrary) into the padded z-coded device layout
 int launch_recode(const uint8_t *d_src, size_t src_pitch, long row0, long nrows, long k, long k_bit_offset,
                   PackedMatrix &dst, hipStream_t s);
-int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k_pad, int n_pad, hipStream_t s);
+int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k_pad, int n_pad, int c, hipStream_t s);
 int launch_colsums(const double *dB, long ldb, long k, int n, const double *d_f /*nullable*/, double *d_part,
                    double *d_sumB, double *d_sumfB, hipStream_t s);
 struct GemmPlan { int a, c, nchunks, n_pad, splits, slabs_per_split, slabs_total, rowblocks; long m_pad; };

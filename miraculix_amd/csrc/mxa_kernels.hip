@@ -69,30 +69,34 @@ int launch_recode(const uint8_t *d_src, size_t src_pitch, long row0, long nrows,
 // =====================================================================================================
 // B -> fragment order
 // =====================================================================================================
-// Bp[S][h][l], S = K-step of 16, h = group of 4 columns, l = lane 0..63 with j = l&3 (column in group),
-// kk = l>>2 (row in K-step): element B[16S+kk][4h+j], zero outside k x n.  One v_mfma_f64_4x4x4_4b_f64 takes the 64
-// doubles of (S,h) as its B operand, lane l <- Bp[S][h][l] (lane map measured on gfx950: B lane = j + 4*blk + 16*k,
-// we assign genotype row 16S + (blk + 4*k) = 16S + (l>>2) to it; tools/mfma_f64_probe2.hip).
+// Bp[chunk][S][h][l]: chunk = column chunk of 4*C columns (one per k_gemm column pass), S = K-step of 16, h = group of 4
+// columns inside the chunk (h < C), l = lane 0..63 with j = l&3 (column in group), kk = l>>2 (row in K-step):
+// element B[16S+kk][chunk*4C + 4h + j], zero outside k x n.  One v_mfma_f64_4x4x4_4b_f64 takes the 64 doubles of (S,h) as
+// its B operand, lane l <- Bp[..][S][h][l] (lane map measured on gfx950: B lane = j + 4*blk + 16*k, we assign genotype row
+// 16S + (blk + 4*k) = 16S + (l>>2) to it; tools/mfma_f64_probe2.hip).  A slab of 8 K-steps of one chunk is one contiguous
+// run of C*4 KiB, so it streams HBM -> LDS as C*4 lane-linear LDS-DMA units for any C.
 __global__ void __launch_bounds__(256) k_pack_B(const double *__restrict__ B, long ldb, long k, int n,
-                                                double *__restrict__ Bp, long total, int H) {
+                                                double *__restrict__ Bp, long total, int C, long S_total) {
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int l = (int)(idx & 63);
     const long sh = idx >> 6;
-    const int h = (int)(sh % H);
-    const long S = sh / H;
+    const int h = (int)(sh % C);
+    const long cs = sh / C;
+    const long S = cs % S_total;
+    const int chunk = (int)(cs / S_total);
     const long row = S * 16 + (l >> 2);
-    const int col = 4 * h + (l & 3);
+    const int col = chunk * 4 * C + 4 * h + (l & 3);
     double v = 0.0;
     if (row < k && col < n) v = B[row + (long)col * ldb];
     Bp[idx] = v;
   }
 }
 
-int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k_pad, int n_pad, hipStream_t s) {
-  const int H = n_pad / 4;
-  const long total = (k_pad / 16) * (long)H * 64;
+int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k_pad, int n_pad, int c, hipStream_t s) {
+  const long S_total = k_pad / 16;
+  const long total = S_total * (long)(n_pad / 4) * 64;
   const int grid = (int)std::min<long>((total + 255) / 256, 256L * 64);
-  hipLaunchKernelGGL(k_pack_B, dim3(grid), dim3(256), 0, s, dB, ldb, k, n, dBp, total, H);
+  hipLaunchKernelGGL(k_pack_B, dim3(grid), dim3(256), 0, s, dB, ldb, k, n, dBp, total, c, S_total);
   MXA_HIP(hipGetLastError());
   return 0;
 }
@@ -182,9 +186,8 @@ struct GemmCfg {
   static constexpr int kABytes = kRowsWG * kSlabBytes;      // packed rows of one slab
   static constexpr int kBufBytes = kBBytes + kABytes;
   static constexpr int kLds = 2 * kBufBytes;
-  static constexpr int kBUnits = kBBytes / 1024;            // 1 KiB wave-instruction units
+  static constexpr int kBUnits = kBBytes / 1024;            // 1 KiB wave-instruction units (= 4C, C per wave)
   static constexpr int kAUnits = kABytes / 1024;
-  static_assert(C % 2 == 0, "C must be even (1 KiB DMA units)");
   static_assert(kABytes % 1024 == 0, "A tile must be a whole number of DMA units");
 };
 
@@ -221,22 +224,20 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
   // fp64 MFMA stream (see MODE comment above).
   const uint32_t b_lane = lane * 16;
   const uint32_t a_lane = lane * 16;
-  const char *Bp_u = reinterpret_cast<const char *>(Bp) + (size_t)nc * C * 512;
+  // chunk-major B fragments: this workgroup's column chunk nc is one contiguous array [S_total][C][64]
+  const char *Bp_u = reinterpret_cast<const char *>(Bp) + (size_t)nc * ((size_t)slabs_total * kSlabSteps * C * 512);
   // tiled layout: the rows [row0, row0 + kRowsWG) of slab s are one contiguous run inside tile (row0/256, s)
   const size_t nslabs_all = pitch / kSlabBytes;
   const char *G_u = reinterpret_cast<const char *>(G) + (size_t)(row0 / kTileRows) * nslabs_all * kTileBytes + (size_t)(row0 % kTileRows) * kSlabBytes;
   const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
   auto issue = [&](int slab, int buf) {
     const uint32_t base = lds0 + buf * Cfg::kBufBytes;
-    // B fragments: per K-step ks a contiguous run of C*512 bytes at Bp[(slab*8+ks)*H + nc*C][0]
-    const char *bslab = Bp_u + (size_t)slab * ((size_t)kSlabSteps * H * 512);
+    // B fragments of the slab: one contiguous run of C*4 KiB -> C units per wave
+    const char *bslab = Bp_u + (size_t)slab * ((size_t)kSlabSteps * C * 512);
 #pragma unroll
-    for (int i = 0; i < (Cfg::kBUnits + kWaves - 1) / kWaves; i++) {
+    for (int i = 0; i < Cfg::kBUnits / kWaves; i++) {
       const int u = wave + i * kWaves;
-      if (Cfg::kBUnits % kWaves == 0 || u < Cfg::kBUnits) {
-        const int ks = u / (C / 2), part = u % (C / 2);
-        dma16_s(bslab + (size_t)ks * H * 512 + part * 1024, b_lane, base + u * 1024);
-      }
+      dma16_s(bslab + u * 1024, b_lane, base + u * 1024);
     }
     // packed genotype rows: unit = 32 rows x 32 B = 1 KiB, contiguous in the tiled layout
     const char *aslab = G_u + (size_t)slab * kTileBytes;
@@ -338,12 +339,13 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
 
 GemmPlan plan_gemm(long m, long k_pad, int n) {
   GemmPlan p{};
-  // tile choice by n: C column groups of 4 per wave pass, A row groups of 4 per wave (A*C = 64 accumulators)
-  if (n <= 8) { p.c = 2; p.a = 16; }
-  else if (n <= 16) { p.c = 4; p.a = 16; }
-  else { p.c = 8; p.a = 8; }
+  // tile choice by n: column chunks of at most 32 columns, C = groups of 4 columns per chunk (balanced over the chunks, so at most
+  // 3 padded columns per chunk), A = row groups of 4 per wave: A*C <= 64 accumulators (128 VGPRs)
+  p.nchunks = (n + 31) / 32;
+  const int per = (n + p.nchunks - 1) / p.nchunks;
+  p.c = (per + 3) / 4;
+  p.a = p.c <= 4 ? 16 : 8;
   const int cols_chunk = 4 * p.c;
-  p.nchunks = (n + cols_chunk - 1) / cols_chunk;
   p.n_pad = p.nchunks * cols_chunk;
   const int rows_wg = kWaves * 4 * p.a;
   p.rowblocks = (int)((m + rows_wg - 1) / rows_wg);
@@ -407,8 +409,13 @@ int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const Gemm
     if (mode == 1) return launch_gemm_t<AA, CC, 1>(G, dBp, dP, p, s);     \
     return launch_gemm_t<AA, CC, 0>(G, dBp, dP, p, s);                    \
   }
+  MXA_DISPATCH(16, 1)
   MXA_DISPATCH(16, 2)
+  MXA_DISPATCH(16, 3)
   MXA_DISPATCH(16, 4)
+  MXA_DISPATCH(8, 5)
+  MXA_DISPATCH(8, 6)
+  MXA_DISPATCH(8, 7)
   MXA_DISPATCH(8, 8)
 #undef MXA_DISPATCH
   set_error(5, "internal: no kernel for tile a=%d c=%d", p.a, p.c);
@@ -472,8 +479,13 @@ k_lut(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B,
       const long kk = (long)slab * KS + 2 * ((tid + Cfg::kThreads * e) >> 4);
 #pragma unroll
       for (int j = 0; j < NV; j++) {
-        b0[e][j] = (j < n && kk < k) ? B[kk + (long)j * ldb] : 0.0;
-        b1[e][j] = (j < n && kk + 1 < k) ? B[kk + 1 + (long)j * ldb] : 0.0;
+        // unconditional loads from clamped addresses, then a select: a branch around each load would serialise them
+        // (every load followed by its own vmcnt(0))
+        const long jc = j < n ? j : 0;
+        const double v0 = B[(kk < k ? kk : k - 1) + jc * ldb];
+        const double v1 = B[(kk + 1 < k ? kk + 1 : k - 1) + jc * ldb];
+        b0[e][j] = (j < n && kk < k) ? v0 : 0.0;
+        b1[e][j] = (j < n && kk + 1 < k) ? v1 : 0.0;
       }
     }
   };
