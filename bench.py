@@ -154,6 +154,17 @@ def main():
 
     launches, total_ms = ctypes.c_int(0), ctypes.c_double(0.0)
     L.mxa_profile_get(ctypes.byref(launches), ctypes.byref(total_ms))
+
+    # parity check on every run (size-independent property; the oracle cannot run at this size): the adjoint identity
+    # <B_T[:,j], Z B_N[:,j]> == <Z^T B_T[:,j], B_N[:,j]> ties the 'N' result (individual-major copy, all-reduced over the
+    # SNP shards) to the 'T' result (SNP-major copy) column by column.
+    lhs = (B_T * C_N).sum(dim=0)
+    rhs = (C_T * B_N).sum(dim=0)
+    if dist.is_initialized():
+        dist.all_reduce(rhs, op=dist.ReduceOp.SUM)
+    adj_err = float(((lhs - rhs).abs() / lhs.abs().clamp_min(1.0)).max())
+    if not (adj_err <= 1e-10):
+        raise SystemExit(f"bench.py: adjoint identity violated (rel err {adj_err:.3e}): results are wrong, no number reported")
     flops_step = 2 * 2.0 * snps * indiv * n
     value = flops_step * args.steps / dt * 1e-9
     ms_per_step = dt / args.steps * 1e3
@@ -182,6 +193,7 @@ def main():
             "config": {"workload": f"{snps} SNPs x {indiv} indiv, ncol={n}, dgemm_compressed 'N' + 'T' per step, "
                                    f"{'centred' if args.centered else 'uncentred'}, SNP-sharded over {world} GPU(s)",
                        "snps": snps, "indiv": indiv, "ncol": n, "parallelism": f"snp-shard{world}"},
+            "check": {"adjoint_identity_max_rel_err": adj_err, "tolerance": 1e-10},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "GB per launch (rocprofv3 PMC, profiles/)",
                          "algorithmic_bytes_per_launch_GB": round((snps_loc * ((indiv + 3) // 4) + 8.0 * (snps_loc + indiv) * n) / 1e9, 3),

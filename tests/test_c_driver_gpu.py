@@ -1,0 +1,19 @@
+"""A compiled C caller (examples/c_driver.c: the reference's Fortran integration test restated in C, BASELINE config 1)
+linked against the shared library only."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_driver(tmp_path):
+    exe = str(tmp_path / "c_driver")
+    lib = os.path.join(ROOT, "miraculix_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_driver.c"), "-o", exe,
+                           "-L" + lib, "-lmiraculix_amd", "-Wl,-rpath," + lib, "-lm"])
+    r = subprocess.run([exe, "1000", "500"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "c_driver ok" in r.stdout
