@@ -166,8 +166,10 @@ __device__ __forceinline__ void xdma16_s(const void *sbase, uint32_t voff, uint3
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory");
 }
 
+template <bool DIAG>
 __global__ void __launch_bounds__(256, 1)
-k_crossprod2(const uint8_t *__restrict__ X, size_t pitch, int stages, const int2 *__restrict__ tiles, long n, double *__restrict__ ans) {
+k_crossprod2(const uint8_t *__restrict__ X, size_t pitch, int stages, const int2 *__restrict__ tiles, long n, double *__restrict__ ans,
+             unsigned long long *__restrict__ diag) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -200,35 +202,76 @@ k_crossprod2(const uint8_t *__restrict__ X, size_t pitch, int stages, const int2
   const int a_off = (wi * 128 + (lane & 31)) * kXStageBytes + (lane >> 5) * 16;
   const int b_off = kXOpBytes + (wj * 128 + (lane & 31)) * kXStageBytes + (lane >> 5) * 16;
 
+  // Software pipeline over stages (ring of 3 LDS buffers, packed words of the NEXT stage prefetched into registers):
+  //   mid-stage s:  wait until stage s+1 has landed (vmcnt leaves only the 4 DMAs of stage s+2 in flight) -> barrier ->
+  //                 issue stage s+3 into buffer s%3 (its words are already in registers) -> ds_read the words of stage s+1
+  //   so neither the DMA latency nor the LDS read latency nor the first unpack is exposed at a stage boundary.
   issue(0, 0);
   if (stages > 1) issue(1, 1);
-  if (stages > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (stages > 2) issue(2, 2);
+  if (stages > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (stages > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  int buf = 0;
+  unsigned long long t0 = 0, r0 = 0;   // DIAG instantiation only: shader-clock / 100 MHz stamps around the K loop
+  if (DIAG) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+  uint4 aw[4], bw[4], awn[4], bwn[4];
+#pragma unroll
+  for (int a = 0; a < 4; a++) aw[a] = *reinterpret_cast<const uint4 *>(smem + a_off + a * 32 * kXStageBytes);
+#pragma unroll
+  for (int b = 0; b < 4; b++) bw[b] = *reinterpret_cast<const uint4 *>(smem + b_off + b * 32 * kXStageBytes);
+#pragma unroll
+  for (int a = 0; a < 4; a++) { awn[a] = aw[a]; bwn[a] = bw[a]; }
+  int buf = 0;   // buffer of stage s
+  auto comp = [](const uint4 &w, int c) -> uint32_t { return c == 0 ? w.x : c == 1 ? w.y : c == 2 ? w.z : w.w; };
+  // The unpack VALU (7 per fragment, 56 per K-step of 16 MFMAs) are software-pipelined one fragment ahead and spread into the
+  // MFMA gaps: measured with one wave per SIMD (tools/mfma_i8_probe2.hip) 3-4 VALU placed after each MFMA cost ~15 %, the same
+  // VALU clustered in front of a group of 4 MFMAs cost 70 %.
+  v4i af_cur = unpack16(aw[0].x), bf_cur[4], bf_nxt[4];
+#pragma unroll
+  for (int b = 0; b < 4; b++) bf_cur[b] = unpack16(bw[b].x);
   for (int s = 0; s < stages; s++) {
-    if (s + 2 < stages) issue(s + 2, buf == 0 ? 2 : buf - 1 == 0 ? 0 : 1);   // (buf + 2) % 3
-    const char *base = smem + buf * kXBufBytes;
-    uint4 aw[4], bw[4];
-#pragma unroll
-    for (int a = 0; a < 4; a++) aw[a] = *reinterpret_cast<const uint4 *>(base + a_off + a * 32 * kXStageBytes);
-#pragma unroll
-    for (int b = 0; b < 4; b++) bw[b] = *reinterpret_cast<const uint4 *>(base + b_off + b * 32 * kXStageBytes);
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
-      v4i bf[4];
+      if (ks == 2 && s + 1 < stages) {
+        // mid-stage: stage s+1 must have landed; the 4 DMAs of stage s+2 (if issued) may stay in flight
+        if (s + 2 < stages) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 3 < stages) issue(s + 3, buf);
+        const int nb = buf == 2 ? 0 : buf + 1;
+        const char *base = smem + nb * kXBufBytes;
 #pragma unroll
-      for (int b = 0; b < 4; b++) bf[b] = unpack16(ks == 0 ? bw[b].x : ks == 1 ? bw[b].y : ks == 2 ? bw[b].z : bw[b].w);
+        for (int a = 0; a < 4; a++) awn[a] = *reinterpret_cast<const uint4 *>(base + a_off + a * 32 * kXStageBytes);
+#pragma unroll
+        for (int b = 0; b < 4; b++) bwn[b] = *reinterpret_cast<const uint4 *>(base + b_off + b * 32 * kXStageBytes);
+        buf = nb;
+      }
 #pragma unroll
       for (int a = 0; a < 4; a++) {
-        const v4i af = unpack16(ks == 0 ? aw[a].x : ks == 1 ? aw[a].y : ks == 2 ? aw[a].z : aw[a].w);
+        // fragments needed next: A of (ks, a+1) or of (ks+1, 0); B fragment a of K-step ks+1 (next stage's first K-step after ks = 3)
+        const uint32_t wa = a < 3 ? comp(aw[a + 1], ks) : (ks < 3 ? comp(aw[0], ks + 1) : awn[0].x);
+        const uint32_t wb = ks < 3 ? comp(bw[a], ks + 1) : bwn[a].x;
+        const v4i af_nxt = unpack16(wa);
+        bf_nxt[a] = unpack16(wb);
 #pragma unroll
-        for (int b = 0; b < 4; b++) acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 4; b++) acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af_cur, bf_cur[b], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        af_cur = af_nxt;
       }
+#pragma unroll
+      for (int b = 0; b < 4; b++) bf_cur[b] = bf_nxt[b];
     }
-    // stage s+1 must have landed before anyone reads it; stage s+2 (4 DMAs of this wave) may stay in flight
-    if (s + 2 < stages) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    buf = buf == 2 ? 0 : buf + 1;
+#pragma unroll
+    for (int a = 0; a < 4; a++) { aw[a] = awn[a]; bw[a] = bwn[a]; }
+  }
+  __syncthreads();   // all waves are done with the ring before it is reused as the epilogue scratch
+  if (DIAG) {
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && diag) { diag[2 * (size_t)blockIdx.x] = t1 - t0; diag[2 * (size_t)blockIdx.x + 1] = r1 - r0; }
   }
 
   // epilogue.  32x32 C/D map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); element (gi, gj) = M[gi][gj].
@@ -292,8 +335,26 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
   static const int xver = [] { const char *e = getenv("MXA_XPROD_VER"); return e ? atoi(e) : 2; }();
   if (xver == 2) {
     static bool attr2 = false;
-    if (!attr2) { MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_crossprod2), hipFuncAttributeMaxDynamicSharedMemorySize, kX2Lds)); attr2 = true; }
-    hipLaunchKernelGGL(k_crossprod2, dim3((unsigned)tiles.size()), dim3(256), kX2Lds, s, d_X, pitch, stages, d_tiles, rows, d_ans);
+    if (!attr2) {
+      MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_crossprod2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kX2Lds));
+      MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_crossprod2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kX2Lds));
+      attr2 = true;
+    }
+    if (getenv("MXA_DIAG")) {   // diagnostic instantiation: in-kernel clock and cycles per stage
+      unsigned long long *d_diag = nullptr;
+      MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_diag), 16 * tiles.size()));
+      hipLaunchKernelGGL(k_crossprod2<true>, dim3((unsigned)tiles.size()), dim3(256), kX2Lds, s, d_X, pitch, stages, d_tiles, rows, d_ans, d_diag);
+      MXA_HIP(hipStreamSynchronize(s));
+      std::vector<unsigned long long> hd(2 * tiles.size());
+      MXA_HIP(hipMemcpy(hd.data(), d_diag, 16 * tiles.size(), hipMemcpyDeviceToHost));
+      std::vector<double> ghz, cyc;
+      for (size_t i = 0; i < tiles.size(); i++) if (hd[2 * i + 1]) { ghz.push_back((double)hd[2 * i] / (double)hd[2 * i + 1] * 0.1); cyc.push_back((double)hd[2 * i] / stages); }
+      std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end());
+      if (!ghz.empty()) printf("MXA_DIAG k_crossprod2: %zu tiles, in-kernel clock median %.3f GHz (min %.3f max %.3f); shader cycles per stage median %.0f (ideal 2048)\n",
+                               tiles.size(), ghz[ghz.size() / 2], ghz.front(), ghz.back(), cyc[cyc.size() / 2]);
+      (void)hipFree(d_diag);
+    } else
+    hipLaunchKernelGGL(k_crossprod2<false>, dim3((unsigned)tiles.size()), dim3(256), kX2Lds, s, d_X, pitch, stages, d_tiles, rows, d_ans, (unsigned long long *)nullptr);
   } else
   hipLaunchKernelGGL(k_crossprod, dim3((unsigned)tiles.size()), dim3(512), kXLds, s, d_X, pitch, stages, d_tiles, rows, d_ans);
   MXA_HIP(hipGetLastError());
