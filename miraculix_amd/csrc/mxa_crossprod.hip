@@ -393,8 +393,8 @@ __global__ void __launch_bounds__(1024) k_vec_reduce(const double *__restrict__ 
 // G = (M - cs 1^T / n - 1 cs^T / n + total / n^2) / c          (crossproduct.jl:96-107)
 __global__ void __launch_bounds__(256) k_grm_update(double *__restrict__ M, long n, const double *__restrict__ cs, const double *__restrict__ total,
                                                     const double *__restrict__ c, int do_scale) {
-  const long j = blockIdx.y;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long j = blockIdx.x;                               // column: gridDim.x may exceed 65535, gridDim.y may not
+  const long i = (long)blockIdx.y * 256 + threadIdx.x;
   if (i >= n) return;
   const double inv_n = 1.0 / (double)n;
   double v = M[(size_t)j * n + i];
@@ -406,8 +406,8 @@ __global__ void __launch_bounds__(256) k_grm_update(double *__restrict__ M, long
 }
 // LD: M <- M - 4 * indiv * f f^T ; sigma = sqrt(diag M) ; M <- M / sigma sigma^T      (crossproduct.jl:139-149)
 __global__ void __launch_bounds__(256) k_ld_center(double *__restrict__ M, long n, const double *__restrict__ f, double four_indiv) {
-  const long j = blockIdx.y;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long j = blockIdx.x;
+  const long i = (long)blockIdx.y * 256 + threadIdx.x;
   if (i >= n) return;
   M[(size_t)j * n + i] = fma(-four_indiv * f[i], f[j], M[(size_t)j * n + i]);
 }
@@ -416,8 +416,8 @@ __global__ void __launch_bounds__(256) k_diag_sqrt(const double *__restrict__ M,
   if (i < n) sigma[i] = sqrt(M[(size_t)i * n + i]);
 }
 __global__ void __launch_bounds__(256) k_ld_scale(double *__restrict__ M, long n, const double *__restrict__ sigma) {
-  const long j = blockIdx.y;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long j = blockIdx.x;
+  const long i = (long)blockIdx.y * 256 + threadIdx.x;
   if (i >= n) return;
   M[(size_t)j * n + i] = M[(size_t)j * n + i] / sigma[i] / sigma[j];
 }
@@ -427,7 +427,7 @@ static int postprocess_device(double *d_M, long rows, long k, int post, int do_s
   if (post == 0) return 0;
   double *tmp = nullptr;
   MXA_HIP(hipMalloc(reinterpret_cast<void **>(&tmp), sizeof(double) * (size_t)(rows + 4)));
-  dim3 g2((unsigned)((rows + 255) / 256), (unsigned)rows);
+  dim3 g2((unsigned)rows, (unsigned)((rows + 255) / 256));   // x = column (unbounded), y = row chunk (<= 65535)
   if (post == 1) {
     hipLaunchKernelGGL(k_sym_colsum, dim3((unsigned)rows), dim3(256), 0, s, d_M, rows, tmp);
     hipLaunchKernelGGL(k_vec_reduce, dim3(1), dim3(1024), 0, s, tmp, rows, 0, tmp + rows);

@@ -640,10 +640,11 @@ int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC
 // =====================================================================================================
 // 64 x 64 genotype tiles through LDS.  in: `rows` rows of ceil(cols/4) bytes; out: `cols` rows of ceil(rows/4) bytes.
 __global__ void __launch_bounds__(256) k_transpose_2bit(const uint8_t *__restrict__ in, long rows, long cols,
-                                                        uint8_t *__restrict__ out) {
+                                                        uint8_t *__restrict__ out, unsigned nbx) {
   __shared__ uint8_t tile[64][17];
   const long bin = (cols + 3) / 4, bout = (rows + 3) / 4;
-  const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+  // 1-D grid (either dimension may exceed the 65535 limit of gridDim.y): block = by * nbx + bx
+  const long r0 = (long)(blockIdx.x / nbx) * 64, c0 = (long)(blockIdx.x % nbx) * 64;
   {
     const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
     for (int u = 0; u < 4; u++) {
@@ -675,8 +676,9 @@ __global__ void __launch_bounds__(256) k_transpose_2bit(const uint8_t *__restric
 
 int launch_transpose_2bit(const uint8_t *d_in, long rows, long cols, uint8_t *d_out, hipStream_t s) {
   if (rows <= 0 || cols <= 0) return 0;
-  dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
-  hipLaunchKernelGGL(k_transpose_2bit, grid, dim3(256), 0, s, d_in, rows, cols, d_out);
+  const long nbx = (cols + 63) / 64, nby = (rows + 63) / 64;
+  if (nbx * nby > 0x7fffffffL) { set_error(3, "mxa_transpose_2bit: matrix too large for one launch"); return 1; }
+  hipLaunchKernelGGL(k_transpose_2bit, dim3((unsigned)(nbx * nby)), dim3(256), 0, s, d_in, rows, cols, d_out, (unsigned)nbx);
   MXA_HIP(hipGetLastError());
   return 0;
 }
