@@ -149,6 +149,8 @@ static void destroy_handle(Handle *h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void *ptrs[] = {h->snp_major.d, h->ind_major.d, h->d_f, h->ws.d_Bstage, h->ws.d_Cstage, h->ws.d_Bp, h->ws.d_P, h->ws.d_colpart};
   for (void *p : ptrs) if (p) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   free(h->h_f);
   h->magic = 0;
@@ -239,9 +241,9 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   if (!use_lut && launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s)) return 1;
   if (centered && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
   const bool prof = g_profile_on && timing;   // the asynchronous entry must not block on an event
-  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipEvent_t e0 = h->ev0, e1 = h->ev1;
   if (prof) {
-    MXA_HIP(hipEventCreate(&e0)); MXA_HIP(hipEventCreate(&e1));
+    if (!e0) { MXA_HIP(hipEventCreate(&h->ev0)); MXA_HIP(hipEventCreate(&h->ev1)); e0 = h->ev0; e1 = h->ev1; }
     MXA_HIP(hipEventRecord(e0, s));
   }
   int rc = use_lut ? launch_lut(G, dB, ldb, n, w.d_P, p, s) : launch_gemm(G, w.d_Bp, w.d_P, p, mode, s);
@@ -254,7 +256,6 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
       MXA_HIP(hipEventElapsedTime(&ms, e0, e1));
       profile().launches += 1; profile().total_ms += ms;
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   }
   return rc;
 }

@@ -62,6 +62,7 @@ struct Handle {
   int max_n = 0;
   Workspace ws;
   hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;   // timing of the dominant kernel (created once, not per call)
 };
 
 struct Profile {
