@@ -639,28 +639,35 @@ int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC
 // staging helpers: 2-bit transpose, allele frequencies (raw PLINK codes in, raw codes out)
 // =====================================================================================================
 // 64 x 64 genotype tiles through LDS.  in: `rows` rows of ceil(cols/4) bytes; out: `cols` rows of ceil(rows/4) bytes.
+// ALIGNED: both row pitches are multiples of 4 bytes -> dword loads and stores (4x fewer memory instructions).
+template <bool ALIGNED>
 __global__ void __launch_bounds__(256) k_transpose_2bit(const uint8_t *__restrict__ in, long rows, long cols,
                                                         uint8_t *__restrict__ out, unsigned nbx) {
-  __shared__ uint8_t tile[64][17];
+  __shared__ uint8_t tile[64][20];
   const long bin = (cols + 3) / 4, bout = (rows + 3) / 4;
   // 1-D grid (either dimension may exceed the 65535 limit of gridDim.y): block = by * nbx + bx
   const long r0 = (long)(blockIdx.x / nbx) * 64, c0 = (long)(blockIdx.x % nbx) * 64;
   {
     const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
-    for (int u = 0; u < 4; u++) {
-      const long byte = c0 / 4 + part * 4 + u;
-      uint8_t v = 0;
-      if (r0 + r < rows && byte < bin) v = in[(size_t)(r0 + r) * bin + byte];
-      tile[r][part * 4 + u] = v;
+    const long byte0 = c0 / 4 + part * 4;
+    uint32_t w = 0;
+    if (r0 + r < rows) {
+      if (ALIGNED && byte0 + 3 < bin) {
+        w = *reinterpret_cast<const uint32_t *>(in + (size_t)(r0 + r) * bin + byte0);
+      } else {
+        for (int u = 0; u < 4; u++)
+          if (byte0 + u < bin) w |= (uint32_t)in[(size_t)(r0 + r) * bin + byte0 + u] << (8 * u);
+      }
     }
+    *reinterpret_cast<uint32_t *>(&tile[r][part * 4]) = w;
   }
   __syncthreads();
   {
     const int c = threadIdx.x >> 2, q = threadIdx.x & 3;  // output row c0+c, output bytes 4q..4q+3 of this tile
     if (c0 + c < cols) {
+      const long obyte0 = r0 / 4 + 4 * q;
+      uint32_t wout = 0;
       for (int ob = 0; ob < 4; ob++) {
-        const long obyte = r0 / 4 + 4 * q + ob;
-        if (obyte >= bout) break;
         uint32_t v = 0;
         for (int u = 0; u < 4; u++) {
           const int r = 16 * q + 4 * ob + u;
@@ -668,7 +675,13 @@ __global__ void __launch_bounds__(256) k_transpose_2bit(const uint8_t *__restric
           if (r0 + r >= rows) code = 0;
           v |= code << (2 * u);
         }
-        out[(size_t)(c0 + c) * bout + obyte] = (uint8_t)v;
+        wout |= v << (8 * ob);
+      }
+      if (ALIGNED && obyte0 + 3 < bout) {
+        *reinterpret_cast<uint32_t *>(out + (size_t)(c0 + c) * bout + obyte0) = wout;
+      } else {
+        for (int ob = 0; ob < 4; ob++)
+          if (obyte0 + ob < bout) out[(size_t)(c0 + c) * bout + obyte0 + ob] = (uint8_t)(wout >> (8 * ob));
       }
     }
   }
@@ -678,12 +691,23 @@ int launch_transpose_2bit(const uint8_t *d_in, long rows, long cols, uint8_t *d_
   if (rows <= 0 || cols <= 0) return 0;
   const long nbx = (cols + 63) / 64, nby = (rows + 63) / 64;
   if (nbx * nby > 0x7fffffffL) { set_error(3, "mxa_transpose_2bit: matrix too large for one launch"); return 1; }
-  hipLaunchKernelGGL(k_transpose_2bit, dim3((unsigned)(nbx * nby)), dim3(256), 0, s, d_in, rows, cols, d_out, (unsigned)nbx);
+  const long bin = (cols + 3) / 4, bout = (rows + 3) / 4;
+  const bool aligned = (bin % 4 == 0) && (bout % 4 == 0) && (reinterpret_cast<uintptr_t>(d_in) % 4 == 0) && (reinterpret_cast<uintptr_t>(d_out) % 4 == 0);
+  if (aligned) hipLaunchKernelGGL(k_transpose_2bit<true>, dim3((unsigned)(nbx * nby)), dim3(256), 0, s, d_in, rows, cols, d_out, (unsigned)nbx);
+  else hipLaunchKernelGGL(k_transpose_2bit<false>, dim3((unsigned)(nbx * nby)), dim3(256), 0, s, d_in, rows, cols, d_out, (unsigned)nbx);
   MXA_HIP(hipGetLastError());
   return 0;
 }
 
-// f_s = (sum of allele counts of SNP s, missing counted 0) / (2*indiv); one wave per SNP row
+// f_s = (sum of allele counts of SNP s, missing counted 0) / (2*indiv); one wave per SNP row, 16 bytes per lane per step when
+// the rows are 16-byte aligned (then the tail bytes, byte-wise)
+__device__ __forceinline__ unsigned count16(uint32_t w) {   // sum of the 16 allele counts in a dword of PLINK codes
+  const uint32_t z = recode16(w);
+  const uint32_t s2 = (z & 0x33333333u) + ((z >> 2) & 0x33333333u);      // 8 nibbles, each <= 4
+  const uint32_t s4 = (s2 & 0x0F0F0F0Fu) + ((s2 >> 4) & 0x0F0F0F0Fu);    // 4 bytes, each <= 8
+  return (s4 * 0x01010101u) >> 24;
+}
+
 __global__ void __launch_bounds__(256) k_allele_freq(const uint8_t *__restrict__ plink, long snps, long indiv, double *__restrict__ f) {
   const long s = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -691,12 +715,21 @@ __global__ void __launch_bounds__(256) k_allele_freq(const uint8_t *__restrict__
   const long bps = (indiv + 3) / 4;
   const uint8_t *row = plink + (size_t)s * bps;
   unsigned long long cnt = 0;
-  for (long b = lane; b < bps; b += 64) {
+  const long full = indiv / 4;                              // bytes whose 4 fields all exist
+  // head bytes up to the first 16-byte boundary, then 16 bytes per lane per step, then the tail
+  long head = (long)((16 - (reinterpret_cast<uintptr_t>(row) & 15)) & 15);
+  if (head > full) head = full;
+  const long nvec = (full - head) / 16;
+  for (long v = lane; v < nvec; v += 64) {
+    const uint4 w = *reinterpret_cast<const uint4 *>(row + head + v * 16);
+    cnt += count16(w.x) + count16(w.y) + count16(w.z) + count16(w.w);
+  }
+  for (long b = lane; b < head; b += 64) cnt += count16(row[b]);
+  for (long b = head + nvec * 16 + lane; b < bps; b += 64) {
     uint32_t w = row[b];
     long valid = indiv - 4 * b;
     if (valid < 4) w &= (1u << (2 * valid)) - 1u;
-    const uint32_t z = recode16(w);
-    cnt += (z & 3u) + ((z >> 2) & 3u) + ((z >> 4) & 3u) + ((z >> 6) & 3u);
+    cnt += count16(w);
   }
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
   if (lane == 0) f[s] = (double)cnt / (2.0 * (double)indiv);
