@@ -1,7 +1,7 @@
 /* miraculix_amd.h -- C ABI of the MI355X-native compressed-genotype GEMM engine.
  *
  * Part 1 is the drop-in boundary: exactly the unmangled C symbols the reference's language bindings
- * bind (dlopen + ccall in src/bindings/Julia/*.jl, bind(C) in src/bindings/Fortran/mod5codesapi.f90).
+ * bind (dlopen + ccall in src/bindings/Julia/{dgemm_compressed,crossproduct}.jl, bind(C) in src/bindings/Fortran/mod5codesapi.f90).
  * Each declaration cites the reference interface it replaces (paths relative to the reference repo).
  * Part 2 are additive entry points (prefix mxa_) for device-resident operands, SNP-sharded multi-GPU
  * use, on-device .bed staging helpers and measurement; the reference has no counterpart for them.
@@ -109,6 +109,16 @@ int mxa_bed2compressed(const char *bed_path, int snps, int indiv, int max_n, voi
 int mxa_grm(const unsigned char *plink_transposed, int snps, int indiv, double *G, int is_plink_format, int do_scale,
             const double *allele_freq);
 int mxa_ld(const unsigned char *plink, int snps, int indiv, double *R, int is_plink_format, const double *allele_freq);
+
+/* multiply engine of dgemm_compressed (process-wide).  0 (default): fp64 on v_mfma_f64_4x4x4_4b_f64, the arithmetic of the
+ * reference (fp64 FMAs).  1 (opt-in, also MXA_ENGINE=i8 in the environment): each column of B is split exactly into 8 signed
+ * 7-bit digits relative to the column's largest entry, the digit matrices are multiplied with the 0/1/2 genotypes on the int8
+ * matrix cores with exact int32 accumulation, and the 8 integer results are recombined in fp64.  B is thereby represented to
+ * 2^-57 of each column's largest |entry| (fixed point per column, not per element); results agree with engine 0 to ~1e-14 of
+ * each result column's largest entry on the test problems, at ~4x the throughput.  mxa_set_engine returns the previous value
+ * (an invalid argument leaves the engine unchanged). */
+int mxa_set_engine(int engine);
+int mxa_get_engine(void);
 
 /* measurement: HIP-event timing of the dominant kernel on the stream it is launched on.
  * mxa_profile_reset() clears the counters; after some dgemm_compressed / snp_multiply_gpu calls

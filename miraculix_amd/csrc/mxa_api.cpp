@@ -8,6 +8,7 @@
 #include "mxa_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -25,6 +26,8 @@ Options &options() { static Options o; return o; }
 Profile &profile() { static Profile p; return p; }
 Geometry &last_geometry() { static Geometry g; return g; }
 static bool g_profile_on = true;
+// multiply engine: 0 = fp64 MFMA (default), 1 = exact int8 slicing on the int8 MFMA (opt-in; MXA_ENGINE=i8 or mxa_set_engine)
+static std::atomic<int> g_engine{[] { const char *e = getenv("MXA_ENGINE"); return (e && std::string(e) == "i8") ? 1 : 0; }()};
 
 int env_print_level() {  // reference: cuda_utils.cu:44-52, env PRINT_LEVEL
   const char *e = getenv("PRINT_LEVEL");
@@ -147,7 +150,7 @@ static void destroy_handle(Handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void *ptrs[] = {h->snp_major.d, h->ind_major.d, h->d_f, h->ws.d_Bstage, h->ws.d_Cstage, h->ws.d_Bp, h->ws.d_P, h->ws.d_colpart};
+  void *ptrs[] = {h->snp_major.d, h->ind_major.d, h->d_f, h->ws.d_Bstage, h->ws.d_Cstage, h->ws.d_Bp, h->ws.d_P, h->ws.d_colpart, h->ws.d_i8};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -238,6 +241,21 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c;
   double *d_sumB = w.d_colpart + (size_t)n * 128, *d_sumfB = d_sumB + n;
   static const int mode = [] { const char *e = getenv("MXA_GEMM_MODE"); return e ? atoi(e) : 0; }();
+  if (g_engine.load() == 1) {   // opt-in: exact int8 slicing of B on the int8 matrix cores (mxa_gemm_i8.hip)
+    if (centered && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
+    const bool prof8 = g_profile_on && timing;
+    if (prof8 && !h->ev0) { MXA_HIP(hipEventCreate(&h->ev0)); MXA_HIP(hipEventCreate(&h->ev1)); }
+    int splits8 = 1;
+    if (gemm_i8_device(G, trans, n, dB, ldb, dC, ldc, centered, d_sumB, d_sumfB, h->d_f, w, s, prof8 ? h->ev0 : nullptr, prof8 ? h->ev1 : nullptr, &splits8)) return 1;
+    geo.splits = splits8; geo.a = 0; geo.c = 0;
+    if (prof8) {
+      MXA_HIP(hipEventSynchronize(h->ev1));
+      float ms = 0.f;
+      MXA_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+      profile().launches += 1; profile().total_ms += ms;
+    }
+    return 0;
+  }
   if (!use_lut && launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s)) return 1;
   if (centered && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
   const bool prof = g_profile_on && timing;   // the asynchronous entry must not block on an event
@@ -382,6 +400,12 @@ int mxa_device_count(void) {
   if (hipGetDeviceCount(&c) != hipSuccess) { (void)hipGetLastError(); return -1; }
   return c;
 }
+
+int mxa_set_engine(int engine) {
+  if (engine != 0 && engine != 1) return g_engine.load();
+  return g_engine.exchange(engine);
+}
+int mxa_get_engine(void) { return g_engine.load(); }
 
 void mxa_profile_reset(void) { profile() = Profile(); }
 void mxa_profile_get(int *launches, double *total_ms) {

@@ -1,0 +1,421 @@
+// mxa_gemm_i8.hip -- OPT-IN engine (env MXA_ENGINE=i8): dgemm_compressed on the int8 matrix cores by exact slicing of B.
+//
+// Not the shipped default: the default path computes in fp64 on v_mfma_f64_4x4x4_4b_f64 (mxa_kernels.hip), as the reference
+// does in fp64 FMAs.  This engine exploits that the genotype operand is an exact small integer (0,1,2):
+//   per column j,  b_kj = 2^(E_j) * sum_{s<S} t_s(k,j) * 2^(-7(s+1)) + r_kj,   t_s int8 in [-64, 64],  |r| <= 2^(E_j - 7S - 1)
+//   (Z B)_ij = sum_s 2^(E_j - 7(s+1)) * ( sum_k z_ik t_s(k,j) )                 <- exact int32 dot products on the int8 MFMA
+// (the "Ozaki" error-free splitting of one operand).  With S = 8 slices B is represented to 2^-57 of each column's largest
+// entry; all integer sums are exact, only the final S-term fp64 combination rounds.  Error bound per output:
+// K * 2 * 2^(E_j - 57), i.e. <= 1.6e-11 * max_k|b_kj| at K = 1M in the worst case (all residuals aligned), ~7e-15 typical --
+// at or below the rounding error of an fp64 dot product of that length, but it is a column-wise fixed-point representation,
+// not element-wise fp64, so it stays opt-in and is never what bench.py reports.
+//
+// Kernel: one workgroup (4 waves, one per SIMD) per 256-row tile of the packed matrix and K range; wave tile 64 rows x
+// (NT x 32) expanded columns (column e = slice * nc + j); accumulators NT x 2 tiles of v_mfma_i32_32x32x32_i8 (<= 256 AGPRs).
+// Same LDS-DMA ring / mid-stage prefetch / unpack pipelining as k_crossprod2; A rows come from the tiled packed layout, the
+// int8 slices of B are pre-arranged in MFMA fragment order by k_slice_B so every LDS read is a lane-linear ds_read_b128.
+#include "mxa_internal.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace mxa {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+using lptr_t = __attribute__((address_space(3))) void *;
+
+__device__ __forceinline__ void idma16_s(const void *sbase, uint32_t voff, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ v4i iunpack16(uint32_t w) {
+  v4i r;
+  r[0] = (int)(w & 0x03030303u);
+  r[1] = (int)((w >> 2) & 0x03030303u);
+  r[2] = (int)((w >> 4) & 0x03030303u);
+  r[3] = (int)((w >> 6) & 0x03030303u);
+  return r;
+}
+
+// ---- per-column exponent: E_j = exponent e with max_k |b_kj| < 2^(e-1)  (so that |b * 2^-E| < 1/2 and the first digit fits [-64,64])
+__global__ void __launch_bounds__(256) k_colmax_partial(const double *__restrict__ B, long ldb, long k, double *__restrict__ part) {
+  const int j = blockIdx.y, c = blockIdx.x;
+  const long per = (k + 63) / 64;
+  const long c0 = c * per, c1 = std::min<long>(k, c0 + per);
+  double m = 0.0;
+  for (long r = c0 + threadIdx.x; r < c1; r += 256) m = fmax(m, fabs(B[r + (long)j * ldb]));
+  __shared__ double sh[256];
+  sh[threadIdx.x] = m;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + w]); __syncthreads(); }
+  if (threadIdx.x == 0) part[(size_t)j * 64 + c] = sh[0];
+}
+__global__ void k_colexp_final(const double *__restrict__ part, int n, int *__restrict__ E) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double m = 0.0;
+  for (int c = 0; c < 64; c++) m = fmax(m, part[(size_t)j * 64 + c]);
+  int e = 0;
+  if (m > 0.0 && isfinite(m)) { (void)frexp(m, &e); e += 1; }   // m = f * 2^e', f in [0.5,1)  ->  m < 2^e' = 2^(E-1)
+  E[j] = e;
+}
+
+// ---- slices in MFMA fragment order.  Bs[chunk][T][nt][lane][16]: T = K-step of 32 genotypes, nt = 32-wide tile of expanded
+// columns e = s * nc + jj (slice s, column jj of the chunk), lane = (col = lane&31, h = lane>>5), byte 4q+i of the lane =
+// digit of B[128(T/4) + 64h + 16(T%4) + 4i + q][chunk*nc + jj]: a lane of half h reads the 16 bytes (64 genotypes) 16h.. of its row
+// per 128-genotype stage and uses dword T%4 of them in K-step T%4; iunpack16 puts field 4i+q of that dword into byte i of register q.
+__global__ void __launch_bounds__(256) k_slice_B(const double *__restrict__ B, long ldb, long k, int n, const int *__restrict__ E, int S, int nc, int NT,
+                                                 long T_total, int ncols, uint32_t *__restrict__ Bs, long total) {
+  // one thread per (q, column cj = chunk*nc + jj, h, T): reads the 4 values k = 128(T/4) + 64h + 16(T%4) + 4i + q (i = 0..3), writes dword q of
+  // lane (h, col) for each slice.  q runs fastest, then the column: 16-byte lane records and 128-byte runs of doubles.
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(idx & 3);
+    const long rest = idx >> 2;
+    const int cj = (int)(rest % ncols);
+    const long hT = rest / ncols;
+    const int h = (int)(hT & 1);
+    const long T = hT >> 1;
+    const int chunk = cj / nc, jj = cj % nc;
+    double r[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const long kk = 128 * (T >> 2) + 64 * h + 16 * (T & 3) + 4 * i + q;   // K order of the A operand: see k_gemm_i8
+      r[i] = (kk < k && cj < n) ? ldexp(B[kk + (long)cj * ldb], -E[cj]) : 0.0;     // |r| < 1/2, exact scaling
+    }
+    for (int s = 0; s < S; s++) {
+      uint32_t w = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const double v = r[i] * 128.0;            // exact
+        const double t = rint(v);                 // |t| <= 64
+        r[i] = v - t;                             // exact, |r| <= 1/2
+        w |= ((uint32_t)(int)t & 0xffu) << (8 * i);
+      }
+      const int e = s * nc + jj;
+      const int nt = e >> 5, col = e & 31;
+      Bs[((((size_t)chunk * T_total + T) * NT + nt) * 64 + (size_t)(h * 32 + col)) * 4 + q] = w;
+    }
+  }
+}
+
+// ---- main kernel
+constexpr int kI8Waves = 4;
+constexpr int kI8StageK = 128;                    // genotypes per stage = one slab of the tiled layout
+constexpr int kI8ABytes = kTileRows * kSlabBytes; // 8 KiB
+
+template <int NT>
+struct I8Cfg {
+  static constexpr int kBBytes = 4 * NT * 1024;   // 4 K-steps x NT tiles x 1 KiB
+  static constexpr int kBufBytes = kI8ABytes + kBBytes;
+  // ring depth: as many stages as fit the 160 KiB LDS when one workgroup owns the CU (NT >= 5)
+  // NT <= 4 needs at most 128 accumulator registers: two workgroups share a CU (3 buffers each) and hide each other's waits.
+  static constexpr int kBufs = NT <= 4 ? 3 : 163840 / kBufBytes;
+  static constexpr int kLds = kBufs * kBufBytes;
+  static constexpr int kUnits = 8 + 4 * NT;       // 1 KiB DMA units per stage
+};
+
+// scheduling pattern of one group of NM MFMAs: after MFMA i one LDS read (while i < NLOAD) and its share of the 7 unpack VALU
+template <int I, int NM, int NLOAD>
+struct SchedIter {
+  static __device__ __forceinline__ void run() {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if constexpr (I < NLOAD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    constexpr int nv = 7 / NM + (I < 7 % NM ? 1 : 0);
+    if constexpr (nv > 0) __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);
+    if constexpr (I + 1 < NM) SchedIter<I + 1, NM, NLOAD>::run();
+  }
+};
+
+// Wave layout: WC waves side by side along the expanded columns, 4/WC along the rows; wave tile (MT x 32) rows x (NT/WC x 32)
+// columns with MT * (4/WC) = 8 so that a workgroup covers one 256-row tile of the packed layout.
+//   <NT, 2, 1>: every wave reads all NT B fragments per K-step (LDS read traffic 4 x NT KiB per K-step of 512 MFMA cycles)
+//   <NT, 4, 2>: wave tile 128 x (NT/2 x 32): half the B-fragment LDS traffic, twice the unpack VALU (28 per 16 MFMAs)
+template <int NT, int MT, int WC, bool DIAG>
+__global__ void __launch_bounds__(256, 1)
+k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict__ Bs, long T_total, int *__restrict__ P, long m_pad, int e_pad,
+          int rowblocks, int nchunks, int stages_total, int stages_per_split, unsigned long long *__restrict__ diag) {
+  using Cfg = I8Cfg<NT>;
+  constexpr int NTW = NT / WC;
+  static_assert(NT % WC == 0 && MT * (4 / WC) == 8 && MT * NTW <= 16, "wave tiling");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave / WC, wc = wave % WC;
+  int bid = blockIdx.x;
+  const int rb = bid % rowblocks; bid /= rowblocks;
+  const int nc = bid % nchunks;
+  const int sp = bid / nchunks;
+  const int st0 = sp * stages_per_split, st1 = min(st0 + stages_per_split, stages_total);
+  const int stages = st1 - st0;
+  const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
+  const uint32_t v_lane = lane * 16;
+  const char *A_u = reinterpret_cast<const char *>(G) + (size_t)rb * (pitch / kSlabBytes) * kTileBytes;
+  const char *B_u = reinterpret_cast<const char *>(Bs) + (size_t)nc * ((size_t)T_total * NT * 1024);
+
+  auto issue = [&](int stage, int buf) {   // stage index relative to st0
+    const uint32_t base = lds0 + buf * Cfg::kBufBytes;
+    const char *asrc = A_u + (size_t)(st0 + stage) * kTileBytes;
+    const char *bsrc = B_u + (size_t)(st0 + stage) * ((size_t)4 * NT * 1024);
+#pragma unroll
+    for (int i = 0; i < (Cfg::kUnits + kI8Waves - 1) / kI8Waves; i++) {
+      const int u = wave + i * kI8Waves;
+      if (Cfg::kUnits % kI8Waves == 0 || u < Cfg::kUnits) {
+        if (u < 8) idma16_s(asrc + u * 1024, v_lane, base + u * 1024);
+        else idma16_s(bsrc + (u - 8) * 1024, v_lane, base + kI8ABytes + (u - 8) * 1024);
+      }
+    }
+  };
+
+  v16i acc[MT][NTW];
+#pragma unroll
+  for (int a = 0; a < MT; a++)
+#pragma unroll
+    for (int b = 0; b < NTW; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0;
+
+  const int a_off = (wr * (MT * 32) + (lane & 31)) * kSlabBytes + (lane >> 5) * 16;
+  const int b_off = kI8ABytes + (wc * NTW) * 1024 + lane * 16;
+
+  constexpr int NB = Cfg::kBufs;
+  constexpr int kPerWave = Cfg::kUnits / kI8Waves;     // 2 + NT DMAs per wave and stage
+  static_assert(Cfg::kUnits % kI8Waves == 0 && (NB - 2) * kPerWave < 64, "vmcnt bookkeeping");
+  // Ring of NB buffers.  At the middle of stage s every wave has finished stage s-1, so that buffer takes stage s+NB-1; stage s+1 is
+  // waited for there (stages s+2 .. s+NB-2 stay in flight) and its packed A words are prefetched into registers.  B fragments are
+  // read from LDS one K-step ahead of their use, so the buffer of stage s stays live until the stage ends.
+#pragma unroll
+  for (int i = 0; i < NB - 1; i++) if (i < stages) issue(i, i);
+  if (stages >= NB - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * kPerWave) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  unsigned long long t0 = 0, r0 = 0;   // DIAG instantiation only: shader-clock / 100 MHz stamps around the K loop
+  if (DIAG) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+  uint4 aw[MT], awn[MT];
+#pragma unroll
+  for (int a = 0; a < MT; a++) { aw[a] = *reinterpret_cast<const uint4 *>(smem + a_off + a * 32 * kSlabBytes); awn[a] = aw[a]; }
+  int buf = 0;
+  auto comp = [](const uint4 &w, int c) -> uint32_t { return c == 0 ? w.x : c == 1 ? w.y : c == 2 ? w.z : w.w; };
+  v4i af_cur = iunpack16(aw[0].x);
+  v4i bf_cur[NTW], bf_nxt[NTW];
+#pragma unroll
+  for (int b = 0; b < NTW; b++) { bf_cur[b] = *reinterpret_cast<const v4i *>(smem + b_off + b * 1024); bf_nxt[b] = bf_cur[b]; }
+  for (int s = 0; s < stages; s++) {
+    const char *bbase = smem + buf * Cfg::kBufBytes + b_off;
+    const int nb = buf == NB - 1 ? 0 : buf + 1;
+    const char *bnext = smem + (s + 1 < stages ? nb : buf) * Cfg::kBufBytes + b_off;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      if (ks == 2 && s + 1 < stages) {
+        if (s + NB - 2 < stages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 3) * kPerWave) : "memory");   // stage s+1 has landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + NB - 1 < stages) issue(s + NB - 1, buf == 0 ? NB - 1 : buf - 1);
+#pragma unroll
+        for (int a = 0; a < MT; a++) awn[a] = *reinterpret_cast<const uint4 *>(smem + nb * Cfg::kBufBytes + a_off + a * 32 * kSlabBytes);
+      }
+      // B fragments of the next K-step (after ks = 3: of the next stage, landed and visible since the barrier above; in the very
+      // last K-step the current buffer is re-read and the values are never used).  The reads and the unpack VALU are pinned
+      // between the MFMAs (sched_group_barrier): left alone the compiler sinks the reads to just before their first use and
+      // clusters the VALU, which exposes the LDS latency in every K-step.
+      const char *bsrc = ks < 3 ? bbase + (ks + 1) * NT * 1024 : bnext;
+#pragma unroll
+      for (int a = 0; a < MT; a++) {
+        const uint32_t wa = a < MT - 1 ? comp(aw[a + 1], ks) : (ks < 3 ? comp(aw[0], ks + 1) : awn[0].x);
+        const v4i af_nxt = iunpack16(wa);
+        const int lo = a * NTW / MT, hi = (a + 1) * NTW / MT;
+#pragma unroll
+        for (int b = 0; b < NTW; b++)
+          if (b >= lo && b < hi) bf_nxt[b] = *reinterpret_cast<const v4i *>(bsrc + b * 1024);
+#pragma unroll
+        for (int b = 0; b < NTW; b++) acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af_cur, bf_cur[b], acc[a][b], 0, 0, 0);
+        SchedIter<0, NTW, (NTW + MT - 1) / MT>::run();
+        __builtin_amdgcn_sched_barrier(0);
+        af_cur = af_nxt;
+      }
+#pragma unroll
+      for (int b = 0; b < NTW; b++) bf_cur[b] = bf_nxt[b];
+    }
+    buf = nb;
+#pragma unroll
+    for (int a = 0; a < MT; a++) aw[a] = awn[a];
+  }
+
+  if (DIAG) {
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && diag) { diag[2 * (size_t)blockIdx.x] = t1 - t0; diag[2 * (size_t)blockIdx.x + 1] = r1 - r0; }
+  }
+  // epilogue: P[split][row][e] int32, e contiguous: lanes (col) write 128-byte runs.  C/D map: col = lane&31,
+  // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const int col = lane & 31, rq = 4 * (lane >> 5);
+  int *Pb = P + (size_t)sp * m_pad * e_pad;
+#pragma unroll
+  for (int a = 0; a < MT; a++)
+#pragma unroll
+    for (int b = 0; b < NTW; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const long row = (long)rb * kTileRows + wr * (MT * 32) + a * 32 + (r & 3) + 8 * (r >> 2) + rq;
+        Pb[(size_t)row * e_pad + (size_t)nc * (NT * 32) + (wc * NTW + b) * 32 + col] = acc[a][b][r];
+      }
+}
+
+// ---- finish: sum the splits exactly (int64), combine the slices smallest scale first, centring, ldc store.
+// Block = 32 rows x one chunk of columns; P is read with the expanded column running along the lanes, the result is
+// transposed through LDS so that C is written with the row running along the lanes.
+__global__ void __launch_bounds__(256) k_finish_i8(const int *__restrict__ P, long m_pad, int e_pad, int splits, long m, int n, int S, int nc, int NT,
+                                                   const int *__restrict__ E, double *__restrict__ Cout, long ldc, int mode_trans, int centered,
+                                                   const double *__restrict__ sumB, const double *__restrict__ sumfB, const double *__restrict__ f) {
+  __shared__ double sh[32][33];
+  const int chunk = blockIdx.y;
+  const long r0 = (long)blockIdx.x * 32;
+  {
+    const int jj = threadIdx.x & 31;
+    const int j = chunk * nc + jj;
+    for (int rr = threadIdx.x >> 5; rr < 32; rr += 8) {
+      const long r = r0 + rr;
+      double v = 0.0;
+      if (r < m && jj < nc && j < n) {
+        const int Ej = E[j];
+        for (int s = S - 1; s >= 0; s--) {
+          const int e = chunk * (NT * 32) + s * nc + jj;
+          long long t = 0;
+          for (int sp = 0; sp < splits; sp++) t += P[((size_t)sp * m_pad + r) * e_pad + e];
+          v += ldexp((double)t, Ej - 7 * (s + 1));
+        }
+        if (centered) {
+          if (mode_trans) v = fma(-2.0 * sumB[j], f[r], v);
+          else v += -2.0 * sumfB[j];
+        }
+      }
+      sh[rr][jj] = v;
+    }
+  }
+  __syncthreads();
+  {
+    const int rr = threadIdx.x & 31;
+    const long r = r0 + rr;
+    for (int jj = threadIdx.x >> 5; jj < nc; jj += 8) {
+      const int j = chunk * nc + jj;
+      if (r < ldc && j < n) Cout[r + (long)j * ldc] = sh[rr][jj];
+    }
+  }
+}
+
+struct I8Plan { int S, nc, nchunks, NT, e_pad, rowblocks, stages_total, stages_per_split, splits; long m_pad, T_total; };
+
+static I8Plan plan_i8(long m, long k_pad, int n) {
+  I8Plan p{};
+  static const int S = [] { const char *e = getenv("MXA_I8_SLICES"); int s = e ? atoi(e) : 8; return std::min(9, std::max(4, s)); }();
+  p.S = S;
+  const int max_nc = 256 / S;                                   // <= 8 tiles of 32 expanded columns per pass
+  p.nchunks = (n + max_nc - 1) / max_nc;
+  p.nc = (n + p.nchunks - 1) / p.nchunks;
+  p.NT = (p.nc * S + 31) / 32;
+  p.e_pad = p.nchunks * p.NT * 32;
+  p.rowblocks = (int)((m + kTileRows - 1) / kTileRows);
+  p.m_pad = (long)p.rowblocks * kTileRows;
+  p.stages_total = (int)(k_pad / kI8StageK);
+  p.T_total = k_pad / 32;
+  const long units = (long)p.rowblocks * p.nchunks;
+  long want = (2048 + units - 1) / units;                        // 256 resident workgroups -> >= 8 rounds
+  long max_splits = std::max<long>(1, p.stages_total / 32);
+  long splits = std::max<long>(1, std::min<long>(want, max_splits));
+  p.stages_per_split = (int)((p.stages_total + splits - 1) / splits);
+  p.splits = (p.stages_total + p.stages_per_split - 1) / p.stages_per_split;
+  return p;
+}
+
+template <int NT, int MT, int WC>
+static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const I8Plan &p, hipStream_t s) {
+  using Cfg = I8Cfg<NT>;
+  static bool attr = false;
+  if (!attr) {
+    MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_i8<NT, MT, WC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds));
+    MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_i8<NT, MT, WC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds));
+    attr = true;
+  }
+  const long grid = (long)p.rowblocks * p.nchunks * p.splits;
+  static const bool diag_on = getenv("MXA_DIAG") != nullptr;
+  if (diag_on) {   // in-kernel clocks: shader cycles and 100 MHz ticks per workgroup K loop
+    unsigned long long *d_diag = nullptr;
+    MXA_HIP(hipMalloc((void **)&d_diag, sizeof(unsigned long long) * 2 * grid));
+    hipLaunchKernelGGL((k_gemm_i8<NT, MT, WC, true>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBs, p.T_total, dP, p.m_pad, p.e_pad,
+                       p.rowblocks, p.nchunks, p.stages_total, p.stages_per_split, d_diag);
+    std::vector<unsigned long long> h(2 * grid);
+    MXA_HIP(hipStreamSynchronize(s));
+    MXA_HIP(hipMemcpy(h.data(), d_diag, sizeof(unsigned long long) * 2 * grid, hipMemcpyDeviceToHost));
+    (void)hipFree(d_diag);
+    std::vector<double> ghz, cyc;
+    for (long i = 0; i < grid; i++) if (h[2 * i + 1] > 0) { ghz.push_back((double)h[2 * i] / ((double)h[2 * i + 1] * 10.0)); cyc.push_back((double)h[2 * i] / p.stages_per_split); }
+    std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end());
+    if (!ghz.empty()) printf("MXA_DIAG k_gemm_i8<%d,%d,%d>: %ld workgroups, in-kernel clock median %.3f GHz (min %.3f max %.3f); shader cycles per stage median %.0f (ideal %d)\n",
+                             NT, MT, WC, grid, ghz[ghz.size() / 2], ghz.front(), ghz.back(), cyc[cyc.size() / 2], 4 * 2 * NT * 32);
+    return 0;
+  }
+  hipLaunchKernelGGL((k_gemm_i8<NT, MT, WC, false>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBs, p.T_total, dP, p.m_pad, p.e_pad,
+                     p.rowblocks, p.nchunks, p.stages_total, p.stages_per_split, (unsigned long long *)nullptr);
+  MXA_HIP(hipGetLastError());
+  return 0;
+}
+
+// Whole product on the device; B, C device pointers; asynchronous on s.  The workspace (exponents, slices, partials) lives with the
+// handle and only grows.
+int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, bool centered, const double *d_sumB,
+                   const double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out) {
+  const long m = G.rows, k = G.k;
+  const I8Plan p = plan_i8(m, G.k_pad, n);
+  if (p.m_pad > G.rows_pad) { set_error(4, "internal: packed matrix smaller than the i8 plan"); return 1; }
+  if (splits_out) *splits_out = p.splits;
+  auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t part_bytes = up(sizeof(double) * 64 * n), e_bytes = up(sizeof(int) * n);
+  const size_t bs_bytes = up((size_t)p.nchunks * p.T_total * p.NT * 1024);
+  const size_t p_bytes = up(sizeof(int) * (size_t)p.splits * p.m_pad * p.e_pad);
+  const size_t need = part_bytes + e_bytes + bs_bytes + p_bytes;
+  if (w.cap_i8 < need) {
+    MXA_HIP(hipStreamSynchronize(s));
+    if (w.d_i8) { MXA_HIP(hipFree(w.d_i8)); w.d_i8 = nullptr; w.cap_i8 = 0; }
+    MXA_HIP(hipMalloc(&w.d_i8, need));
+    w.cap_i8 = need;
+  }
+  char *base = static_cast<char *>(w.d_i8);
+  double *d_part = reinterpret_cast<double *>(base);
+  int *d_E = reinterpret_cast<int *>(base + part_bytes);
+  int8_t *d_Bs = reinterpret_cast<int8_t *>(base + part_bytes + e_bytes);
+  int *d_P = reinterpret_cast<int *>(base + part_bytes + e_bytes + bs_bytes);
+
+  hipLaunchKernelGGL(k_colmax_partial, dim3(64, n), dim3(256), 0, s, dB, ldb, k, d_part);
+  hipLaunchKernelGGL(k_colexp_final, dim3((n + 63) / 64), dim3(64), 0, s, d_part, n, d_E);
+  if (p.NT * 32 != p.nc * p.S) MXA_HIP(hipMemsetAsync(d_Bs, 0, bs_bytes, s));   // expanded columns beyond nc*S are never written
+  {
+    const int ncols = p.nchunks * p.nc;
+    const long total = (long)p.T_total * 2 * ncols * 4;
+    hipLaunchKernelGGL(k_slice_B, dim3((unsigned)std::min<long>((total + 255) / 256, 256L * 64)), dim3(256), 0, s, dB, ldb, k, n, d_E, p.S, p.nc, p.NT,
+                       p.T_total, ncols, reinterpret_cast<uint32_t *>(d_Bs), total);
+  }
+  MXA_HIP(hipGetLastError());
+  if (ev0) MXA_HIP(hipEventRecord(ev0, s));
+  int rc = 0;
+  switch (p.NT) {
+    case 1: rc = launch_i8_t<1, 2, 1>(G, d_Bs, d_P, p, s); break;
+    case 2: rc = launch_i8_t<2, 2, 1>(G, d_Bs, d_P, p, s); break;
+    case 3: rc = launch_i8_t<3, 2, 1>(G, d_Bs, d_P, p, s); break;
+    case 4: rc = launch_i8_t<4, 2, 1>(G, d_Bs, d_P, p, s); break;
+    case 5: rc = launch_i8_t<5, 2, 1>(G, d_Bs, d_P, p, s); break;
+    case 6: rc = launch_i8_t<6, 2, 1>(G, d_Bs, d_P, p, s); break;
+    case 7: rc = launch_i8_t<7, 2, 1>(G, d_Bs, d_P, p, s); break;
+    default: rc = launch_i8_t<8, 4, 2>(G, d_Bs, d_P, p, s); break;
+  }
+  if (rc) return rc;
+  if (ev1) MXA_HIP(hipEventRecord(ev1, s));
+  {
+    dim3 grid((unsigned)((ldc + 31) / 32), p.nchunks);
+    hipLaunchKernelGGL(k_finish_i8, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, dC, ldc, trans ? 1 : 0,
+                       centered ? 1 : 0, d_sumB, d_sumfB, d_f);
+  }
+  MXA_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace mxa

@@ -46,6 +46,7 @@ struct Workspace {
   double *d_Bp = nullptr;     size_t cap_Bp = 0;       // B in MFMA fragment order
   double *d_P = nullptr;      size_t cap_P = 0;        // split-K partial slabs
   double *d_colpart = nullptr; size_t cap_colpart = 0; // column-sum partials + sums
+  void *d_i8 = nullptr;       size_t cap_i8 = 0;       // int8 engine: exponents, slices of B, int32 partials (bytes)
 };
 
 constexpr uint32_t kMagic = 0x4d584131u;  // "MXA1"
@@ -99,5 +100,9 @@ int launch_allele_freq(const uint8_t *d_plink, long snps, long indiv, double *d_
 // crossproduct
 int launch_plink_lut(uint8_t *d, size_t nbytes, hipStream_t s);
 int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double *d_ans, hipStream_t s);
+// opt-in engine (mxa_set_engine(1) / MXA_ENGINE=i8, mxa_gemm_i8.hip): whole product by exact int8 slicing of B.
+// Asynchronous on s; ev0/ev1 (optional) are recorded around the dominant kernel.
+int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, bool centered, const double *d_sumB,
+                   const double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out);
 
 }  // namespace mxa

@@ -16,6 +16,19 @@ def set_options(use_gpu=False, cores=0, not_center=False, variant=0, verbose=1):
     L.setOptions_compressed(int(use_gpu), int(cores), floatLoop, meanSubstract, ignore_missings, int(not_center), normalize, use_miraculix_freq, int(variant), int(verbose))
 
 
+_ENGINES = {"f64": 0, "i8": 1}
+
+
+def set_engine(name):
+    """Additive (no reference counterpart): 'f64' = fp64 matrix cores (default), 'i8' = exact int8 slicing of B on the int8
+    matrix cores (include/miraculix_amd.h, mxa_set_engine).  Returns the previous engine's name."""
+    L = _lib.check_library_handle()
+    if name not in _ENGINES:
+        raise ValueError("engine must be 'f64' or 'i8'")
+    prev = L.mxa_set_engine(_ENGINES[name])
+    return "i8" if prev == 1 else "f64"
+
+
 def check_dimensions(plink, snps, indiv):
     """miraculix.jl check_dimensions: rows of ceil(indiv/4) bytes, one row per SNP (row-major here)."""
     nbytes = int(np.prod(plink.shape))

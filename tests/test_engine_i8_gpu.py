@@ -1,0 +1,80 @@
+"""Opt-in engine 'i8' (mxa_gemm_i8.hip: every column of B split exactly into 8 signed 7-bit digits, int8 matrix cores, exact
+int32 accumulation, fp64 recombination) against the oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+from _util import Oracle, make_B, make_problem
+
+pytestmark = pytest.mark.gpu
+
+# B is represented to 2^-57 of each column's largest |entry|; all integer sums are exact.  Stated tolerance, relative to each
+# result column's largest |entry| (the same figure as the fp64 engine's, tests/test_dgemm_gpu.py):
+RTOL = 1e-11
+
+
+@pytest.fixture(scope="module")
+def dg():
+    import miraculix_amd as m
+    m.load_shared_library()
+    prev = m.dgemm_compressed.set_engine("i8")
+    yield m.dgemm_compressed
+    m.dgemm_compressed.set_engine(prev)
+
+
+@pytest.mark.parametrize("snps,indiv,n", [(1000, 500, 1), (1003, 501, 3), (2047, 771, 4), (777, 1301, 10), (4100, 515, 15), (3001, 2050, 32), (1500, 700, 40), (20000, 300, 33)])
+@pytest.mark.parametrize("centered", [0, 1])
+def test_i8_engine_vs_oracle(dg, snps, indiv, n, centered):
+    o = Oracle()
+    prob = make_problem(snps, indiv, n, seed=42 + snps, missing_frac=0.02)
+    dg.set_options(use_gpu=True, not_center=not centered, verbose=0)
+    obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], n)
+    try:
+        for trans in (0, 1):
+            k = indiv if trans else snps
+            m = snps if trans else indiv
+            B = make_B(k, n, seed=43)
+            B[n // 2, :k] *= 1e-9  # column scales differ by 16 decades: per-column exponents
+            B[0, :k] *= 3e7
+            ref = o.dgemm_dense(trans, prob, B, centered)[:, :m]
+            C = dg.dgemm_compressed_main(bool(trans), obj, np.asfortranarray(B[:, :k].T), snps, indiv)
+            err = (np.abs(C.T - ref).max(axis=1) / np.abs(ref).max(axis=1)).max()  # worst column-wise relative error
+            assert err <= RTOL, (trans, err)
+    finally:
+        dg.free_compressed(obj)
+
+
+def test_i8_engine_zero_column_ld_padding_and_engine_switch(dg):
+    o = Oracle()
+    prob = make_problem(1203, 610, 5, seed=7)
+    dg.set_options(use_gpu=True, not_center=True, verbose=0)
+    obj = dg.init_compressed(prob["plink"], prob["plink_t"], 1203, 610, prob["f"], 5)
+    try:
+        B = make_B(1203, 5, seed=1, ldb=1210)   # poisoned ld padding must not be read
+        B[2, :1203] = 0.0
+        ref = o.dgemm_dense(0, prob, B, 0)[:, :610]
+        Bcm = np.asfortranarray(B[:, :1203].T)
+        C8 = dg.dgemm_compressed_main(False, obj, Bcm, 1203, 610)
+        assert np.abs(C8[:, 2]).max() == 0.0
+        assert np.abs(C8.T - ref).max() <= RTOL * np.abs(ref).max()
+        assert dg.set_engine("f64") == "i8"
+        C64 = dg.dgemm_compressed_main(False, obj, Bcm, 1203, 610)
+        assert dg.set_engine("i8") == "f64"
+        assert np.abs(C64 - C8).max() <= RTOL * np.abs(ref).max()
+    finally:
+        dg.free_compressed(obj)
+
+
+def test_i8_engine_integer_B_is_exact(dg):
+    """With integer-valued B (|b| < 2^20) the digits represent B exactly and every sum is an integer below 2^53: the result must
+    equal the integer product bit for bit."""
+    rng = np.random.default_rng(3)
+    prob = make_problem(3000, 400, 6, seed=11)
+    dg.set_options(use_gpu=True, not_center=True, verbose=0)
+    obj = dg.init_compressed(prob["plink"], prob["plink_t"], 3000, 400, prob["f"], 6)
+    try:
+        B = rng.integers(-(2 ** 20), 2 ** 20, size=(6, 3000)).astype(np.float64)
+        C = dg.dgemm_compressed_main(False, obj, np.asfortranarray(B.T), 3000, 400)
+        ref = prob["Z"].astype(np.int64) @ B.T.astype(np.int64)
+        assert np.array_equal(C, ref.astype(np.float64))
+    finally:
+        dg.free_compressed(obj)
