@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--ncol", type=int, default=32)
     ap.add_argument("--centered", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-engine", action="store_true", help="skip the extra (untimed, informational) pass with the opt-in int8 engine")
     args = ap.parse_args()
 
     import torch
@@ -105,6 +106,7 @@ def main():
     import miraculix_amd as mx
     from miraculix_amd.distributed import HipLocalEngine, ShardedGenotypeOperator, shard_bounds
     L = mx.load_shared_library()
+    L.mxa_set_engine(0)   # the headline number is the fp64 engine, whatever MXA_ENGINE says
 
     snps, indiv, n = args.snps, args.indiv, args.ncol
     b, e = shard_bounds(snps, world, rank)
@@ -166,6 +168,34 @@ def main():
     if not (adj_err <= 1e-10):
         raise SystemExit(f"bench.py: adjoint identity violated (rel err {adj_err:.3e}): results are wrong, no number reported")
     flops_step = 2 * 2.0 * snps * indiv * n
+    # informational second pass, outside the timed region: the same steps with the opt-in int8 engine (exact 8 x 7-bit slicing of
+    # B, include/miraculix_amd.h mxa_set_engine).  Reported beside the headline, never as `value`.
+    alt = None
+    if not args.no_alt_engine:
+        C_N64, C_T64 = C_N.clone(), C_T.clone()
+        L.mxa_set_engine(1)
+        step(); sync()
+        L.mxa_profile_reset()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        dt8 = time.perf_counter() - t1
+        la8, ms8 = ctypes.c_int(0), ctypes.c_double(0.0)
+        L.mxa_profile_get(ctypes.byref(la8), ctypes.byref(ms8))
+        L.mxa_set_engine(0)
+        if dist.is_initialized():
+            t = torch.tensor([dt8], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt8 = float(t.item())
+        dN = float(((C_N - C_N64).abs().amax(dim=0) / C_N64.abs().amax(dim=0)).max())
+        dT = float(((C_T - C_T64).abs().amax(dim=0) / C_T64.abs().amax(dim=0)).max())
+        alt = {"engine": "i8: B split exactly into 8 signed 7-bit digits per column, v_mfma_i32_32x32x32_i8, exact int32 sums, fp64 recombination",
+               "value": round(flops_step * args.steps / dt8 * 1e-9, 1), "unit": "GFLOP/s (fp64-equivalent: same 2*snps*indiv*ncol count)",
+               "ms_per_step": round(dt8 / args.steps * 1e3, 3), "avg_kernel_ms": round(ms8.value / max(1, la8.value), 3),
+               "int8_ops_per_s_P": round(2.0 * snps_loc * indiv * n * 8 / (ms8.value / max(1, la8.value) * 1e-3) * 1e-15, 3),
+               "max_colwise_rel_diff_vs_f64_engine": max(dN, dT)}
+        del C_N64, C_T64
     value = flops_step * args.steps / dt * 1e-9
     ms_per_step = dt / args.steps * 1e3
     # dominant kernel: k_gemm; algorithmic flops per launch on this rank = 2 * snps_loc * indiv * n
@@ -199,6 +229,8 @@ def main():
                          "algorithmic_bytes_per_launch_GB": round((snps_loc * ((indiv + 3) // 4) + 8.0 * (snps_loc + indiv) * n) / 1e9, 3),
                          "kernel": "k_gemm<8,8> (v_mfma_f64_4x4x4_4b_f64)", "launches": launches.value, "avg_launch_ms": round(avg_ms, 3)},
         }
+        if alt is not None:
+            out["opt_in_engine"] = alt
         if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
