@@ -54,6 +54,21 @@ void free_compressed(void **compressed);
 /* replaces src/miraculix/5codesAPI.c:37-39.  Returns the allele frequencies stored with the object. */
 void get_compressed_freq(void *compressed, double *f);
 
+/* replaces src/miraculix/5codesAPI.c:135-157 -> sparseTGenoPlinkApi (5codesChar.cc:472-491) -> sparseTGenoPlink
+ * (plinkUint.cc:352-470); Fortran binding src/bindings/Fortran/mod5codesapi.f90:84-100, caller
+ * tests/sparse_plink/test_sparse_plink.f90:99.  Sparse (CSR) times packed genotypes, uncentred, missing -> 0.  Behaviour as
+ * observed from the reference's library (golden fixtures in tests/golden/sparse_golden.npz): the sparse COLUMN index selects a row
+ * of the packed matrix and the result runs over the 2-bit entries of that row --
+ *   transcompressed in {N,n}: C (nIdx x indiv, ld Ldc) = S (nIdx x snps)  * Z^T, packed matrix = plink;
+ *   transcompressed in {T,t,Y,y}: C (nIdx x snps, ld Ldc) = S (nIdx x indiv) * Z, packed matrix = plink_transposed.
+ * rowIdxB (nIdx + 1 entries) / colIdxB / B are ZERO-based CSR; C is zero-filled over Ldc x columns.  transsparse must be N
+ * (the reference aborts otherwise; so does this).  Only the packed matrix that is used needs to be non-NULL.  Pointers may be
+ * host or device.  Errors: message on stderr, C unwritten, mxa_last_error() != 0.
+ * The neighbouring reference entry dgemm_plink (5codesAPI.c:112-130) is not provided: in the reference it ends in an
+ * unconditional BUG abort for every input (plink256.cc:332), so there is no behaviour to be a drop-in for. */
+void sparse_times_plink(char *transsparse, char *transcompressed, char *plink, char *plink_transposed, int snps, int indiv,
+                        int nIdx, int *rowIdxB, int *colIdxB, double *B, double *C, int Ldc);
+
 /* replaces src/cuda/snp_multiply_cuda.cu:375-382 (prototype src/cuda/snp_multiply_cuda.h:113-114; Julia binding
  * src/bindings/Julia/crossproduct.jl:54-58, which passes the bool as Cint).
  * ans(indiv x indiv, column-major doubles, full symmetric) = X * X^T where X has `indiv` rows of ceil(snps/4) bytes
@@ -65,7 +80,8 @@ int snp_multiply_gpu(unsigned char *snp_matrix, int snps, int indiv, double *ans
 
 /* ------------------------------------------------------------------ Part 2: additive entry points */
 
-/* last error of the calling process: 0 = none.  Message valid until the next failing call. */
+/* status of the most recent fallible API call of the process: 0 = it succeeded (every such entry clears the status first);
+ * the message is valid until the next call. */
 int mxa_last_error(void);
 const char *mxa_last_error_string(void);
 

@@ -34,6 +34,8 @@ int env_print_level() {  // reference: cuda_utils.cu:44-52, env PRINT_LEVEL
   return e ? atoi(e) : 0;
 }
 
+void clear_error() { g_err = 0; g_errmsg[0] = 0; }
+
 void set_error(int code, const char *fmt, ...) {
   g_err = code;
   va_list ap;
@@ -335,6 +337,7 @@ void setOptions_compressed(int use_gpu, int cores, int floatLoop, int meanSubstr
 }
 
 void plink2compressed(char *plink, char *plink_transposed, int snps, int indiv, double *f, int max_n, void **compressed) {
+  clear_error();
   const size_t ps = ((size_t)indiv + 3) / 4, pi = ((size_t)snps + 3) / 4;
   (void)create_handle(reinterpret_cast<const uint8_t *>(plink), ps, reinterpret_cast<const uint8_t *>(plink_transposed), pi, snps, indiv, f,
                       max_n, compressed);
@@ -342,6 +345,7 @@ void plink2compressed(char *plink, char *plink_transposed, int snps, int indiv, 
 
 void mxa_plink2compressed_shard(char *plink, char *plink_transposed, int snps_total, int indiv, int snp_begin, int snp_end, double *f,
                                 int max_n, void **compressed) {
+  clear_error();
   if (compressed) *compressed = nullptr;
   if (snp_begin < 0 || snp_end > snps_total || snp_begin >= snp_end || (snp_begin & 3)) {
     set_error(1, "mxa_plink2compressed_shard: need 0 <= snp_begin < snp_end <= snps_total and snp_begin %% 4 == 0");
@@ -360,6 +364,7 @@ static int trans_flag(const char *trans) {  // 5codesAPI.c:73-77
 }
 
 void dgemm_compressed(char *trans, void *compressed, int n, double *B, int Ldb, double *C, int Ldc) {
+  clear_error();
   const int t = trans_flag(trans);
   Handle *h = as_handle(compressed, "dgemm_compressed");
   if (!h) return;
@@ -368,6 +373,7 @@ void dgemm_compressed(char *trans, void *compressed, int n, double *B, int Ldb, 
 
 int mxa_dgemm_compressed_device(char trans, void *compressed, int n, const double *dB, long ldb, double *dC, long ldc, void *hip_stream,
                                 int sync) {
+  clear_error();
   const int t = trans_flag(&trans);
   Handle *h = as_handle(compressed, "mxa_dgemm_compressed_device");
   if (!h) return 1;
@@ -384,6 +390,99 @@ void free_compressed(void **compressed) {
   Handle *h = as_handle(*compressed, "free_compressed");
   if (h) destroy_handle(h);
   *compressed = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------ sparse x packed
+namespace {
+struct DevBuf {   // frees on scope exit
+  void *p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) { MXA_HIP(hipMalloc(&p, bytes ? bytes : 1)); return 0; }
+};
+}  // namespace
+
+static int sparse_times_plink_impl(bool tcompressed, const uint8_t *plink, const uint8_t *plink_transposed, int snps, int indiv, int nIdx,
+                                   const int *rowIdxB, const int *colIdxB, const double *B, double *C, long ldc) {
+  // reference semantics, pinned by running its library (tests/golden/make_golden_sparse.py): the sparse column index selects a ROW of
+  // the packed matrix, the result runs over the 2-bit entries of that row:
+  //   'N': P = plink (snps rows of indiv entries):             C (nIdx x indiv) = S (nIdx x snps)  * Z^T
+  //   'T': P = plink_transposed (indiv rows of snps entries):  C (nIdx x snps)  = S (nIdx x indiv) * Z
+  // zero-based CSR, uncentred, missing -> 0, C zero-filled over Ldc x entries (haplogeno.cc:1696).
+  const uint8_t *P = tcompressed ? plink_transposed : plink;
+  const long rows = tcompressed ? indiv : snps, entries = tcompressed ? snps : indiv;
+  if (!P || !rowIdxB || !C || snps <= 0 || indiv <= 0 || nIdx < 0) { set_error(1, "sparse_times_plink: invalid argument"); return 1; }
+  if (nIdx == 0) return 0;
+  if (ldc < nIdx) { set_error(7, "sparse_times_plink: Ldc %ld < nIdx %d", ldc, nIdx); return 1; }
+  const int dev = select_device();
+  if (dev < 0) return 1;
+  const size_t pitch = ((size_t)entries + 3) / 4;
+  // CSR arrays on the host for validation
+  std::vector<int> h_row((size_t)nIdx + 1);
+  MXA_HIP(hipMemcpy(h_row.data(), rowIdxB, sizeof(int) * ((size_t)nIdx + 1), is_device_ptr(rowIdxB) ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
+  const long nnz = h_row[nIdx];
+  if (h_row[0] != 0 || nnz < 0) { set_error(1, "sparse_times_plink: rowIdxB must be zero-based CSR row pointers (rowIdxB[0] = %d)", h_row[0]); return 1; }
+  for (int j = 0; j < nIdx; j++) if (h_row[j + 1] < h_row[j]) { set_error(1, "sparse_times_plink: rowIdxB is not non-decreasing at row %d", j); return 1; }
+  if (nnz > 0 && (!colIdxB || !B)) { set_error(1, "sparse_times_plink: colIdxB / B are NULL"); return 1; }
+  std::vector<int> h_col((size_t)nnz);
+  if (nnz) MXA_HIP(hipMemcpy(h_col.data(), colIdxB, sizeof(int) * (size_t)nnz, is_device_ptr(colIdxB) ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
+  for (long t = 0; t < nnz; t++)
+    if (h_col[t] < 0 || h_col[t] >= rows) { set_error(1, "sparse_times_plink: colIdxB[%ld] = %d outside [0, %ld)", t, h_col[t], rows); return 1; }
+
+  // packed rows on the device: a device matrix is used in place; from the host only the rows S refers to are uploaded
+  DevBuf dP;
+  const uint8_t *d_packed = P;
+  if (!is_device_ptr(P)) {
+    std::vector<int> remap((size_t)rows, -1), used;
+    for (long t = 0; t < nnz; t++) if (remap[h_col[t]] < 0) { remap[h_col[t]] = 0; used.push_back(h_col[t]); }
+    std::sort(used.begin(), used.end());
+    for (size_t u = 0; u < used.size(); u++) remap[used[u]] = (int)u;
+    for (long t = 0; t < nnz; t++) h_col[t] = remap[h_col[t]];
+    if (dP.alloc(used.size() * pitch)) return 1;
+    const size_t rows_per_chunk = std::max<size_t>(1, ((size_t)256 << 20) / pitch);
+    std::vector<uint8_t> bounce(std::min(rows_per_chunk, std::max<size_t>(1, used.size())) * pitch);
+    for (size_t u0 = 0; u0 < used.size(); u0 += rows_per_chunk) {
+      const size_t cnt = std::min(rows_per_chunk, used.size() - u0);
+      for (size_t u = 0; u < cnt; u++) memcpy(bounce.data() + u * pitch, P + (size_t)used[u0 + u] * pitch, pitch);
+      MXA_HIP(hipMemcpy(static_cast<uint8_t *>(dP.p) + u0 * pitch, bounce.data(), cnt * pitch, hipMemcpyHostToDevice));
+    }
+    d_packed = static_cast<const uint8_t *>(dP.p);
+  }
+  DevBuf dRow, dCol, dVal;
+  if (dRow.alloc(sizeof(int) * ((size_t)nIdx + 1)) || dCol.alloc(sizeof(int) * (size_t)nnz) || dVal.alloc(sizeof(double) * (size_t)nnz)) return 1;
+  MXA_HIP(hipMemcpy(dRow.p, h_row.data(), sizeof(int) * ((size_t)nIdx + 1), hipMemcpyHostToDevice));
+  if (nnz) {
+    MXA_HIP(hipMemcpy(dCol.p, h_col.data(), sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+    MXA_HIP(hipMemcpy(dVal.p, B, sizeof(double) * (size_t)nnz, is_device_ptr(B) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  }
+  hipStream_t s = nullptr;   // legacy default stream: ordered with everything else of the process
+  if (is_device_ptr(C)) {
+    if (launch_sparse_times_plink(d_packed, pitch, entries, nIdx, (const int *)dRow.p, (const int *)dCol.p, (const double *)dVal.p, C, ldc, 0, entries, s)) return 1;
+    MXA_HIP(hipStreamSynchronize(s));
+    return 0;
+  }
+  // host C: slabs of columns through a device buffer of at most 1 GiB
+  long e_slab = std::max<long>(512, (((long)1 << 30) / (8 * ldc)) / 512 * 512);
+  e_slab = std::min(e_slab, (entries + 511) / 512 * 512);
+  DevBuf dC;
+  if (dC.alloc(sizeof(double) * (size_t)ldc * (size_t)e_slab)) return 1;
+  for (long e0 = 0; e0 < entries; e0 += e_slab) {
+    const long cnt = std::min(e_slab, entries - e0);
+    if (launch_sparse_times_plink(d_packed, pitch, entries, nIdx, (const int *)dRow.p, (const int *)dCol.p, (const double *)dVal.p, (double *)dC.p, ldc, e0, cnt, s)) return 1;
+    MXA_HIP(hipMemcpy(C + (size_t)e0 * ldc, dC.p, sizeof(double) * (size_t)ldc * (size_t)cnt, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+void sparse_times_plink(char *transsparse, char *transcompressed, char *plink, char *plink_transposed, int snps, int indiv, int nIdx, int *rowIdxB,
+                        int *colIdxB, double *B, double *C, int Ldc) {
+  clear_error();
+  const int tc = trans_flag(transcompressed);
+  if (trans_flag(transsparse)) {   // reference: BUG -> "Severe error occured in function 'sparseTGeno'" + exit (haplogeno.cc:1698)
+    fprintf(stderr, "miraculix_amd: sparse_times_plink: a transposed sparse matrix is not supported (nor by the reference)\n");
+    exit(EXIT_FAILURE);
+  }
+  (void)sparse_times_plink_impl(tc != 0, reinterpret_cast<const uint8_t *>(plink), reinterpret_cast<const uint8_t *>(plink_transposed), snps, indiv, nIdx,
+                                rowIdxB, colIdxB, B, C, Ldc);
 }
 
 void get_compressed_freq(void *compressed, double *f) {
@@ -429,6 +528,7 @@ static long count_lines(const char *path) {
 }
 
 int mxa_bed2compressed(const char *bed_path, int snps, int indiv, int max_n, void **compressed, double *f_out, int *snps_out, int *indiv_out) {
+  clear_error();
   if (compressed) *compressed = nullptr;
   if (!bed_path || !compressed) { set_error(1, "mxa_bed2compressed: bad arguments"); return 1; }
   std::string base(bed_path);
@@ -479,6 +579,7 @@ out:
 
 // ---- staging helpers
 int mxa_transpose_2bit(const unsigned char *in, long rows, long cols, unsigned char *out) {
+  clear_error();
   if (!in || !out || rows <= 0 || cols <= 0) { set_error(1, "mxa_transpose_2bit: bad arguments"); return 1; }
   if (select_device() < 0) return 1;
   const size_t nin = (size_t)rows * ((cols + 3) / 4), nout = (size_t)cols * ((rows + 3) / 4);
@@ -496,6 +597,7 @@ int mxa_transpose_2bit(const unsigned char *in, long rows, long cols, unsigned c
 }
 
 int mxa_allele_freq(const unsigned char *plink, long snps, long indiv, double *f) {
+  clear_error();
   if (!plink || !f || snps <= 0 || indiv <= 0) { set_error(1, "mxa_allele_freq: bad arguments"); return 1; }
   if (select_device() < 0) return 1;
   const size_t nin = (size_t)snps * ((indiv + 3) / 4);

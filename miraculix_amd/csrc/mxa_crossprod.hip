@@ -518,15 +518,18 @@ done:
 
 extern "C" int snp_multiply_gpu(unsigned char *snp_matrix, int snps, int indiv, double *ans, bool is_plink_format) {
   // positional meaning as in the reference: arg 2 = packed (inner) dimension, arg 3 = output dimension
+  mxa::clear_error();
   return mxa::crossprod_any(snp_matrix, snps, indiv, ans, is_plink_format);
 }
 
 extern "C" int mxa_grm(const unsigned char *plink_transposed, int snps, int indiv, double *G, int is_plink_format, int do_scale, const double *allele_freq) {
+  mxa::clear_error();
   if (do_scale && !allele_freq) { mxa::set_error(1, "mxa_grm: allele frequencies are required when do_scale is set"); return 1; }
   return mxa::crossprod_any(plink_transposed, snps, indiv, G, is_plink_format != 0, 1, do_scale, allele_freq);
 }
 
 extern "C" int mxa_ld(const unsigned char *plink, int snps, int indiv, double *R, int is_plink_format, const double *allele_freq) {
+  mxa::clear_error();
   if (!allele_freq) { mxa::set_error(1, "mxa_ld: allele frequencies are required"); return 1; }
   return mxa::crossprod_any(plink, indiv, snps, R, is_plink_format != 0, 2, 0, allele_freq);
 }

@@ -77,6 +77,7 @@ Geometry &last_geometry();
 
 // ---- error handling: print + remember (reference: cuda_utils.cu:83-90 prints "Internal error in function ...")
 void set_error(int code, const char *fmt, ...);
+void clear_error();   // every fallible API entry starts with it: mxa_last_error() describes the most recent such call
 bool check_hip(hipError_t e, const char *func, int line);
 #define MXA_HIP(x) do { if (!::mxa::check_hip((x), __func__, __LINE__)) return 1; } while (0)
 void debug_info(const char *fmt, ...);
@@ -100,6 +101,9 @@ int launch_allele_freq(const uint8_t *d_plink, long snps, long indiv, double *d_
 // crossproduct
 int launch_plink_lut(uint8_t *d, size_t nbytes, hipStream_t s);
 int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double *d_ans, hipStream_t s);
+// sparse_times_plink (mxa_sparse.hip): one slab of C columns [e_base, e_base + e_count) (e_base a multiple of 4), C slab pointer = column e_base
+int launch_sparse_times_plink(const uint8_t *dP, size_t pitch, long entries, int nIdx, const int *d_rowIdx, const int *d_colIdx, const double *d_val,
+                              double *dC_slab, long ldc, long e_base, long e_count, hipStream_t s);
 // opt-in engine (mxa_set_engine(1) / MXA_ENGINE=i8, mxa_gemm_i8.hip): whole product by exact int8 slicing of B.
 // Asynchronous on s; ev0/ev1 (optional) are recorded around the dominant kernel.
 int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, bool centered, const double *d_sumB,

@@ -130,6 +130,34 @@ def dgemm_compressed_main(transpose, obj_ref, B, snps, indiv, out=None):
     return C
 
 
+def sparse_times_plink(transcompressed, plink, plink_transposed, snps, indiv, row_idx, col_idx, values, ldc=None, out=None):
+    """Mirror of the Fortran binding c_sparse_times_plink (src/bindings/Fortran/mod5codesapi.f90:84-100, caller
+    tests/sparse_plink/test_sparse_plink.f90:99) with transsparse = 'N'.  (row_idx, col_idx, values): ZERO-based CSR of the sparse
+    matrix S with nIdx = len(row_idx) - 1 rows.
+      transcompressed False ('N'): C (nIdx x indiv) = S (nIdx x snps)  * Z^T, reads `plink`;
+      transcompressed True  ('T'): C (nIdx x snps)  = S (nIdx x indiv) * Z,   reads `plink_transposed`.
+    Returns the column-major C (Fortran-ordered numpy, or `out`: numpy F-ordered / torch column-major, host or device)."""
+    L = _lib.check_library_handle()
+    ia = np.ascontiguousarray(row_idx, dtype=np.int32)
+    ja = np.ascontiguousarray(col_idx, dtype=np.int32)
+    a = np.ascontiguousarray(values, dtype=np.float64)
+    nidx = len(ia) - 1
+    entries = snps if transcompressed else indiv
+    ldc = int(ldc or nidx)
+    if out is None:
+        C = np.zeros((ldc, entries), dtype=np.float64, order="F")
+    else:
+        C = out
+        Cc, ld = _colmajor(C)
+        if Cc is not C or ld != ldc:
+            raise ValueError("out must be column-major with leading dimension ldc")
+    L.sparse_times_plink(b"N", b"T" if transcompressed else b"N", _lib.ptr(plink), _lib.ptr(plink_transposed), int(snps), int(indiv), int(nidx),
+                         _lib.ptr(ia), _lib.ptr(ja), _lib.ptr(a), _lib.ptr(C), ldc)
+    if L.mxa_last_error():
+        raise RuntimeError("sparse_times_plink failed: " + _lib.last_error()[1])
+    return C[:nidx, :] if out is None else C
+
+
 def free_compressed(obj_ref):
     """dgemm_compressed.jl:149-156"""
     check_storage_object(obj_ref)

@@ -363,3 +363,27 @@ int oracle_num_threads(void) {
   return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* sparse_times_plink restated (reference: src/miraculix/5codesAPI.c:135-157 -> sparseTGenoPlinkApi 5codesChar.cc:472-491 ->
+ * sparseTGeno haplogeno.cc:1683-1711 -> sparseTGenoPlink plinkUint.cc:352-470).  The sparse column index selects a ROW of the
+ * packed matrix P (rows x ceil(entries/4) bytes), the result runs over that row's 2-bit entries:
+ *   C[j + e*ldc] = sum_{t in row j of S} val[t] * z(P[col[t]], e),   z = 00->0, 01->0, 10->1, 11->2,
+ * zero-based CSR, C zero-filled over ldc x entries first (haplogeno.cc:1696).  The reference adds the stored entries in groups of
+ * up to 8 (its MULTI switch); here they are accumulated in long double, so agreement is to rounding, not bitwise.
+ * Pinned against the reference library's own output in tests/golden/sparse_golden.npz (tests/golden/make_golden_sparse.py). */
+void oracle_sparse_times_plink(const uint8_t *P, long rows, long entries, int nIdx, const int *rowIdx, const int *colIdx,
+                               const double *val, double *C, long ldc) {
+  long bps = (entries + 3) / 4;
+  (void)rows;
+  for (long i = 0; i < ldc * entries; i++) C[i] = 0.0;
+#pragma omp parallel for schedule(static)
+  for (long e = 0; e < entries; e++) {
+    for (int j = 0; j < nIdx; j++) {
+      long double acc = 0.0L;
+      for (int t = rowIdx[j]; t < rowIdx[j + 1]; t++)
+        acc += (long double)val[t] * (long double)plink_value(get_code(P + (long)colIdx[t] * bps, e));
+      C[j + e * ldc] = (double)acc;
+    }
+  }
+}

@@ -87,6 +87,7 @@ class Oracle:
         L.oracle_transpose_2bit.argtypes = [c_u8p, ctypes.c_long, ctypes.c_long, c_u8p]
         L.oracle_allele_freq.argtypes = [c_u8p, ctypes.c_long, ctypes.c_long, c_f64p]
         L.oracle_num_threads.restype = ctypes.c_int
+        L.oracle_sparse_times_plink.argtypes = [c_u8p, ctypes.c_long, ctypes.c_long, ctypes.c_int, c_i32p, c_i32p, c_f64p, c_f64p, ctypes.c_long]
 
     @staticmethod
     def _u8(a):
@@ -140,10 +141,33 @@ class Oracle:
         self.L.oracle_transpose_2bit(self._u8(X), rows, cols, self._u8(out))
         return out
 
+    def sparse_times_plink(self, P, rows, entries, ia, ja, a, ldc=None):
+        """P: rows x ceil(entries/4) PLINK bytes; (ia, ja, a): zero-based CSR with len(ia)-1 sparse rows.  Returns the column-major
+        C as numpy (entries, ldc)."""
+        nidx = len(ia) - 1
+        ldc = ldc or nidx
+        C = np.full((entries, ldc), -777.0)
+        ia = np.ascontiguousarray(ia, np.int32); ja = np.ascontiguousarray(ja, np.int32); a = np.ascontiguousarray(a, np.float64)
+        self.L.oracle_sparse_times_plink(self._u8(P), rows, entries, nidx, ia.ctypes.data_as(c_i32p), ja.ctypes.data_as(c_i32p), self._f64(a), self._f64(C), ldc)
+        return C
+
     def allele_freq(self, plink, snps, indiv):
         f = np.zeros(snps)
         self.L.oracle_allele_freq(self._u8(plink), snps, indiv, self._f64(f))
         return f
+
+
+def random_csr(nidx, ncols, max_nnz, seed, empty_rows=True):
+    """Zero-based CSR (ia, ja, a) with 0..max_nnz sorted distinct columns per row and N(0,1) values."""
+    rng = np.random.default_rng(seed)
+    ia, ja, a = [0], [], []
+    for j in range(nidx):
+        k = int(rng.integers(0 if empty_rows else 1, min(max_nnz, ncols) + 1))
+        cols = np.sort(rng.choice(ncols, size=k, replace=False))
+        ja += cols.tolist()
+        a += rng.standard_normal(k).tolist()
+        ia.append(len(ja))
+    return np.array(ia, np.int32), np.array(ja, np.int32), np.array(a, np.float64)
 
 
 def have_reference():
