@@ -102,6 +102,12 @@ void mxa_plink2compressed_shard(char *plink, char *plink_transposed, int snps_to
 int mxa_dgemm_compressed_device(char trans, void *compressed, int n, const double *dB, long ldb, double *dC,
                                 long ldc, void *hip_stream, int sync);
 
+/* one step of the GRM-based solvers (reference loop: examples/iterative_solver/grm_solve_cg.jl:74-84, which calls
+ * dgemm_compressed 'T' then 'N' and notes the cost of moving the operands each time at dgemm_compressed_cuda.cu:251-252):
+ * out (indiv x n, ld ldo) = Zc * (Zc^T * V), V indiv x n (ld ldv); the snps x n intermediate stays in HBM.  Centring as set by
+ * setOptions_compressed.  V / out host or device.  On a SNP shard the result is that shard's partial sum.  Returns 0 / 1. */
+int mxa_gram_matvec(void *compressed, int n, const double *V, long ldv, double *out, long ldo);
+
 /* on-device .bed staging helpers (reference counterparts live in the bindings:
  * transpose_genotype_matrix src/bindings/Julia/compressed_operations.jl:45-66, popcount frequencies
  * src/bindings/Julia/read_plink.jl:199-203).  Pointers may be host or device. */

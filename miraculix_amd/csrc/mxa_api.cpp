@@ -152,7 +152,7 @@ static void destroy_handle(Handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void *ptrs[] = {h->snp_major.d, h->ind_major.d, h->d_f, h->ws.d_Bstage, h->ws.d_Cstage, h->ws.d_Bp, h->ws.d_P, h->ws.d_colpart, h->ws.d_i8};
+  void *ptrs[] = {h->snp_major.d, h->ind_major.d, h->d_f, h->ws.d_Bstage, h->ws.d_Cstage, h->ws.d_Bp, h->ws.d_P, h->ws.d_colpart, h->ws.d_i8, h->ws.d_tmp};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -308,6 +308,36 @@ static int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, dou
   return 0;
 }
 
+// out (indiv x n) = Zc * (Zc^T * V): the 'T' then the 'N' product with the snps x n intermediate kept in HBM
+static int gram_any(Handle *h, int n, const double *V, long ldv, double *out, long ldo) {
+  MXA_HIP(hipSetDevice(h->device));
+  const long snps = h->snps, indiv = h->indiv;
+  if (n <= 0) return 0;
+  if (!V || !out) { set_error(1, "mxa_gram_matvec: V and out must not be NULL"); return 1; }
+  if (ldv < indiv || ldo < indiv) { set_error(7, "mxa_gram_matvec: leading dimension too small (ldv %ld, ldo %ld < %ld)", ldv, ldo, indiv); return 1; }
+  hipStream_t s = h->stream;
+  Workspace &w = h->ws;
+  const bool v_dev = is_device_ptr(V), o_dev = is_device_ptr(out);
+  const double *dV = V; long dldv = ldv;
+  double *dO = out; long dldo = ldo;
+  if (!v_dev) {
+    if (grow(&w.d_Bstage, &w.cap_Bstage, (size_t)std::max(snps, indiv) * n)) return 1;
+    if (ldv == indiv) MXA_HIP(hipMemcpyAsync(w.d_Bstage, V, sizeof(double) * (size_t)indiv * n, hipMemcpyHostToDevice, s));
+    else MXA_HIP(hipMemcpy2DAsync(w.d_Bstage, sizeof(double) * indiv, V, sizeof(double) * ldv, sizeof(double) * indiv, n, hipMemcpyHostToDevice, s));
+    dV = w.d_Bstage; dldv = indiv;
+  }
+  if (!o_dev) {
+    if (grow(&w.d_Cstage, &w.cap_Cstage, (size_t)ldo * n)) return 1;
+    dO = w.d_Cstage; dldo = ldo;
+  }
+  if (grow(&w.d_tmp, &w.cap_tmp, (size_t)snps * n)) return 1;
+  if (gemm_device(h, true, n, dV, dldv, w.d_tmp, snps, s, false)) return 1;
+  if (gemm_device(h, false, n, w.d_tmp, snps, dO, dldo, s, false)) return 1;
+  if (!o_dev) MXA_HIP(hipMemcpyAsync(out, dO, sizeof(double) * (size_t)ldo * n, hipMemcpyDeviceToHost, s));
+  MXA_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
 }  // namespace mxa
 
 using namespace mxa;
@@ -383,6 +413,13 @@ int mxa_dgemm_compressed_device(char trans, void *compressed, int n, const doubl
   if (gemm_device(h, t != 0, n, dB, ldb, dC, ldc, s, sync != 0)) return 1;
   if (sync) MXA_HIP(hipStreamSynchronize(s));
   return 0;
+}
+
+int mxa_gram_matvec(void *compressed, int n, const double *V, long ldv, double *out, long ldo) {
+  clear_error();
+  Handle *h = as_handle(compressed, "mxa_gram_matvec");
+  if (!h) return 1;
+  return gram_any(h, n, V, ldv, out, ldo);
 }
 
 void free_compressed(void **compressed) {

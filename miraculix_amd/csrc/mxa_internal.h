@@ -46,6 +46,7 @@ struct Workspace {
   double *d_Bp = nullptr;     size_t cap_Bp = 0;       // B in MFMA fragment order
   double *d_P = nullptr;      size_t cap_P = 0;        // split-K partial slabs
   double *d_colpart = nullptr; size_t cap_colpart = 0; // column-sum partials + sums
+  double *d_tmp = nullptr;    size_t cap_tmp = 0;      // snps x n intermediate of mxa_gram_matvec
   void *d_i8 = nullptr;       size_t cap_i8 = 0;       // int8 engine: exponents, slices of B, int32 partials (bytes)
 };
 

@@ -158,6 +158,30 @@ def sparse_times_plink(transcompressed, plink, plink_transposed, snps, indiv, ro
     return C[:nidx, :] if out is None else C
 
 
+def gram_matvec(obj_ref, V, snps, indiv, out=None):
+    """Additive: out (indiv x n) = Zc (Zc^T V) in one call (the 'T' + 'N' pair of a CG / GBLUP step,
+    examples/iterative_solver/grm_solve_cg.jl:74-84) with the snps x n intermediate kept on the device."""
+    check_storage_object(obj_ref)
+    if V.shape[0] != indiv:
+        raise ValueError(f"Matrix V must have {indiv} rows")
+    n = V.shape[1]
+    Vc, ldv = _colmajor(V)
+    if out is not None:
+        C = out
+    elif _lib.is_torch_tensor(V):
+        import torch
+        C = torch.zeros((n, indiv), dtype=torch.float64, device=V.device).t()
+    else:
+        C = np.zeros((indiv, n), dtype=np.float64, order="F")
+    Cc, ldo = _colmajor(C)
+    if Cc is not C:
+        raise ValueError("out must be column-major")
+    L = _lib.check_library_handle()
+    if L.mxa_gram_matvec(obj_ref, int(n), _lib.ptr(Vc), int(ldv), _lib.ptr(C), int(ldo)):
+        raise RuntimeError("mxa_gram_matvec failed: " + _lib.last_error()[1])
+    return C
+
+
 def free_compressed(obj_ref):
     """dgemm_compressed.jl:149-156"""
     check_storage_object(obj_ref)

@@ -34,6 +34,10 @@ class HipLocalEngine:
     def multiply(self, transpose, B, out=None):
         return self.dg.dgemm_compressed_main(transpose, self.obj, B, self.snps, self.indiv, out=out)
 
+    def gram(self, V, out=None):
+        """Zc_local (Zc_local^T V) in one library call (mxa_gram_matvec)"""
+        return self.dg.gram_matvec(self.obj, V, self.snps, self.indiv, out=out)
+
     def close(self):
         if self.obj is not None and self.obj.value:
             self.dg.free_compressed(self.obj)
@@ -61,6 +65,20 @@ class ShardedGenotypeOperator:
                 raise ValueError("matmul_N: result buffer must be column-major or row-major contiguous")
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return (C, work) if async_op else C
+
+    def gram(self, V, out=None):
+        """G V = Zc Zc^T V for V (indiv x n, identical on all ranks): every rank applies its SNP block (one fused 'T' + 'N' call when
+        the local engine has one), then the same fp64 sum all-reduce as matmul_N.  Returns the full result on every rank."""
+        if hasattr(self.engine, "gram"):
+            C = self.engine.gram(V, out=out)
+        else:
+            C = self.engine.multiply(False, self.engine.multiply(True, V), out=out)
+        if self.world > 1 or (dist.is_initialized() and self.force_collective):
+            flat = C.t() if (C.dim() == 2 and not C.is_contiguous() and C.t().is_contiguous()) else C
+            if not flat.is_contiguous():
+                raise ValueError("gram: result buffer must be column-major or row-major contiguous")
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        return C
 
     def matmul_T(self, B, out=None):
         """B: indiv x n (identical on all ranks).  Returns this rank's row block of C (snps_local x n)."""

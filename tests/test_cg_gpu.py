@@ -32,3 +32,34 @@ def test_cg_matches_dense_solve():
     x_ref = np.linalg.solve(A, b)
     assert res < 1e-9
     assert np.abs(x.cpu().numpy() - x_ref).max() <= 1e-9 * np.abs(x_ref).max()
+
+
+def test_gram_matvec_matches_two_products_and_oracle():
+    """mxa_gram_matvec = 'T' then 'N' with the intermediate on the device: bitwise equal to the two separate calls (same kernels,
+    same order), and equal to the dense oracle within the stated tolerance; host and device operands, ld padding."""
+    import torch
+    import miraculix_amd as mx
+    from _util import Oracle, make_B, make_problem
+    mx.load_shared_library()
+    dg = mx.dgemm_compressed
+    o = Oracle()
+    for snps, indiv, n, centered in [(3001, 517, 1, 1), (2050, 1301, 2, 1), (1500, 700, 5, 0), (4100, 515, 33, 1)]:
+        prob = make_problem(snps, indiv, n, seed=snps)
+        dg.set_options(use_gpu=True, not_center=not centered, verbose=0)
+        obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], n)
+        try:
+            V = make_B(indiv, n, seed=9)                      # n x indiv
+            Vcm = np.asfortranarray(V.T)
+            G = dg.gram_matvec(obj, Vcm, snps, indiv)
+            T = dg.dgemm_compressed_main(True, obj, Vcm, snps, indiv)
+            N = dg.dgemm_compressed_main(False, obj, T, snps, indiv)
+            assert np.array_equal(G, N)
+            t_ref = o.dgemm_dense(1, prob, V, centered)[:, :snps]
+            ref = o.dgemm_dense(0, prob, np.ascontiguousarray(t_ref), centered)[:, :indiv].T
+            assert np.abs(G - ref).max() <= 1e-11 * np.abs(ref).max()
+            dV = torch.from_numpy(V).cuda().t()                 # column-major on the device
+            dOut = torch.full((n, indiv + 7), -1.0, dtype=torch.float64, device="cuda").t()[:indiv]   # ld = indiv + 7
+            Gd = dg.gram_matvec(obj, dV, snps, indiv, out=dOut)
+            assert np.array_equal(Gd.cpu().numpy(), G)
+        finally:
+            dg.free_compressed(obj)

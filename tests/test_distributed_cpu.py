@@ -60,7 +60,11 @@ def _worker(rank, world, port, snps, indiv, n, centered, ret):
     refT = o.dgemm_dense(1, prob, BT, centered)
     errN = np.abs(CN.t().numpy() - refN).max() / np.abs(refN).max()
     errT = np.abs(CT.t().numpy() - refT[:, b:e]).max() / np.abs(refT).max()
-    ret[rank] = (float(errN), float(errT))
+    # G V = Zc Zc^T V: every rank applies its SNP block, one all-reduce (the CG step of examples/grm_solve_cg.py)
+    GV = op.gram(torch.from_numpy(BT).t())
+    refG = o.dgemm_dense(0, prob, np.ascontiguousarray(refT[:, :snps]), centered)
+    errG = np.abs(GV.t().numpy() - refG).max() / np.abs(refG).max()
+    ret[rank] = (float(errN), float(errT), float(errG))
     dist.destroy_process_group()
 
 
@@ -72,5 +76,5 @@ def test_world2_gloo_sharded_operator(centered):
     mp.spawn(_worker, args=(2, port, 1003, 301, 5, centered, ret), nprocs=2, join=True)
     assert len(ret) == 2
     for r in range(2):
-        errN, errT = ret[r]
-        assert errN <= 1e-12 and errT <= 1e-12
+        errN, errT, errG = ret[r]
+        assert errN <= 1e-12 and errT <= 1e-12 and errG <= 1e-12
