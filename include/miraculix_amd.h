@@ -123,6 +123,16 @@ int mxa_allele_freq(const unsigned char *plink, long snps, long indiv, double *f
 int mxa_bed2compressed(const char *bed_path, int snps, int indiv, int max_n, void **compressed, double *f_out, int *snps_out,
                        int *indiv_out);
 
+/* Output-tile sharding of the crossproduct for one-process-per-GPU use (packed matrix replicated, independent
+ * units, no collective): columns [col_begin, col_end) of the symmetric result of snp_multiply_gpu, i.e. the contiguous slab
+ * ans + col_begin*indiv of the full column-major matrix, into `panel` (indiv rows, col_end - col_begin columns, leading
+ * dimension ld).  col_begin must be a multiple of 256, col_end a multiple of 256 or == indiv.  upper_only != 0 computes only
+ * rows [0, col_end) of the panel, i.e. everything above its diagonal block and the block itself (a host panel gets zeros in the
+ * rows below, a device panel is left untouched there) -- half the total work for callers that exchange the transposed blocks
+ * (miraculix_amd/distributed.py: crossprod_sharded).  Same argument meaning otherwise as snp_multiply_gpu.  Returns 0 / 1. */
+int mxa_snp_multiply_panel(const unsigned char *snp_matrix, int snps, int indiv, int col_begin, int col_end, int upper_only,
+                           double *panel, long ld, int is_plink_format);
+
 /* GRM and LD with the post-processing done on the device before the result leaves HBM (reference: host BLAS in
  * src/bindings/Julia/crossproduct.jl:83-110 grm(), :128-152 ld(); maths docs/grm.md:5-12).
  * mxa_grm: G(indiv x indiv) = P Z Z^T P^T [/ (2 sum f(1-f))], plink_transposed = indiv rows of ceil(snps/4) bytes.

@@ -31,6 +31,29 @@ def snp_crossprod(plink, snps, indiv, is_snpmajor, is_plink_format=False, out=No
     return M
 
 
+def snp_crossprod_panel(plink, inner, n_out, col_begin, col_end, upper_only=False, is_plink_format=False, out=None):
+    """Additive (C entry mxa_snp_multiply_panel): columns [col_begin, col_end) of the symmetric n_out x n_out crossproduct of the
+    2-bit matrix `plink` (n_out rows of ceil(inner/4) bytes).  Returns the panel as a tensor/array P of shape
+    (col_end - col_begin, n_out) with P[c, r] = M[r, col_begin + c] -- the contiguous slab of the column-major result.
+    upper_only: only rows [0, col_end) are computed (zeros below)."""
+    if int(np.prod(plink.shape)) != n_out * ((inner + 3) // 4):
+        raise ValueError(f"Matrix has wrong dimensions: {tuple(plink.shape)}")
+    w = col_end - col_begin
+    L = _lib.check_library_handle()
+    if out is not None:
+        P = out
+    elif _lib.is_torch_tensor(plink):
+        import torch
+        P = torch.zeros((w, n_out), dtype=torch.float64, device=plink.device)
+    else:
+        P = np.zeros((w, n_out), dtype=np.float64)
+    rc = L.mxa_snp_multiply_panel(_lib.ptr(plink), int(inner), int(n_out), int(col_begin), int(col_end), int(bool(upper_only)), _lib.ptr(P), int(n_out),
+                                  int(bool(is_plink_format)))
+    if rc != 0:
+        raise RuntimeError("mxa_snp_multiply_panel failed: " + _lib.last_error()[1])
+    return P
+
+
 def _result_like(plink, n):
     if _lib.is_torch_tensor(plink):
         import torch

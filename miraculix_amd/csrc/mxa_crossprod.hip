@@ -168,13 +168,13 @@ __device__ __forceinline__ void xdma16_s(const void *sbase, uint32_t voff, uint3
 
 template <bool DIAG>
 __global__ void __launch_bounds__(256, 1)
-k_crossprod2(const uint8_t *__restrict__ X, size_t pitch, int stages, const int2 *__restrict__ tiles, long n, double *__restrict__ ans,
-             unsigned long long *__restrict__ diag) {
+k_crossprod2(const uint8_t *__restrict__ X, size_t pitch, int stages, const int4 *__restrict__ tiles, long n, double *__restrict__ ans,
+             long ld, long c0, unsigned long long *__restrict__ diag) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wi = wave >> 1, wj = wave & 1;      // wave tile: rows [128*wi, +128) of the I block x rows [128*wj, +128) of the J block
-  const int2 t = tiles[blockIdx.x];
+  const int4 t = tiles[blockIdx.x];             // (I tile, J tile, images to store: 1 = M[gj, gi] "direct", 2 = M[gi, gj] "mirror")
   const long i0 = (long)t.x * kXT, j0 = (long)t.y * kXT;
   const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
   const uint32_t v_lane = (uint32_t)(lane >> 1) * (uint32_t)pitch + (lane & 1) * 16;
@@ -275,8 +275,10 @@ k_crossprod2(const uint8_t *__restrict__ X, size_t pitch, int stages, const int2
   }
 
   // epilogue.  32x32 C/D map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); element (gi, gj) = M[gi][gj].
-  // Direct image: ans[gj + gi*n], lanes run along gj (256-byte segments).  Mirror image ans[gi + gj*n]: the tile is transposed
-  // through a per-wave LDS scratch (row stride 33 doubles: conflict-free both ways) so its lanes run along gi as well.
+  // The output holds columns [c0, ..) of M with leading dimension ld (whole matrix: c0 = 0, ld = n).
+  // Direct image: M[gj, gi] at ans[gj + (gi-c0)*ld], lanes run along gj (256-byte segments).  Mirror image M[gi, gj] at
+  // ans[gi + (gj-c0)*ld]: the tile is transposed through a per-wave LDS scratch (row stride 33 doubles: conflict-free both ways)
+  // so its lanes run along gi as well.
   double *scratch = reinterpret_cast<double *>(smem) + wave * (32 * 33);   // the DMA ring is dead after the last barrier
   const int col = lane & 31, hh = lane >> 5, rq = 4 * hh;
 #pragma unroll
@@ -289,16 +291,16 @@ k_crossprod2(const uint8_t *__restrict__ X, size_t pitch, int stages, const int2
       for (int r = 0; r < 16; r++) {
         const int row = (r & 3) + 8 * (r >> 2) + rq;
         const double v = (double)acc[a][b][r];
-        if (gi_base + row < n && gj < n) ans[(size_t)gj + (size_t)(gi_base + row) * n] = v;
+        if ((t.z & 1) && gi_base + row < n && gj < n) ans[(size_t)gj + (size_t)(gi_base + row - c0) * ld] = v;
         scratch[row * 33 + col] = v;
       }
-      if (t.x != t.y) {
+      if (t.z & 2) {
 #pragma unroll
         for (int it = 0; it < 16; it++) {
           const int cc = 2 * it + hh;                       // column of the tile = gj offset; lanes (lane&31) run along gi
           const double v = scratch[col * 33 + cc];
           const long gi = gi_base + col, gjj = gj_base + cc;
-          if (gi < n && gjj < n) ans[(size_t)gi + (size_t)gjj * n] = v;
+          if (gi < n && gjj < n) ans[(size_t)gi + (size_t)(gjj - c0) * ld] = v;
         }
       }
     }
@@ -313,14 +315,33 @@ int launch_plink_lut(uint8_t *d, size_t nbytes, hipStream_t s) {
 }
 
 // X: device, padded: rows_pad (multiple of 256) x pitch (multiple of 32 B), zero padded
-int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double *d_ans, hipStream_t s) {
+// Columns [c_begin, c_end) of M = X X^T into d_ans (leading dimension ld; c_begin a multiple of the 256-row tile, c_end a multiple
+// or the matrix end).  upper_only: only rows [0, c_end) are written -- everything above the panel's diagonal block and the block
+// itself; rows >= c_end are left untouched.  The whole matrix is c_begin = 0, c_end = rows, ld = rows.
+int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double *d_ans, hipStream_t s, long c_begin, long c_end, bool upper_only,
+                     long ld) {
   const int nb = (int)((rows + kXT - 1) / kXT);
   const int stages = (int)((k + kXStageK - 1) / kXStageK);
   if ((size_t)stages * kXStageBytes > pitch) { set_error(4, "internal: crossproduct pitch too small"); return 1; }
+  if (c_begin % kXT != 0 || c_begin < 0 || c_end > rows || c_begin >= c_end || ld < (upper_only ? c_end : rows)) { set_error(4, "crossproduct: bad column panel"); return 1; }
+  const int t0 = (int)(c_begin / kXT), t1 = (int)((c_end + kXT - 1) / kXT);
+  const bool whole = c_begin == 0 && c_end == rows;
+  if (!whole && c_end % kXT != 0 && c_end != rows) { set_error(4, "crossproduct: panel end must be a multiple of %d or the matrix end", kXT); return 1; }
+  // upper-triangular tiles (i <= j) that touch the panel: the direct image M[J rows, I cols] lands in the panel when i is a panel
+  // column tile, the mirror image M[I rows, J cols] when j is
+  std::vector<int4> tiles4;
   std::vector<int2> tiles;
-  tiles.reserve((size_t)nb * (nb + 1) / 2);
   for (int i = 0; i < nb; i++)
-    for (int j = i; j < nb; j++) tiles.push_back(make_int2(i, j));
+    for (int j = i; j < nb; j++) {
+      int flags = 0;
+      if (i >= t0 && i < t1 && (!upper_only || j < t1)) flags |= 1;      // rows of tile j >= i: on/below the diagonal
+      if (j >= t0 && j < t1 && i != j) flags |= 2;                        // rows of tile i < j: above the diagonal
+      if (flags) { tiles4.push_back(make_int4(i, j, flags, 0)); tiles.push_back(make_int2(i, j)); }
+    }
+  if (tiles4.empty()) return 0;
+  int4 *d_tiles4 = nullptr;
+  MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_tiles4), tiles4.size() * sizeof(int4)));
+  MXA_HIP(hipMemcpyAsync(d_tiles4, tiles4.data(), tiles4.size() * sizeof(int4), hipMemcpyHostToDevice, s));
   int2 *d_tiles = nullptr;
   MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_tiles), tiles.size() * sizeof(int2)));
   MXA_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice, s));
@@ -332,7 +353,9 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
   hipEvent_t e0, e1;
   MXA_HIP(hipEventCreate(&e0)); MXA_HIP(hipEventCreate(&e1));
   MXA_HIP(hipEventRecord(e0, s));
-  static const int xver = [] { const char *e = getenv("MXA_XPROD_VER"); return e ? atoi(e) : 2; }();
+  static const int xver_env = [] { const char *e = getenv("MXA_XPROD_VER"); return e ? atoi(e) : 2; }();
+  const int xver = whole ? xver_env : 2;   // the first-generation kernel only knows the whole matrix
+  const long c0 = c_begin;
   if (xver == 2) {
     static bool attr2 = false;
     if (!attr2) {
@@ -343,7 +366,7 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
     if (getenv("MXA_DIAG")) {   // diagnostic instantiation: in-kernel clock and cycles per stage
       unsigned long long *d_diag = nullptr;
       MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_diag), 16 * tiles.size()));
-      hipLaunchKernelGGL(k_crossprod2<true>, dim3((unsigned)tiles.size()), dim3(256), kX2Lds, s, d_X, pitch, stages, d_tiles, rows, d_ans, d_diag);
+      hipLaunchKernelGGL(k_crossprod2<true>, dim3((unsigned)tiles.size()), dim3(256), kX2Lds, s, d_X, pitch, stages, d_tiles4, rows, d_ans, ld, c0, d_diag);
       MXA_HIP(hipStreamSynchronize(s));
       std::vector<unsigned long long> hd(2 * tiles.size());
       MXA_HIP(hipMemcpy(hd.data(), d_diag, 16 * tiles.size(), hipMemcpyDeviceToHost));
@@ -354,7 +377,7 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
                                tiles.size(), ghz[ghz.size() / 2], ghz.front(), ghz.back(), cyc[cyc.size() / 2]);
       (void)hipFree(d_diag);
     } else
-    hipLaunchKernelGGL(k_crossprod2<false>, dim3((unsigned)tiles.size()), dim3(256), kX2Lds, s, d_X, pitch, stages, d_tiles, rows, d_ans, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(k_crossprod2<false>, dim3((unsigned)tiles.size()), dim3(256), kX2Lds, s, d_X, pitch, stages, d_tiles4, rows, d_ans, ld, c0, (unsigned long long *)nullptr);
   } else
   hipLaunchKernelGGL(k_crossprod, dim3((unsigned)tiles.size()), dim3(512), kXLds, s, d_X, pitch, stages, d_tiles, rows, d_ans);
   MXA_HIP(hipGetLastError());
@@ -365,6 +388,7 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
   profile().launches += 1; profile().total_ms += ms;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(d_tiles);
+  (void)hipFree(d_tiles4);
   return 0;
 }
 
@@ -451,7 +475,9 @@ static bool xp_is_device_ptr(const void *p) {
 }
 
 static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, double *ans, bool is_plink, int post = 0, int do_scale = 0,
-                         const double *freq = nullptr) {
+                         const double *freq = nullptr, long c_begin = 0, long c_end = -1, bool upper_only = false, long ld = -1) {
+  if (c_end < 0) c_end = rows;
+  if (ld < 0) ld = rows;
   if (!snp_matrix || !ans || k <= 0 || rows <= 0) { set_error(1, "snp_multiply_gpu: bad arguments"); return 1; }
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); set_error(10, "snp_multiply_gpu: no HIP device available; this engine is GPU-only"); return 1; }
@@ -462,7 +488,11 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
   const long rows_pad = (rows + kXT - 1) / kXT * kXT;
   const size_t pitch = (size_t)((k + kXStageK - 1) / kXStageK) * kXStageBytes;
   const bool in_dev = xp_is_device_ptr(snp_matrix), out_dev = xp_is_device_ptr(ans);
-  const size_t xbytes = (size_t)rows_pad * pitch, abytes = (size_t)rows * rows * sizeof(double);
+  if (c_begin < 0 || c_begin >= c_end || c_end > rows || c_begin % kXT != 0 || (c_end % kXT != 0 && c_end != rows) || ld < (upper_only ? c_end : rows)) {
+    set_error(1, "crossproduct panel: need 0 <= col_begin < col_end <= n, col_begin %% %d == 0, col_end %% %d == 0 or col_end == n, ld >= rows written", kXT, kXT);
+    return 1;
+  }
+  const size_t xbytes = (size_t)rows_pad * pitch, abytes = (size_t)ld * (size_t)(c_end - c_begin) * sizeof(double);
   size_t free_b = 0, total_b = 0;
   MXA_HIP(hipMemGetInfo(&free_b, &total_b));
   const size_t need = xbytes + (out_dev ? 0 : abytes) + (in_dev ? 0 : std::min<size_t>((size_t)rows * row_bytes, (size_t)256 << 20));
@@ -493,7 +523,8 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
     }
   }
   if (!out_dev && fail(hipMalloc(reinterpret_cast<void **>(&d_ans), abytes), __LINE__)) goto done;
-  rc = crossprod_device(d_X, k, rows, pitch, d_ans, s);
+  if (!out_dev && upper_only && !rc) fail(hipMemsetAsync(d_ans, 0, abytes, s), __LINE__);   // the untouched part travels back as zeros
+  if (!rc) rc = crossprod_device(d_X, k, rows, pitch, d_ans, s, c_begin, c_end, upper_only, ld);
   if (!rc && post) {
     const long flen = post == 1 ? k : rows;
     const double *d_f = freq;
@@ -520,6 +551,12 @@ extern "C" int snp_multiply_gpu(unsigned char *snp_matrix, int snps, int indiv, 
   // positional meaning as in the reference: arg 2 = packed (inner) dimension, arg 3 = output dimension
   mxa::clear_error();
   return mxa::crossprod_any(snp_matrix, snps, indiv, ans, is_plink_format);
+}
+
+extern "C" int mxa_snp_multiply_panel(const unsigned char *snp_matrix, int snps, int indiv, int col_begin, int col_end, int upper_only, double *panel,
+                                      long ld, int is_plink_format) {
+  mxa::clear_error();
+  return mxa::crossprod_any(snp_matrix, snps, indiv, panel, is_plink_format != 0, 0, 0, nullptr, col_begin, col_end, upper_only != 0, ld);
 }
 
 extern "C" int mxa_grm(const unsigned char *plink_transposed, int snps, int indiv, double *G, int is_plink_format, int do_scale, const double *allele_freq) {

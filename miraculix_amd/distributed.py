@@ -83,3 +83,65 @@ class ShardedGenotypeOperator:
     def matmul_T(self, B, out=None):
         """B: indiv x n (identical on all ranks).  Returns this rank's row block of C (snps_local x n)."""
         return self.engine.multiply(True, B, out=out)
+
+
+# ------------------------------------------------------------------------------------------------ crossproduct over GPUs
+XTILE = 256   # tile size of the crossproduct kernel: panel boundaries are multiples of it
+
+
+def panel_bounds(n, world, rank, balance_upper=False):
+    """Column panel [c0, c1) of the n x n crossproduct owned by `rank`; boundaries are multiples of XTILE.
+    balance_upper=False: equal numbers of column tiles (every rank computes its whole panel -- independent units, no collective).
+    balance_upper=True: equal areas of the upper triangle (each rank computes rows [0, c1) of its panel)."""
+    nb = (n + XTILE - 1) // XTILE
+    if balance_upper:
+        edges = [int(round(nb * (i / world) ** 0.5)) for i in range(world + 1)]
+    else:
+        edges = [(nb * i) // world for i in range(world + 1)]
+    edges[0], edges[-1] = 0, nb
+    for i in range(1, world + 1):
+        edges[i] = max(edges[i], edges[i - 1])
+    return min(n, edges[rank] * XTILE), min(n, edges[rank + 1] * XTILE)
+
+
+class ShardedCrossproduct:
+    """M = X X^T (output-tile sharding, packed matrix replicated on every GPU).
+    panel_fn(c0, c1, upper_only) -> tensor P (c1 - c0, n) with P[c, r] = M[r, c0 + c] (crossproduct.snp_crossprod_panel)."""
+
+    def __init__(self, panel_fn, n, group=None):
+        self.panel_fn, self.n, self.group = panel_fn, n, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def compute(self, exchange_symmetric=False):
+        """Returns (c0, c1, P): this rank's column panel of M.
+        exchange_symmetric=False: every rank computes its whole panel; no communication at all.
+        exchange_symmetric=True: every rank computes only rows [0, c1) of an area-balanced panel (about half the total work)
+        and the blocks below its diagonal block arrive as transposes from the ranks that own them (point-to-point sends over RCCL/xGMI)."""
+        if not exchange_symmetric or self.world == 1:
+            c0, c1 = panel_bounds(self.n, self.world, self.rank, False)
+            if c1 <= c0:
+                return c0, c1, None
+            return c0, c1, self.panel_fn(c0, c1, False)
+        bounds = [panel_bounds(self.n, self.world, r, True) for r in range(self.world)]
+        c0, c1 = bounds[self.rank]
+        P = self.panel_fn(c0, c1, True) if c1 > c0 else None
+        ops, recvs, keep = [], [], []
+        for peer in range(self.world):
+            p0, p1 = bounds[peer]
+            if peer == self.rank or p1 <= p0 or c1 <= c0:
+                continue
+            if peer < self.rank:     # peer's panel lies left of mine: it needs M[my columns, its columns] = (M[its rows.., mine])^T
+                blk = P[:, p0:p1].contiguous()          # (w_me, w_peer): blk[c, r] = M[p0 + r, c0 + c]
+                keep.append(blk)
+                ops.append(dist.P2POp(dist.isend, blk, peer, group=self.group))
+            else:                    # peer right of me sends its block of rows [c0, c1): (w_peer, w_me)
+                buf = P.new_empty((p1 - p0, c1 - c0))
+                recvs.append((p0, p1, buf))
+                ops.append(dist.P2POp(dist.irecv, buf, peer, group=self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for p0, p1, buf in recvs:    # buf[cb, ra] = M[c0 + ra, p0 + cb] = M[p0 + cb, c0 + ra]  ->  P[ra, p0 + cb]
+            P[:, p0:p1] = buf.t()
+        return c0, c1, P

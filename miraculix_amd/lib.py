@@ -59,6 +59,8 @@ def load_shared_library():
     L.sparse_times_plink.restype = None
     L.mxa_gram_matvec.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_long]
     L.mxa_gram_matvec.restype = ctypes.c_int
+    L.mxa_snp_multiply_panel.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_int]
+    L.mxa_snp_multiply_panel.restype = ctypes.c_int
     L.mxa_set_engine.argtypes = [ctypes.c_int]
     L.mxa_set_engine.restype = ctypes.c_int
     L.mxa_get_engine.restype = ctypes.c_int

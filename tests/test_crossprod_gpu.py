@@ -83,3 +83,36 @@ def test_grm_device_resident(mx):
     assert np.abs(G.cpu().numpy() - Gref).max() <= 1e-9 * np.abs(Gref).max()
     G2 = mx.crossproduct.grm(prob["plink_t"], 2500, 333, is_plink_format=True, do_scale=False)
     assert np.abs(G2 - Zc @ Zc.T).max() <= 1e-9 * np.abs(Zc @ Zc.T).max()
+
+
+@pytest.mark.parametrize("rows,k", [(1000, 900), (1537, 333)])
+def test_crossprod_panels_tile_the_full_result(rows, k):
+    """mxa_snp_multiply_panel (output-tile sharding, SURVEY.md 8e): panels are bit-identical slabs of snp_multiply_gpu's result;
+    upper_only computes rows [0, col_end) and leaves zeros below; host and device operands."""
+    import torch
+    import miraculix_amd as mx
+    from miraculix_amd.distributed import ShardedCrossproduct, panel_bounds
+    mx.load_shared_library()
+    rng = np.random.default_rng(rows)
+    Z = rng.integers(0, 3, size=(rows, k)).astype(np.int8)
+    from _util import pack_plink
+    X = np.ascontiguousarray(pack_plink(Z))                       # PLINK codes, rows x ceil(k/4)
+    full = mx.crossproduct.snp_crossprod(X, k, rows, is_snpmajor=False, is_plink_format=True)
+    ref = Z.astype(np.int64) @ Z.astype(np.int64).T
+    assert np.array_equal(full, ref.astype(np.float64))
+    for world in (1, 2, 3):
+        for rank in range(world):
+            for balance in (False, True):
+                c0, c1 = panel_bounds(rows, world, rank, balance)
+                if c1 <= c0:
+                    continue
+                P = mx.crossproduct.snp_crossprod_panel(X, k, rows, c0, c1, upper_only=balance, is_plink_format=True)
+                expect = full[c0:c1, :].copy()
+                if balance:
+                    expect[:, c1:] = 0.0
+                assert np.array_equal(P, expect), (world, rank, balance)
+    dX = torch.from_numpy(X).cuda()
+    c0, c1, P = ShardedCrossproduct(lambda a, b, u: mx.crossproduct.snp_crossprod_panel(dX, k, rows, a, b, upper_only=u, is_plink_format=True), rows).compute()
+    assert (c0, c1) == (0, rows) and np.array_equal(P.cpu().numpy(), full)
+    with pytest.raises(RuntimeError):
+        mx.crossproduct.snp_crossprod_panel(X, k, rows, 100, 512, is_plink_format=True)   # col_begin must be a multiple of 256

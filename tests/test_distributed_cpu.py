@@ -78,3 +78,42 @@ def test_world2_gloo_sharded_operator(centered):
     for r in range(2):
         errN, errT, errG = ret[r]
         assert errN <= 1e-12 and errT <= 1e-12 and errG <= 1e-12
+
+
+def _xworker(rank, world, port, n, k, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from miraculix_amd.distributed import ShardedCrossproduct, XTILE
+    rng = np.random.default_rng(3)
+    X = rng.integers(0, 3, size=(n, k)).astype(np.int64)
+    M = (X @ X.T).astype(np.float64)
+
+    def panel_fn(c0, c1, upper_only):   # TEST-ONLY local engine with the semantics of mxa_snp_multiply_panel
+        P = M[c0:c1, :].copy()          # P[c, r] = M[r, c0 + c] (M symmetric)
+        if upper_only:
+            P[:, c1:] = 0.0             # rows below the panel's diagonal block are not computed
+        return torch.from_numpy(P)
+
+    res = {}
+    for exch in (False, True):
+        c0, c1, P = ShardedCrossproduct(panel_fn, n).compute(exchange_symmetric=exch)
+        res[exch] = (c0, c1, None if P is None else bool(np.array_equal(P.numpy(), M[c0:c1, :])))
+    ret[rank] = res
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 1500), (3, 2600)])
+def test_gloo_sharded_crossproduct_panels(world, n):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_xworker, args=(world, port, n, 40, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for exch in (False, True):
+        edges = sorted((ret[r][exch][0], ret[r][exch][1]) for r in range(world))
+        assert edges[0][0] == 0 and edges[-1][1] == n
+        for (b0, e0), (b1, e1) in zip(edges, edges[1:]):
+            assert e0 == b1
+        assert all(ret[r][exch][2] in (True, None) for r in range(world))
+        assert any(ret[r][exch][2] for r in range(world))
