@@ -1,14 +1,17 @@
 // mxa_gemm_i8.hip -- OPT-IN engine (env MXA_ENGINE=i8): dgemm_compressed on the int8 matrix cores by exact slicing of B.
 //
 // Not the shipped default: the default path computes in fp64 on v_mfma_f64_4x4x4_4b_f64 (mxa_kernels.hip), as the reference
-// does in fp64 FMAs.  This engine exploits that the genotype operand is an exact small integer (0,1,2):
-//   per column j,  b_kj = 2^(E_j) * sum_{s<S} t_s(k,j) * 2^(-7(s+1)) + r_kj,   t_s int8 in [-64, 64],  |r| <= 2^(E_j - 7S - 1)
-//   (Z B)_ij = sum_s 2^(E_j - 7(s+1)) * ( sum_k z_ik t_s(k,j) )                 <- exact int32 dot products on the int8 MFMA
-// (the "Ozaki" error-free splitting of one operand).  With S = 8 slices B is represented to 2^-57 of each column's largest
-// entry; all integer sums are exact, only the final S-term fp64 combination rounds.  Error bound per output:
-// K * 2 * 2^(E_j - 57), i.e. <= 1.6e-11 * max_k|b_kj| at K = 1M in the worst case (all residuals aligned), ~7e-15 typical --
-// at or below the rounding error of an fp64 dot product of that length, but it is a column-wise fixed-point representation,
-// not element-wise fp64, so it stays opt-in and is never what bench.py reports.
+// does in fp64 FMAs.  This engine exploits that the genotype operand is an exact small integer (0,1,2).  Per column j, with E_j
+// such that |b_kj| * 2^-E_j < 1/2, B is written in radix 256 (two's-complement style: first digit signed, the others unsigned):
+//   b_kj * 2^-E_j = t_0/2^8 + sum_{1<=s<S} u_s/2^(8(s+1)) + r,   t_0 in [-128,127], u_s in [0,255], |r| <= 2^(-8S-1)
+// every step exact in fp64 (the last digit is rounded to nearest).  The unsigned digits are stored as int8 t_s = u_s - 128, so
+//   (Z B)_ij = 2^E_j * [ I_0/2^8 + sum_{s>=1} (I_s + 128 * rowsum_i) / 2^(8(s+1)) ],   I_s = sum_k z_ik t_s(k,j)
+// where the I_s are exact int32 dot products on the int8 MFMA and rowsum_i = sum_k z_ik is computed once per packed matrix (the
+// "Ozaki" error-free splitting of one operand; Z needs no splitting).  With S = 7 digits B is represented to 2^-57 of 2^E_j;
+// all integer sums are exact, only the final S-term fp64 combination rounds.  Error bound per output: K * 2 * 2^(E_j - 57), i.e.
+// <= 1.6e-11 * max_k|b_kj| at K = 1M in the worst case (all residuals aligned), ~7e-15 typical -- at or below the rounding error
+// of an fp64 dot product of that length, but it is a column-wise fixed-point representation, not element-wise fp64, so it stays
+// opt-in and is never what bench.py reports.
 //
 // Kernel: one workgroup (4 waves, one per SIMD) per 256-row tile of the packed matrix and K range; wave tile 64 rows x
 // (NT x 32) expanded columns (column e = slice * nc + j); accumulators NT x 2 tiles of v_mfma_i32_32x32x32_i8 (<= 256 AGPRs).
@@ -38,7 +41,7 @@ __device__ __forceinline__ v4i iunpack16(uint32_t w) {
   return r;
 }
 
-// ---- per-column exponent: E_j = exponent e with max_k |b_kj| < 2^(e-1)  (so that |b * 2^-E| < 1/2 and the first digit fits [-64,64])
+// ---- per-column exponent: E_j = exponent e with max_k |b_kj| < 2^(e-1)  (so that |b * 2^-E| < 1/2 and the first, signed digit fits [-128,127])
 __global__ void __launch_bounds__(256) k_colmax_partial(const double *__restrict__ B, long ldb, long k, double *__restrict__ part) {
   const int j = blockIdx.y, c = blockIdx.x;
   const long per = (k + 63) / 64;
@@ -59,6 +62,21 @@ __global__ void k_colexp_final(const double *__restrict__ part, int n, int *__re
   int e = 0;
   if (m > 0.0 && isfinite(m)) { (void)frexp(m, &e); e += 1; }   // m = f * 2^e', f in [0.5,1)  ->  m < 2^e' = 2^(E-1)
   E[j] = e;
+}
+
+// ---- row sums of the packed matrix (tiled layout): rowsum[r] = sum_k z_rk.  One thread per row, 32 bytes per slab; the 256 rows of
+// a tile read one contiguous 8 KiB run per slab.
+__global__ void __launch_bounds__(256) k_rowsum(const uint8_t *__restrict__ G, long nslabs, int *__restrict__ rowsum) {
+  const long rb = blockIdx.x;
+  const uint4 *p = reinterpret_cast<const uint4 *>(G + (size_t)rb * nslabs * kTileBytes) + 2 * threadIdx.x;
+  int acc = 0;
+  for (long sl = 0; sl < nslabs; sl++) {
+    const uint4 a = p[sl * (kTileBytes / 16)], b = p[sl * (kTileBytes / 16) + 1];
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc += __popc(w[i] & 0x55555555u) + 2 * __popc(w[i] & 0xaaaaaaaau);
+  }
+  rowsum[rb * kTileRows + threadIdx.x] = acc;
 }
 
 // ---- slices in MFMA fragment order.  Bs[chunk][T][nt][lane][16]: T = K-step of 32 genotypes, nt = 32-wide tile of expanded
@@ -87,9 +105,10 @@ __global__ void __launch_bounds__(256) k_slice_B(const double *__restrict__ B, l
       uint32_t w = 0;
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const double v = r[i] * 128.0;            // exact
-        const double t = rint(v);                 // |t| <= 64
-        r[i] = v - t;                             // exact, |r| <= 1/2
+        const double v = r[i] * 256.0;            // exact; first digit: v in (-128, 128), later digits: v in [0, 256)
+        double t = s + 1 < S ? floor(v) : fmin(floor(v + 0.5), s == 0 ? 127.0 : 255.0);   // last digit rounds to nearest
+        r[i] = v - t;                             // exact, in [0, 1)
+        if (s > 0) t -= 128.0;                    // unsigned digit stored with offset: the kernel multiplies signed int8
         w |= ((uint32_t)(int)t & 0xffu) << (8 * i);
       }
       const int e = s * nc + jj;
@@ -265,8 +284,9 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
 // Block = 32 rows x one chunk of columns; P is read with the expanded column running along the lanes, the result is
 // transposed through LDS so that C is written with the row running along the lanes.
 __global__ void __launch_bounds__(256) k_finish_i8(const int *__restrict__ P, long m_pad, int e_pad, int splits, long m, int n, int S, int nc, int NT,
-                                                   const int *__restrict__ E, double *__restrict__ Cout, long ldc, int mode_trans, int centered,
-                                                   const double *__restrict__ sumB, const double *__restrict__ sumfB, const double *__restrict__ f) {
+                                                   const int *__restrict__ E, const int *__restrict__ rowsum, double *__restrict__ Cout, long ldc,
+                                                   int mode_trans, int centered, const double *__restrict__ sumB, const double *__restrict__ sumfB,
+                                                   const double *__restrict__ f) {
   __shared__ double sh[32][33];
   const int chunk = blockIdx.y;
   const long r0 = (long)blockIdx.x * 32;
@@ -278,11 +298,12 @@ __global__ void __launch_bounds__(256) k_finish_i8(const int *__restrict__ P, lo
       double v = 0.0;
       if (r < m && jj < nc && j < n) {
         const int Ej = E[j];
+        const long long off = 128LL * rowsum[r];    // the unsigned digits were stored minus 128
         for (int s = S - 1; s >= 0; s--) {
           const int e = chunk * (NT * 32) + s * nc + jj;
-          long long t = 0;
+          long long t = s > 0 ? off : 0;
           for (int sp = 0; sp < splits; sp++) t += P[((size_t)sp * m_pad + r) * e_pad + e];
-          v += ldexp((double)t, Ej - 7 * (s + 1));
+          v += ldexp((double)t, Ej - 8 * (s + 1));
         }
         if (centered) {
           if (mode_trans) v = fma(-2.0 * sumB[j], f[r], v);
@@ -307,9 +328,9 @@ struct I8Plan { int S, nc, nchunks, NT, e_pad, rowblocks, stages_total, stages_p
 
 static I8Plan plan_i8(long m, long k_pad, int n) {
   I8Plan p{};
-  static const int S = [] { const char *e = getenv("MXA_I8_SLICES"); int s = e ? atoi(e) : 8; return std::min(9, std::max(4, s)); }();
+  static const int S = [] { const char *e = getenv("MXA_I8_SLICES"); int s = e ? atoi(e) : 7; return std::min(8, std::max(3, s)); }();   // 8 bits per digit
   p.S = S;
-  const int max_nc = 256 / S;                                   // <= 8 tiles of 32 expanded columns per pass
+  const int max_nc = std::min(32, 256 / S);                     // <= 8 tiles of 32 expanded columns per pass; k_finish_i8 handles <= 32 columns per chunk
   p.nchunks = (n + max_nc - 1) / max_nc;
   p.nc = (n + p.nchunks - 1) / p.nchunks;
   p.NT = (p.nc * S + 31) / 32;
@@ -322,6 +343,7 @@ static I8Plan plan_i8(long m, long k_pad, int n) {
   long want = (2048 + units - 1) / units;                        // 256 resident workgroups -> >= 8 rounds
   long max_splits = std::max<long>(1, p.stages_total / 32);
   long splits = std::max<long>(1, std::min<long>(want, max_splits));
+  splits = std::max<long>(splits, (p.stages_total + 32767) / 32768);   // int32 accumulators: 2 * 128 * (K per split) < 2^31
   p.stages_per_split = (int)((p.stages_total + splits - 1) / splits);
   p.splits = (p.stages_total + p.stages_per_split - 1) / p.stages_per_split;
   return p;
@@ -362,12 +384,17 @@ static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const 
 
 // Whole product on the device; B, C device pointers; asynchronous on s.  The workspace (exponents, slices, partials) lives with the
 // handle and only grows.
-int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, bool centered, const double *d_sumB,
+int gemm_i8_device(PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, bool centered, const double *d_sumB,
                    const double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out) {
   const long m = G.rows, k = G.k;
   const I8Plan p = plan_i8(m, G.k_pad, n);
   if (p.m_pad > G.rows_pad) { set_error(4, "internal: packed matrix smaller than the i8 plan"); return 1; }
   if (splits_out) *splits_out = p.splits;
+  if (!G.d_rowsum) {   // once per packed matrix
+    MXA_HIP(hipMalloc(reinterpret_cast<void **>(&G.d_rowsum), sizeof(int) * (size_t)G.rows_pad));
+    hipLaunchKernelGGL(k_rowsum, dim3((unsigned)(G.rows_pad / kTileRows)), dim3(256), 0, s, G.d, G.nslabs, G.d_rowsum);
+    MXA_HIP(hipGetLastError());
+  }
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
   const size_t part_bytes = up(sizeof(double) * 64 * n), e_bytes = up(sizeof(int) * n);
   const size_t bs_bytes = up((size_t)p.nchunks * p.T_total * p.NT * 1024);
@@ -411,7 +438,7 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   if (ev1) MXA_HIP(hipEventRecord(ev1, s));
   {
     dim3 grid((unsigned)((ldc + 31) / 32), p.nchunks);
-    hipLaunchKernelGGL(k_finish_i8, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, dC, ldc, trans ? 1 : 0,
+    hipLaunchKernelGGL(k_finish_i8, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, G.d_rowsum, dC, ldc, trans ? 1 : 0,
                        centered ? 1 : 0, d_sumB, d_sumfB, d_f);
   }
   MXA_HIP(hipGetLastError());

@@ -1,4 +1,4 @@
-"""Opt-in engine 'i8' (mxa_gemm_i8.hip: every column of B split exactly into 8 signed 7-bit digits, int8 matrix cores, exact
+"""Opt-in engine 'i8' (mxa_gemm_i8.hip: every column of B split exactly into 7 radix-256 digits, int8 matrix cores, exact
 int32 accumulation, fp64 recombination) against the oracle, through the C ABI."""
 import numpy as np
 import pytest
