@@ -8,6 +8,8 @@
 // 9*K for K < 2.3e8.
 #include "../../include/miraculix_amd.h"
 #include "mxa_internal.h"
+#include <atomic>
+#include <thread>
 #include <algorithm>
 #include <cstdio>
 #include <vector>
@@ -392,6 +394,83 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
   return 0;
 }
 
+// Whole matrix for a HOST result (the plain reference ABI): the upper-triangular tiles are launched in chunks of tile rows i
+// (all j >= i).  Tile (i, j) stores M[J rows, I cols] and M[I rows, J cols], so once every chunk up to tile row i1 has run, columns
+// [0, 256*i1) of M are final: a helper thread copies each finished column slab to the host on its own non-blocking stream while
+// the next chunk computes (at config 3 the 80 GB device-to-host copy is as long as the compute).
+static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch, double *d_ans, double *h_ans, hipStream_t s) {
+  const int nb = (int)((rows + kXT - 1) / kXT);
+  const int stages = (int)((k + kXStageK - 1) / kXStageK);
+  if ((size_t)stages * kXStageBytes > pitch) { set_error(4, "internal: crossproduct pitch too small"); return 1; }
+  std::vector<int4> tiles;
+  std::vector<size_t> first(nb + 1, 0);
+  tiles.reserve((size_t)nb * (nb + 1) / 2);
+  for (int i = 0; i < nb; i++) {
+    first[i] = tiles.size();
+    for (int j = i; j < nb; j++) tiles.push_back(make_int4(i, j, i == j ? 1 : 3, 0));
+  }
+  first[nb] = tiles.size();
+  int4 *d_tiles = nullptr;
+  MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_tiles), tiles.size() * sizeof(int4)));
+  MXA_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, s));
+  static bool attr2 = false;
+  if (!attr2) { MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_crossprod2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kX2Lds)); attr2 = true; }
+  const char *slab_env = getenv("MXA_XPROD_SLAB_MB");                                        // tests use small slabs
+  const long slab_bytes = (slab_env && atol(slab_env) > 0 ? atol(slab_env) : 1024L) << 20;
+  const int rows_per_chunk = (int)std::max<long>(1, slab_bytes / (rows * 8 * kXT));         // ~1 GiB column slabs
+  const int nchunks = (nb + rows_per_chunk - 1) / rows_per_chunk;
+  std::vector<hipEvent_t> ev((size_t)nchunks, nullptr);
+  int dev = 0;
+  MXA_HIP(hipGetDevice(&dev));
+  for (auto &e : ev) MXA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  hipEvent_t e0, e1;
+  MXA_HIP(hipEventCreate(&e0)); MXA_HIP(hipEventCreate(&e1));
+  std::atomic<int> launched{0}, copy_err{0};
+  std::atomic<bool> abort_copy{false};
+  // a copy into pageable memory is staged by the runtime and bound by one host thread's memcpy (~17 GB/s measured): several
+  // copier threads, each with its own stream and its own share of every slab, run those memcpys side by side
+  constexpr int kCopiers = 4;
+  hipStream_t cs[kCopiers] = {};
+  for (auto &c : cs) MXA_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+  auto copy_loop = [&](int t) {
+    if (hipSetDevice(dev) != hipSuccess) { copy_err = 1; return; }
+    for (int c = 0; c < nchunks; c++) {
+      while (launched.load() <= c) { if (abort_copy.load()) return; std::this_thread::yield(); }
+      if (hipEventSynchronize(ev[c]) != hipSuccess) { copy_err = 1; return; }
+      const long col0 = (long)c * rows_per_chunk * kXT, col1 = std::min<long>(rows, (long)(c + 1) * rows_per_chunk * kXT);
+      const long w = col1 - col0, a = col0 + w * t / kCopiers, b = col0 + w * (t + 1) / kCopiers;
+      if (b <= a) continue;
+      const size_t off = (size_t)a * rows, cnt = (size_t)(b - a) * rows;
+      if (hipMemcpyAsync(h_ans + off, d_ans + off, cnt * sizeof(double), hipMemcpyDeviceToHost, cs[t]) != hipSuccess || hipStreamSynchronize(cs[t]) != hipSuccess) { copy_err = 1; return; }
+    }
+  };
+  std::vector<std::thread> copiers;
+  for (int t = 0; t < kCopiers; t++) copiers.emplace_back(copy_loop, t);
+  int rc = 0;
+  if (hipEventRecord(e0, s) != hipSuccess) rc = 1;
+  for (int c = 0; c < nchunks && !rc; c++) {
+    const int i0 = c * rows_per_chunk, i1 = std::min(nb, i0 + rows_per_chunk);
+    const size_t cnt = first[i1] - first[i0];
+    hipLaunchKernelGGL(k_crossprod2<false>, dim3((unsigned)cnt), dim3(256), kX2Lds, s, d_X, pitch, stages, d_tiles + first[i0], rows, d_ans, rows, 0L, (unsigned long long *)nullptr);
+    if (hipGetLastError() != hipSuccess || hipEventRecord(ev[c], s) != hipSuccess) { rc = 1; break; }
+    launched.store(c + 1);
+  }
+  if (rc) abort_copy = true;
+  if (!rc && hipEventRecord(e1, s) != hipSuccess) rc = 1;
+  for (auto &t : copiers) t.join();
+  if (hipStreamSynchronize(s) != hipSuccess) rc = 1;
+  if (!rc && !copy_err.load()) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { profile().launches += 1; profile().total_ms += ms; }
+  }
+  for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  for (auto &c : cs) (void)hipStreamDestroy(c);
+  (void)hipFree(d_tiles);
+  if (rc || copy_err.load()) { set_error(13, "snp_multiply_gpu: pipelined device-to-host copy of the result failed"); return 1; }
+  return 0;
+}
+
 // ---- GRM / LD post-processing on the device (reference: host BLAS in src/bindings/Julia/crossproduct.jl:83-152, maths docs/grm.md)
 // column sums of the symmetric n x n matrix, fixed-order tree per column
 __global__ void __launch_bounds__(256) k_sym_colsum(const double *__restrict__ M, long n, double *__restrict__ cs) {
@@ -524,6 +603,10 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
   }
   if (!out_dev && fail(hipMalloc(reinterpret_cast<void **>(&d_ans), abytes), __LINE__)) goto done;
   if (!out_dev && upper_only && !rc) fail(hipMemsetAsync(d_ans, 0, abytes, s), __LINE__);   // the untouched part travels back as zeros
+  if (!rc && !out_dev && !post && c_begin == 0 && c_end == rows && ld == rows && !getenv("MXA_XPROD_NO_PIPELINE")) {
+    rc = crossprod_to_host(d_X, k, rows, pitch, d_ans, ans, s);
+    goto done;
+  }
   if (!rc) rc = crossprod_device(d_X, k, rows, pitch, d_ans, s, c_begin, c_end, upper_only, ld);
   if (!rc && post) {
     const long flen = post == 1 ? k : rows;

@@ -116,3 +116,22 @@ def test_crossprod_panels_tile_the_full_result(rows, k):
     assert (c0, c1) == (0, rows) and np.array_equal(P.cpu().numpy(), full)
     with pytest.raises(RuntimeError):
         mx.crossproduct.snp_crossprod_panel(X, k, rows, 100, 512, is_plink_format=True)   # col_begin must be a multiple of 256
+
+
+def test_crossprod_host_result_is_pipelined_in_slabs(monkeypatch):
+    """Host result: tile rows are launched in chunks and each finished column slab is copied out while the next chunk computes.
+    Small slabs force many chunks; the result must be the same matrix, and identical to the unpipelined path."""
+    import miraculix_amd as mx
+    from _util import pack_plink
+    mx.load_shared_library()
+    rng = np.random.default_rng(5)
+    rows, k = 2305, 700
+    Z = rng.integers(0, 3, size=(rows, k)).astype(np.int8)
+    X = np.ascontiguousarray(pack_plink(Z))
+    ref = (Z.astype(np.int64) @ Z.astype(np.int64).T).astype(np.float64)
+    monkeypatch.setenv("MXA_XPROD_SLAB_MB", "5")          # 5 MiB -> one tile row (256 columns) per chunk, 10 chunks
+    M = mx.crossproduct.snp_crossprod(X, k, rows, is_snpmajor=False, is_plink_format=True)
+    assert np.array_equal(M, ref)
+    monkeypatch.setenv("MXA_XPROD_NO_PIPELINE", "1")
+    M2 = mx.crossproduct.snp_crossprod(X, k, rows, is_snpmajor=False, is_plink_format=True)
+    assert np.array_equal(M2, ref)
