@@ -152,7 +152,7 @@ static void destroy_handle(Handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void *ptrs[] = {h->snp_major.d, h->ind_major.d, h->snp_major.d_rowsum, h->ind_major.d_rowsum, h->d_f, h->ws.d_Bstage, h->ws.d_Cstage, h->ws.d_Bp, h->ws.d_P, h->ws.d_colpart, h->ws.d_i8, h->ws.d_tmp};
+  void *ptrs[] = {h->snp_major.d, h->ind_major.d, h->snp_major.d_rowsum, h->ind_major.d_rowsum, h->d_f, h->ws.d_Bstage, h->ws.d_Cstage, h->ws.d_Bp, h->ws.d_P, h->ws.d_colpart, h->ws.d_i8, h->ws.d_tmp, h->ws.d_exp};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -242,7 +242,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   Geometry &geo = last_geometry();
   geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c;
   double *d_sumB = w.d_colpart + (size_t)n * 128, *d_sumfB = d_sumB + n;
-  static const int mode = [] { const char *e = getenv("MXA_GEMM_MODE"); return e ? atoi(e) : 0; }();
+  static const int mode = [] { const char *e = getenv("MXA_GEMM_MODE"); return e ? atoi(e) : 2; }();
   if (g_engine.load() == 1) {   // opt-in: exact int8 slicing of B on the int8 matrix cores (mxa_gemm_i8.hip)
     if (centered && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
     const bool prof8 = g_profile_on && timing;
@@ -258,7 +258,19 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     }
     return 0;
   }
-  if (!use_lut && launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s)) return 1;
+  // MODE 2 (default): genotype operand as the denormal z * 2^-1074 (one VALU per fragment instead of two); B scaled per column
+  const int *d_E = nullptr;
+  if (!use_lut && mode == 2) {
+    if (w.cap_exp < (size_t)n) {
+      MXA_HIP(hipStreamSynchronize(s));
+      if (w.d_exp) { MXA_HIP(hipFree(w.d_exp)); w.d_exp = nullptr; w.cap_exp = 0; }
+      MXA_HIP(hipMalloc(reinterpret_cast<void **>(&w.d_exp), sizeof(int) * (size_t)n));
+      w.cap_exp = n;
+    }
+    if (launch_colexp(dB, ldb, k, n, w.d_colpart, w.d_exp, 0, s)) return 1;
+    d_E = w.d_exp;
+  }
+  if (!use_lut && launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, d_E)) return 1;
   if (centered && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
   const bool prof = g_profile_on && timing;   // the asynchronous entry must not block on an event
   hipEvent_t e0 = h->ev0, e1 = h->ev1;
@@ -268,7 +280,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   }
   int rc = use_lut ? launch_lut(G, dB, ldb, n, w.d_P, p, s) : launch_gemm(G, w.d_Bp, w.d_P, p, mode, s);
   if (prof && !rc) MXA_HIP(hipEventRecord(e1, s));
-  if (!rc) rc = launch_finish(w.d_P, p, m, n, dC, ldc, trans ? 1 : 0, centered, d_sumB, d_sumfB, h->d_f, s);
+  if (!rc) rc = launch_finish(w.d_P, p, m, n, dC, ldc, trans ? 1 : 0, centered, d_sumB, d_sumfB, h->d_f, s, d_E);
   if (prof) {
     if (!rc) {
       MXA_HIP(hipEventSynchronize(e1));

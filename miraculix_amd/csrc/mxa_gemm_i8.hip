@@ -41,29 +41,6 @@ __device__ __forceinline__ v4i iunpack16(uint32_t w) {
   return r;
 }
 
-// ---- per-column exponent: E_j = exponent e with max_k |b_kj| < 2^(e-1)  (so that |b * 2^-E| < 1/2 and the first, signed digit fits [-128,127])
-__global__ void __launch_bounds__(256) k_colmax_partial(const double *__restrict__ B, long ldb, long k, double *__restrict__ part) {
-  const int j = blockIdx.y, c = blockIdx.x;
-  const long per = (k + 63) / 64;
-  const long c0 = c * per, c1 = std::min<long>(k, c0 + per);
-  double m = 0.0;
-  for (long r = c0 + threadIdx.x; r < c1; r += 256) m = fmax(m, fabs(B[r + (long)j * ldb]));
-  __shared__ double sh[256];
-  sh[threadIdx.x] = m;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + w]); __syncthreads(); }
-  if (threadIdx.x == 0) part[(size_t)j * 64 + c] = sh[0];
-}
-__global__ void k_colexp_final(const double *__restrict__ part, int n, int *__restrict__ E) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  double m = 0.0;
-  for (int c = 0; c < 64; c++) m = fmax(m, part[(size_t)j * 64 + c]);
-  int e = 0;
-  if (m > 0.0 && isfinite(m)) { (void)frexp(m, &e); e += 1; }   // m = f * 2^e', f in [0.5,1)  ->  m < 2^e' = 2^(E-1)
-  E[j] = e;
-}
-
 // ---- row sums of the packed matrix (tiled layout): rowsum[r] = sum_k z_rk.  One thread per row, 32 bytes per slab; the 256 rows of
 // a tile read one contiguous 8 KiB run per slab.
 __global__ void __launch_bounds__(256) k_rowsum(const uint8_t *__restrict__ G, long nslabs, int *__restrict__ rowsum) {
@@ -412,8 +389,7 @@ int gemm_i8_device(PackedMatrix &G, bool trans, int n, const double *dB, long ld
   int8_t *d_Bs = reinterpret_cast<int8_t *>(base + part_bytes + e_bytes);
   int *d_P = reinterpret_cast<int *>(base + part_bytes + e_bytes + bs_bytes);
 
-  hipLaunchKernelGGL(k_colmax_partial, dim3(64, n), dim3(256), 0, s, dB, ldb, k, d_part);
-  hipLaunchKernelGGL(k_colexp_final, dim3((n + 63) / 64), dim3(64), 0, s, d_part, n, d_E);
+  if (launch_colexp(dB, ldb, k, n, d_part, d_E, 1, s)) return 1;   // E_j = e + 1: |b| * 2^-E_j < 1/2, the signed first digit fits [-128, 127]
   if (p.NT * 32 != p.nc * p.S) MXA_HIP(hipMemsetAsync(d_Bs, 0, bs_bytes, s));   // expanded columns beyond nc*S are never written
   {
     const int ncols = p.nchunks * p.nc;

@@ -48,6 +48,7 @@ struct Workspace {
   double *d_P = nullptr;      size_t cap_P = 0;        // split-K partial slabs
   double *d_colpart = nullptr; size_t cap_colpart = 0; // column-sum partials + sums
   double *d_tmp = nullptr;    size_t cap_tmp = 0;      // snps x n intermediate of mxa_gram_matvec
+  int *d_exp = nullptr;       size_t cap_exp = 0;      // per-column exponents of B (denormal-operand mode)
   void *d_i8 = nullptr;       size_t cap_i8 = 0;       // int8 engine: exponents, slices of B, int32 partials (bytes)
 };
 
@@ -88,7 +89,12 @@ void debug_info(const char *fmt, ...);
 // recode raw PLINK rows (src pitch arbitrary) into the padded z-coded device layout
 int launch_recode(const uint8_t *d_src, size_t src_pitch, long row0, long nrows, long k, long k_bit_offset,
                   PackedMatrix &dst, hipStream_t s);
-int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k_pad, int n_pad, int c, hipStream_t s);
+// denormal-operand mode of k_gemm (MODE 2): B columns are scaled to just below 2^kDenUp, the genotype operand is z * 2^-1074
+constexpr int kDenUp = 900;
+// E[j] = binary exponent of the largest |entry| of column j (frexp convention) + bias; d_part: 64 * n doubles of scratch
+int launch_colexp(const double *dB, long ldb, long k, int n, double *d_part, int *d_E, int bias, hipStream_t s);
+// d_E (nullable): per-column exponents for the denormal-operand mode
+int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k_pad, int n_pad, int c, hipStream_t s, const int *d_E = nullptr);
 int launch_colsums(const double *dB, long ldb, long k, int n, const double *d_f /*nullable*/, double *d_part,
                    double *d_sumB, double *d_sumfB, hipStream_t s);
 struct GemmPlan { int a, c, nchunks, n_pad, splits, slabs_per_split, slabs_total, rowblocks; long m_pad; };
@@ -97,7 +103,7 @@ int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const Gemm
 GemmPlan plan_lut(long m, long k_pad, int n);
 int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double *dP, const GemmPlan &p, hipStream_t s);
 int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC, long ldc, int mode_trans,
-                  bool centered, const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s);
+                  bool centered, const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s, const int *d_E = nullptr);
 int launch_transpose_2bit(const uint8_t *d_in, long rows, long cols, uint8_t *d_out, hipStream_t s);
 int launch_allele_freq(const uint8_t *d_plink, long snps, long indiv, double *d_f, hipStream_t s);
 // crossproduct

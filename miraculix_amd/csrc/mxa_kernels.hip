@@ -76,7 +76,7 @@ int launch_recode(const uint8_t *d_src, size_t src_pitch, long row0, long nrows,
 // 16S + (blk + 4*k) = 16S + (l>>2) to it; tools/mfma_f64_probe2.hip).  A slab of 8 K-steps of one chunk is one contiguous
 // run of C*4 KiB, so it streams HBM -> LDS as C*4 lane-linear LDS-DMA units for any C.
 __global__ void __launch_bounds__(256) k_pack_B(const double *__restrict__ B, long ldb, long k, int n,
-                                                double *__restrict__ Bp, long total, int C, long S_total) {
+                                                double *__restrict__ Bp, long total, int C, long S_total, const int *__restrict__ E, int up) {
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int l = (int)(idx & 63);
     const long sh = idx >> 6;
@@ -87,16 +87,48 @@ __global__ void __launch_bounds__(256) k_pack_B(const double *__restrict__ B, lo
     const long row = S * 16 + (l >> 2);
     const int col = chunk * 4 * C + 4 * h + (l & 3);
     double v = 0.0;
-    if (row < k && col < n) v = B[row + (long)col * ldb];
+    if (row < k && col < n) {
+      v = B[row + (long)col * ldb];
+      if (E) v = ldexp(v, up - E[col]);      // denormal-operand mode: column scaled to just below 2^up (exact)
+    }
     Bp[idx] = v;
   }
 }
 
-int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k_pad, int n_pad, int c, hipStream_t s) {
+// ---- per-column binary exponent: E[j] = e + bias with max_k |B[k,j]| = f * 2^e, f in [0.5, 1)  (0 + bias for a zero or non-finite column)
+__global__ void __launch_bounds__(256) k_colmax_partial(const double *__restrict__ B, long ldb, long k, double *__restrict__ part) {
+  const int j = blockIdx.y, c = blockIdx.x;
+  const long per = (k + 63) / 64;
+  const long c0 = c * per, c1 = std::min<long>(k, c0 + per);
+  double m = 0.0;
+  for (long r = c0 + threadIdx.x; r < c1; r += 256) m = fmax(m, fabs(B[r + (long)j * ldb]));
+  __shared__ double sh[256];
+  sh[threadIdx.x] = m;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + w]); __syncthreads(); }
+  if (threadIdx.x == 0) part[(size_t)j * 64 + c] = sh[0];
+}
+__global__ void k_colexp_final(const double *__restrict__ part, int n, int bias, int *__restrict__ E) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double m = 0.0;
+  for (int c = 0; c < 64; c++) m = fmax(m, part[(size_t)j * 64 + c]);
+  int e = 0;
+  if (m > 0.0 && isfinite(m)) (void)frexp(m, &e);
+  E[j] = e + bias;
+}
+int launch_colexp(const double *dB, long ldb, long k, int n, double *d_part, int *d_E, int bias, hipStream_t s) {
+  hipLaunchKernelGGL(k_colmax_partial, dim3(64, n), dim3(256), 0, s, dB, ldb, k, d_part);
+  hipLaunchKernelGGL(k_colexp_final, dim3((n + 63) / 64), dim3(64), 0, s, d_part, n, bias, d_E);
+  MXA_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k_pad, int n_pad, int c, hipStream_t s, const int *d_E) {
   const long S_total = k_pad / 16;
   const long total = S_total * (long)(n_pad / 4) * 64;
   const int grid = (int)std::min<long>((total + 255) / 256, 256L * 64);
-  hipLaunchKernelGGL(k_pack_B, dim3(grid), dim3(256), 0, s, dB, ldb, k, n, dBp, total, c, S_total);
+  hipLaunchKernelGGL(k_pack_B, dim3(grid), dim3(256), 0, s, dB, ldb, k, n, dBp, total, c, S_total, d_E, kDenUp);
   MXA_HIP(hipGetLastError());
   return 0;
 }
@@ -191,8 +223,14 @@ struct GemmCfg {
   static_assert(kABytes % 1024 == 0, "A tile must be a whole number of DMA units");
 };
 
-// Conversion of a 2-bit allele count z (lane's field of the packed word) to the fp64 MFMA operand, exact in both modes:
-//   MODE 0 (shipped): v_bfe_u32 + v_cvt_f64_u32 -- 2 VALU per fragment, all A fragments of a K-step converted first, then
+// Conversion of a 2-bit allele count z (lane's field of the packed word) to the fp64 MFMA operand, exact in all modes:
+//   MODE 2 (shipped): v_bfe_u32 only.  The register pair (low word z, high word 0) IS the double z * 2^-1074, a denormal, which
+//                     v_mfma_f64_4x4x4_4b_f64 takes exactly and at full rate (tools/mfma_f64_denorm_probe.hip: bit-identical
+//                     to normal operands over 4096 accumulation steps, 76.5 vs 75.1 TFLOP/s).  The high words are zeroed once
+//                     before the K loop and stay in place; k_pack_B scales every column of B to just below 2^900 (per-column
+//                     exponent from launch_colexp), k_finish scales the sums back by 2^(174 + e_j): powers of two, so every
+//                     product and sum is the same as with normal operands unless an intermediate would under- or overflow.
+//   MODE 0:           v_bfe_u32 + v_cvt_f64_u32 -- 2 VALU per fragment, all A fragments of a K-step converted first, then
 //                     the A*C MFMAs back to back (pinned with sched_barrier).
 //   MODE 1 (kept for A/B measurement): v_bfe_u32, v_lshl_add_u32, v_cmp, v_cndmask building the high word by integer ops
 //                     -- 4 VALU per fragment, interleaved with the MFMAs by the compiler.
@@ -200,7 +238,8 @@ struct GemmCfg {
 // is placed and whether or not an MFMA depends on it (tools/mfma_f64_probe5.hip, profiles/r01_mfma_f64_probe.txt): the
 // VALU instruction count per MFMA is the lever, not latency hiding.  Measured on MI355X, 200k x 50k x 32:
 // MODE 1 63.6 TFLOP/s, MODE 0 69.7 TFLOP/s; with the LDS-DMA addresses computed on the VALU instead of the scalar
-// unit MODE 0 drops to 65.5.
+// unit MODE 0 drops to 65.5.  MODE 2 vs MODE 0 at 1M x 50k: n = 32 (C = 8) 17.1k vs 17.3k cycles per slab (+1 %),
+// n = 20 (C = 5) 72.0 vs 68.7 TFLOP/s, n = 10 (C = 3) 56.0 vs 52.0.
 template <int A, int C, int MODE, bool DIAG = false>
 __global__ void __launch_bounds__(256, 2)
 k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ Bp, int H, double *__restrict__ P,
@@ -254,6 +293,14 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
 #pragma unroll
     for (int h = 0; h < C; h++) acc[g][h] = 0.0;
 
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 ap[A];                                                    // MODE 2: A operands as (low, high) word pairs, high words stay 0
+#pragma unroll
+  for (int g = 0; g < A; g++) {
+    uint32_t zero;   // opaque to the optimiser: a known constant would be re-materialised next to every low word (one v_mov per fragment)
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+    ap[g].x = 0; ap[g].y = zero;
+  }
   const int sh = 2 * (lane >> 2);                                 // field of this lane inside a 16-genotype dword
   const int a_off = (wave * Cfg::kRowsWave + (lane & 3)) * kSlabBytes;  // + g*4 rows -> + g*4*32 bytes
   const int b_off = lane * 8;
@@ -281,7 +328,19 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
         double bf[C];
 #pragma unroll
         for (int h = 0; h < C; h++) bf[h] = *reinterpret_cast<const double *>(bbase + (ks * C + h) * 512);
-        if (MODE == 0) {
+        if (MODE == 2) {
+          // denormal operand: the pair (low word = z, high word = 0) IS the double z * 2^-1074.  Only the low word is rewritten
+          // (one v_bfe_u32); the high words were zeroed once before the K loop and stay in place (loop-carried register pairs).
+          double af[A];
+#pragma unroll
+          for (int g = 0; g < A; g++) { ap[g].x = __builtin_amdgcn_ubfe(kk ? aw[g].y : aw[g].x, sh, 2); af[g] = __builtin_bit_cast(double, ap[g]); }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int g = 0; g < A; g++)
+#pragma unroll
+            for (int h = 0; h < C; h++) acc[g][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[g], bf[h], acc[g][h], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        } else if (MODE == 0) {
           double af[A];
 #pragma unroll
           for (int g = 0; g < A; g++) af[g] = (double)__builtin_amdgcn_ubfe(kk ? aw[g].y : aw[g].x, sh, 2);
@@ -407,6 +466,7 @@ int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const Gemm
 #define MXA_DISPATCH(AA, CC)                                              \
   if (p.a == AA && p.c == CC) {                                           \
     if (mode == 1) return launch_gemm_t<AA, CC, 1>(G, dBp, dP, p, s);     \
+    if (mode == 2) return launch_gemm_t<AA, CC, 2>(G, dBp, dP, p, s);     \
     return launch_gemm_t<AA, CC, 0>(G, dBp, dP, p, s);                    \
   }
   MXA_DISPATCH(16, 1)
@@ -611,13 +671,14 @@ int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double 
 __global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, long m_pad, int n_pad, int splits, long m, int n,
                                                 double *__restrict__ Cout, long ldc, int mode_trans, int centered,
                                                 const double *__restrict__ sumB, const double *__restrict__ sumfB,
-                                                const double *__restrict__ f) {
+                                                const double *__restrict__ f, const int *__restrict__ E, int back) {
   const int j = blockIdx.y;
   const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= ldc) return;
   double v = 0.0;
   if (r < m) {
     for (int s = 0; s < splits; s++) v += P[((size_t)s * n_pad + j) * m_pad + r];
+    if (E) v = ldexp(v, back + E[j]);          // undo the operand scaling of the denormal-operand mode (exact)
     if (centered) {
       if (mode_trans) v = fma(-2.0 * sumB[j], f[r], v);
       else v += -2.0 * sumfB[j];
@@ -627,10 +688,10 @@ __global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, lo
 }
 
 int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC, long ldc, int mode_trans, bool centered,
-                  const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s) {
+                  const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s, const int *d_E) {
   dim3 grid((unsigned)((ldc + 255) / 256), n);
   hipLaunchKernelGGL(k_finish, grid, dim3(256), 0, s, dP, p.m_pad, p.n_pad, p.splits, m, n, dC, ldc, mode_trans, centered ? 1 : 0,
-                     d_sumB, d_sumfB, d_f);
+                     d_sumB, d_sumfB, d_f, d_E, 1074 - kDenUp);
   MXA_HIP(hipGetLastError());
   return 0;
 }
