@@ -98,3 +98,43 @@ def test_uncentred_without_frequencies(mx):
     _check(mx, o, obj, prob, 0, 4, 0)
     _check(mx, o, obj, prob, 1, 4, 0)
     mx.dgemm_compressed.free_compressed(obj)
+
+
+def test_extreme_magnitudes_of_B(mx):
+    """k_gemm feeds the genotypes as denormal doubles (z * 2^-1074) and scales every column of B by a power of two into a fixed
+    window; the scaling must be invisible: columns at 1e-300, 1e+250, around the denormal threshold, an all-zero column, and a
+    column that mixes 1e+20 with 1e-20 come out within the stated tolerance of the oracle (relative to each column's largest entry);
+    non-finite input stays non-finite."""
+    o = Oracle()
+    snps, indiv, n = 2051, 700, 7
+    prob = make_problem(snps, indiv, n, seed=77, missing_frac=0.03)
+    dg = mx.dgemm_compressed
+    dg.set_options(use_gpu=True, not_center=True, verbose=0)
+    obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], n)
+    try:
+        for trans in (0, 1):
+            k = indiv if trans else snps
+            m = snps if trans else indiv
+            B = make_B(k, n, seed=3)
+            B[0] *= 1e-300
+            B[1] *= 1e250
+            B[2] *= 3e-308           # products with z = 2 straddle the smallest normal number
+            B[3] = 0.0
+            B[4, ::2] *= 1e20
+            B[4, 1::2] *= 1e-20
+            B[5] *= 2.0 ** -1040     # denormal inputs
+            ref = o.dgemm_dense(trans, prob, B, 0)[:, :m]
+            C = dg.dgemm_compressed_main(bool(trans), obj, np.asfortranarray(B.T), snps, indiv)
+            assert np.all(np.isfinite(C))
+            assert np.all(C[:, 3] == 0.0)
+            for j in range(n):
+                scale = np.abs(ref[j]).max()
+                if scale > 0:
+                    assert np.abs(C[:, j] - ref[j]).max() <= RTOL * scale, (trans, j)
+            Binf = make_B(k, 5, seed=4)
+            Binf[1, 5] = np.inf
+            Cinf = dg.dgemm_compressed_main(bool(trans), obj, np.asfortranarray(Binf.T), snps, indiv)
+            assert np.all(np.isfinite(Cinf[:, [0, 2, 3, 4]]))      # the other columns are untouched by the bad one
+            assert not np.any(np.isfinite(Cinf[:, 1]))             # inf * z is inf (z > 0) or NaN (z = 0), as in plain fp64
+    finally:
+        dg.free_compressed(obj)
