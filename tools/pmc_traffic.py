@@ -11,7 +11,7 @@ def per_dispatch(d):
     src = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
     agg = collections.OrderedDict()
     for r in csv.DictReader(open(src)):
-        if "k_gemm" in r["Kernel_Name"]:
+        if "k_gemm<" in r["Kernel_Name"]:   # the fp64 kernel, not k_gemm_i8
             agg[r["Dispatch_Id"]] = agg.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
     return list(agg.values())
 
