@@ -29,39 +29,46 @@ __device__ __forceinline__ uint32_t recode16(uint32_t w) {
   return ((H & L) << 1) | (H & ~L);
 }
 
+// Workgroup = 32 rows x 4 slabs (128 source bytes per row): 8 threads read one full 128-byte run of a source row (16 bytes each,
+// dword loads when the address allows), and the 64 threads of a slab write one contiguous 1 KiB run of the tiled layout
+// (mxa_internal.h: byte b of row R -> ((R/256)*nslabs + b/32)*8192 + (R%256)*32 + b%32).
 __global__ void __launch_bounds__(256) k_recode(const uint8_t *__restrict__ src, size_t src_pitch, long src_row_bytes,
-                                                long nrows, long k, uint8_t *__restrict__ dst, size_t dst_pitch,
-                                                long dst_row0, long nslabs) {
-  const long dwords_per_row = (long)(dst_pitch >> 2);
-  const long total = nrows * dwords_per_row;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const long r = idx / dwords_per_row, d = idx - r * dwords_per_row;
-    const long b = d * 4;
-    const uint8_t *p = src + (size_t)r * src_pitch + b;
-    uint32_t w = 0;
-    if (b + 3 < src_row_bytes) {
-      w = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-    } else {
-      for (int u = 0; u < 4; u++)
-        if (b + u < src_row_bytes) w |= (uint32_t)p[u] << (8 * u);
-    }
-    w = recode16(w);
-    long valid = k - 16 * d;  // genotypes of this dword that exist
-    if (valid <= 0) w = 0;
-    else if (valid < 16) w &= (1u << (2 * valid)) - 1u;
-    // tiled layout (mxa_internal.h): byte b of row R -> ((R/256)*nslabs + b/32)*8192 + (R%256)*32 + b%32
-    const long R = dst_row0 + r;
-    const size_t off = ((size_t)(R / kTileRows) * nslabs + (size_t)(b / kSlabBytes)) * kTileBytes + (size_t)(R % kTileRows) * kSlabBytes + (b % kSlabBytes);
-    *reinterpret_cast<uint32_t *>(dst + off) = w;
+                                                long nrows, long k, uint8_t *__restrict__ dst, long dst_row0, long nslabs, long rows_blocks) {
+  const long rblk = blockIdx.x % rows_blocks, sgrp = blockIdx.x / rows_blocks;
+  const int rr = threadIdx.x >> 3, part = threadIdx.x & 7;
+  const long r = rblk * 32 + rr;
+  const long slab = sgrp * 4 + (part >> 1);
+  if (r >= nrows || slab >= nslabs) return;
+  const long b = slab * kSlabBytes + (part & 1) * 16;        // first source byte of this thread's 16
+  uint32_t w[4] = {0u, 0u, 0u, 0u};
+  const uint8_t *p = src + (size_t)r * src_pitch + b;
+  if (b + 16 <= src_row_bytes && (reinterpret_cast<size_t>(p) & 3) == 0) {
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
+    w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; w[3] = q[3];
+  } else {
+    for (int u = 0; u < 16; u++)
+      if (b + u < src_row_bytes) w[u >> 2] |= (uint32_t)p[u] << (8 * (u & 3));
   }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    uint32_t x = recode16(w[i]);
+    const long valid = k - 4 * (b + 4 * i);                  // genotypes of this dword that exist
+    if (valid <= 0) x = 0;
+    else if (valid < 16) x &= (1u << (2 * valid)) - 1u;
+    w[i] = x;
+  }
+  const long R = dst_row0 + r;
+  const size_t off = ((size_t)(R / kTileRows) * nslabs + (size_t)slab) * kTileBytes + (size_t)(R % kTileRows) * kSlabBytes + (part & 1) * 16;
+  *reinterpret_cast<uint4 *>(dst + off) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 int launch_recode(const uint8_t *d_src, size_t src_pitch, long row0, long nrows, long k, long /*unused*/,
                   PackedMatrix &dst, hipStream_t s) {
   if (nrows <= 0) return 0;
-  const long total = nrows * (long)(dst.pitch >> 2);
-  const int grid = (int)std::min<long>((total + 255) / 256, 256L * 32);
-  hipLaunchKernelGGL(k_recode, dim3(grid), dim3(256), 0, s, d_src, src_pitch, (k + 3) / 4, nrows, k, dst.d, dst.pitch, row0, dst.nslabs);
+  const long rows_blocks = (nrows + 31) / 32, slab_groups = (dst.nslabs + 3) / 4;
+  const long grid = rows_blocks * slab_groups;
+  if (grid > 0x7fffffffL) { set_error(4, "internal: recode grid too large"); return 1; }
+  hipLaunchKernelGGL(k_recode, dim3((unsigned)grid), dim3(256), 0, s, d_src, src_pitch, (k + 3) / 4, nrows, k, dst.d, row0, dst.nslabs, rows_blocks);
   MXA_HIP(hipGetLastError());
   return 0;
 }
