@@ -250,17 +250,23 @@ struct GemmCfg {
 template <int A, int C, int MODE, bool DIAG = false>
 __global__ void __launch_bounds__(256, 2)
 k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ Bp, int H, double *__restrict__ P,
-       long m_pad, int n_pad, int rowblocks, int nchunks, int slabs_total, int slabs_per_split,
+       long m_pad, int n_pad, int rowblocks, int nchunks, int slabs_total, int slabs_per_split, int xcd_order,
        unsigned long long *__restrict__ diag = nullptr) {
   using Cfg = GemmCfg<A, C>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // Workgroups that share a B slab stream are all row blocks of one (column chunk, K split) group.  Plain order: row block fastest.
+  // XCD-aware order (when the number of groups is a multiple of 8): consecutive blockIdx.x are dealt round-robin to the 8 XCDs, each
+  // with its own L2, so group g is given to XCD g % 8 only -- its B slabs cross the fabric once instead of once per XCD.
   int bid = blockIdx.x;
-  const int rb = bid % rowblocks; bid /= rowblocks;
-  const int nc = bid % nchunks;
-  const int sp = bid / nchunks;
+  const int ngroups = (int)(gridDim.x / rowblocks);
+  int rb, grp;
+  if (xcd_order && (ngroups & 7) == 0) { const int xcd = bid & 7, slot = bid >> 3; rb = slot % rowblocks; grp = xcd + 8 * (slot / rowblocks); }
+  else { rb = bid % rowblocks; grp = bid / rowblocks; }
+  const int nc = grp % nchunks;
+  const int sp = grp / nchunks;
   const int slab0 = sp * slabs_per_split;
   const int slab1 = min(slab0 + slabs_per_split, slabs_total);
   const long row0 = (long)rb * Cfg::kRowsWG;
@@ -438,6 +444,7 @@ static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, c
   }
   const long grid = (long)p.rowblocks * p.nchunks * p.splits;
   if (grid > 0x7fffffffL) { set_error(3, "grid too large"); return 1; }
+  static const int xcd_order = [] { const char *e = getenv("MXA_XCD_ORDER"); return e ? atoi(e) : 1; }();   // 0: plain order (A/B measurement)
   static const bool diag_on = getenv("MXA_DIAG") != nullptr;
   if (diag_on && A == 8 && C == 8) {   // diagnostic instantiation: in-kernel clock + cycles per slab
     static bool attr2 = false;
@@ -445,7 +452,7 @@ static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, c
     unsigned long long *d_diag = nullptr;
     MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_diag), sizeof(unsigned long long) * 2 * grid));
     hipLaunchKernelGGL((k_gemm<A, C, MODE, true>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBp, p.n_pad / 4, dP,
-                       p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, p.slabs_per_split, d_diag);
+                       p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, p.slabs_per_split, xcd_order, d_diag);
     MXA_HIP(hipStreamSynchronize(s));
     std::vector<unsigned long long> h(2 * grid);
     MXA_HIP(hipMemcpy(h.data(), d_diag, sizeof(unsigned long long) * 2 * grid, hipMemcpyDeviceToHost));
@@ -458,7 +465,7 @@ static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, c
     return 0;
   }
   hipLaunchKernelGGL((k_gemm<A, C, MODE>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBp, p.n_pad / 4, dP,
-                     p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, p.slabs_per_split, nullptr);
+                     p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, p.slabs_per_split, xcd_order, nullptr);
   MXA_HIP(hipGetLastError());
   return 0;
 }
