@@ -233,6 +233,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   const bool centered = options().centered;
   if (centered && !h->has_f) { set_error(6, "dgemm_compressed: centring requested but no allele frequencies were supplied to plink2compressed"); return 1; }
   if (ldb < k || ldc < m) { set_error(7, "dgemm_compressed: leading dimension too small (ldb %ld < %ld or ldc %ld < %ld)", ldb, k, ldc, m); return 1; }
+  if (n > 65535) { set_error(7, "dgemm_compressed: n = %d exceeds the supported 65535 columns per call", n); return 1; }
   if (n > h->max_n) { h->max_n = n; }
   if (ensure_workspace(h, n)) return 1;
   Workspace &w = h->ws;
