@@ -61,10 +61,8 @@ __global__ void __launch_bounds__(256) k_xstage(const uint8_t *__restrict__ src,
 constexpr int kXT = 256;              // tile edge (rows of X per operand block)
 constexpr int kXStageK = 128;         // genotypes per LDS stage = 32 packed bytes per row
 constexpr int kXStageBytes = kXStageK / 4;
-constexpr int kXWaves = 8;            // 2 (I) x 4 (J) waves, wave tile 128 x 64
 constexpr int kXOpBytes = kXT * kXStageBytes;     // 8 KiB per operand per stage
 constexpr int kXBufBytes = 2 * kXOpBytes;
-constexpr int kXLds = 2 * kXBufBytes;             // 32 KiB
 
 // 16 two-bit fields of a dword -> 16 int8 in 4 dwords (field order permuted identically for both operands)
 __device__ __forceinline__ v4i unpack16(uint32_t w) {
@@ -76,91 +74,9 @@ __device__ __forceinline__ v4i unpack16(uint32_t w) {
   return r;
 }
 
-__global__ void __launch_bounds__(512, 2)
-k_crossprod(const uint8_t *__restrict__ X, size_t pitch, int stages, const int2 *__restrict__ tiles, long n, double *__restrict__ ans) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wi = wave >> 2, wj = wave & 3;      // wave tile: rows [128*wi, +128) of the I block, rows [64*wj, +64) of the J block
-  const int2 t = tiles[blockIdx.x];
-  const long i0 = (long)t.x * kXT, j0 = (long)t.y * kXT;
-
-  // DMA: 16 units of 1 KiB per stage (8 per operand); unit u covers rows [32u', 32u'+32) x 32 B; lane -> row lane/2, half lane&1
-  auto issue = [&](int stage, int buf) {
-    char *base = smem + buf * kXBufBytes;
-#pragma unroll
-    for (int u = wave; u < 16; u += kXWaves) {
-      const int op = u >> 3, uu = u & 7;
-      const long row = (op ? j0 : i0) + uu * 32 + (lane >> 1);
-      const char *src = reinterpret_cast<const char *>(X) + (size_t)row * pitch + (size_t)stage * kXStageBytes + (lane & 1) * 16;
-      xdma16(src, base + op * kXOpBytes + uu * 1024);
-    }
-  };
-
-  v16i acc[4][2];
-#pragma unroll
-  for (int a = 0; a < 4; a++)
-#pragma unroll
-    for (int b = 0; b < 2; b++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[a][b][r] = 0;
-
-  // lane (r = lane&31, h = lane>>5) reads the 16-byte half h of row r: 4 dwords = its K subset for the 4 K-steps of a stage
-  const int a_off = (wi * 128 + (lane & 31)) * kXStageBytes + (lane >> 5) * 16;
-  const int b_off = kXOpBytes + (wj * 64 + (lane & 31)) * kXStageBytes + (lane >> 5) * 16;
-
-  issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int s = 0; s < stages; s++) {
-    const int buf = s & 1;
-    if (s + 1 < stages) issue(s + 1, buf ^ 1);
-    const char *base = smem + buf * kXBufBytes;
-    uint4 aw[4], bw[2];
-#pragma unroll
-    for (int a = 0; a < 4; a++) aw[a] = *reinterpret_cast<const uint4 *>(base + a_off + a * 32 * kXStageBytes);
-#pragma unroll
-    for (int b = 0; b < 2; b++) bw[b] = *reinterpret_cast<const uint4 *>(base + b_off + b * 32 * kXStageBytes);
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-      v4i bf[2];
-#pragma unroll
-      for (int b = 0; b < 2; b++) bf[b] = unpack16(ks == 0 ? bw[b].x : ks == 1 ? bw[b].y : ks == 2 ? bw[b].z : bw[b].w);
-#pragma unroll
-      for (int a = 0; a < 4; a++) {
-        const v4i af = unpack16(ks == 0 ? aw[a].x : ks == 1 ? aw[a].y : ks == 2 ? aw[a].z : aw[a].w);
-#pragma unroll
-        for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[b], acc[a][b], 0, 0, 0);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-
-  // epilogue.  32x32 C/D map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Element (I row gi, J row gj) = M[gi][gj]:
-  // write ans[gj + gi*n] (coalesced along lanes) and its mirror ans[gi + gj*n].
-  const int col = lane & 31, rq = 4 * (lane >> 5);
-#pragma unroll
-  for (int a = 0; a < 4; a++)
-#pragma unroll
-    for (int b = 0; b < 2; b++) {
-      const long gj = j0 + wj * 64 + b * 32 + col;
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const long gi = i0 + wi * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + rq;
-        if (gi < n && gj < n) {
-          const double v = (double)acc[a][b][r];
-          ans[(size_t)gj + (size_t)gi * n] = v;
-          if (t.x != t.y) ans[(size_t)gi + (size_t)gj * n] = v;
-        }
-      }
-    }
-}
-
-// ---- v2: 4 waves, one per SIMD, wave tile 128 x 128 (16 accumulator tiles = 256 registers), 3-deep LDS-DMA ring with a
-// counted vmcnt.  Per K-step of 32 genotypes a wave unpacks 8 fragments (56 VALU) for 16 MFMAs (512 MFMA cycles), half the
-// VALU density of v1 (6 fragments per 8 MFMAs), which is what limited v1 (tools/perf_crossprod.py: 43-54 % of the int8 peak).
-constexpr int kX2Waves = 4;
+// 4 waves, one per SIMD, wave tile 128 x 128 (16 accumulator tiles = 256 registers), 3-deep LDS-DMA ring with a counted vmcnt.
+// Per K-step of 32 genotypes a wave unpacks 8 fragments (56 VALU) for 16 MFMAs (512 MFMA cycles).  (The first version used 8
+// waves with 128 x 64 wave tiles -- 6 fragments per 8 MFMAs -- and stalled at 43-54 % of the int8 peak on that VALU density.)
 constexpr int kX2Bufs = 3;
 constexpr int kX2Lds = kX2Bufs * kXBufBytes;      // 48 KiB
 
@@ -331,34 +247,23 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
   if (!whole && c_end % kXT != 0 && c_end != rows) { set_error(4, "crossproduct: panel end must be a multiple of %d or the matrix end", kXT); return 1; }
   // upper-triangular tiles (i <= j) that touch the panel: the direct image M[J rows, I cols] lands in the panel when i is a panel
   // column tile, the mirror image M[I rows, J cols] when j is
-  std::vector<int4> tiles4;
-  std::vector<int2> tiles;
+  std::vector<int4> tiles;
   for (int i = 0; i < nb; i++)
     for (int j = i; j < nb; j++) {
       int flags = 0;
       if (i >= t0 && i < t1 && (!upper_only || j < t1)) flags |= 1;      // rows of tile j >= i: on/below the diagonal
       if (j >= t0 && j < t1 && i != j) flags |= 2;                        // rows of tile i < j: above the diagonal
-      if (flags) { tiles4.push_back(make_int4(i, j, flags, 0)); tiles.push_back(make_int2(i, j)); }
+      if (flags) tiles.push_back(make_int4(i, j, flags, 0));
     }
-  if (tiles4.empty()) return 0;
-  int4 *d_tiles4 = nullptr;
-  MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_tiles4), tiles4.size() * sizeof(int4)));
-  MXA_HIP(hipMemcpyAsync(d_tiles4, tiles4.data(), tiles4.size() * sizeof(int4), hipMemcpyHostToDevice, s));
-  int2 *d_tiles = nullptr;
-  MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_tiles), tiles.size() * sizeof(int2)));
-  MXA_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice, s));
-  static bool attr_set = false;
-  if (!attr_set) {
-    MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_crossprod), hipFuncAttributeMaxDynamicSharedMemorySize, kXLds));
-    attr_set = true;
-  }
+  if (tiles.empty()) return 0;
+  int4 *d_tiles = nullptr;
+  MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_tiles), tiles.size() * sizeof(int4)));
+  MXA_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, s));
   hipEvent_t e0, e1;
   MXA_HIP(hipEventCreate(&e0)); MXA_HIP(hipEventCreate(&e1));
   MXA_HIP(hipEventRecord(e0, s));
-  static const int xver_env = [] { const char *e = getenv("MXA_XPROD_VER"); return e ? atoi(e) : 2; }();
-  const int xver = whole ? xver_env : 2;   // the first-generation kernel only knows the whole matrix
   const long c0 = c_begin;
-  if (xver == 2) {
+  {
     static bool attr2 = false;
     if (!attr2) {
       MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_crossprod2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kX2Lds));
@@ -368,7 +273,7 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
     if (getenv("MXA_DIAG")) {   // diagnostic instantiation: in-kernel clock and cycles per stage
       unsigned long long *d_diag = nullptr;
       MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_diag), 16 * tiles.size()));
-      hipLaunchKernelGGL(k_crossprod2<true>, dim3((unsigned)tiles.size()), dim3(256), kX2Lds, s, d_X, pitch, stages, d_tiles4, rows, d_ans, ld, c0, d_diag);
+      hipLaunchKernelGGL(k_crossprod2<true>, dim3((unsigned)tiles.size()), dim3(256), kX2Lds, s, d_X, pitch, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
       MXA_HIP(hipStreamSynchronize(s));
       std::vector<unsigned long long> hd(2 * tiles.size());
       MXA_HIP(hipMemcpy(hd.data(), d_diag, 16 * tiles.size(), hipMemcpyDeviceToHost));
@@ -379,9 +284,8 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
                                tiles.size(), ghz[ghz.size() / 2], ghz.front(), ghz.back(), cyc[cyc.size() / 2]);
       (void)hipFree(d_diag);
     } else
-    hipLaunchKernelGGL(k_crossprod2<false>, dim3((unsigned)tiles.size()), dim3(256), kX2Lds, s, d_X, pitch, stages, d_tiles4, rows, d_ans, ld, c0, (unsigned long long *)nullptr);
-  } else
-  hipLaunchKernelGGL(k_crossprod, dim3((unsigned)tiles.size()), dim3(512), kXLds, s, d_X, pitch, stages, d_tiles, rows, d_ans);
+    hipLaunchKernelGGL(k_crossprod2<false>, dim3((unsigned)tiles.size()), dim3(256), kX2Lds, s, d_X, pitch, stages, d_tiles, rows, d_ans, ld, c0, (unsigned long long *)nullptr);
+  }
   MXA_HIP(hipGetLastError());
   MXA_HIP(hipEventRecord(e1, s));
   MXA_HIP(hipStreamSynchronize(s));   // tiles vector / d_tiles lifetime
@@ -390,7 +294,6 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
   profile().launches += 1; profile().total_ms += ms;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(d_tiles);
-  (void)hipFree(d_tiles4);
   return 0;
 }
 

@@ -649,7 +649,6 @@ static int launch_lut_t(const PackedMatrix &G, const double *dB, long ldb, int n
 }
 
 constexpr int kLutKS = 128;   // genotypes per slab of the lookup kernel (= kSlabK, so the staged pitch fits)
-constexpr int kLutMaxN = 2;   // n <= 2 uses the lookup kernel (n = 4 measured slower than the MFMA (16,2) tile)
 
 GemmPlan plan_lut(long m, long k_pad, int n) {
   GemmPlan p{};
