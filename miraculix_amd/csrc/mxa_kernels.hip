@@ -761,12 +761,104 @@ __global__ void __launch_bounds__(256) k_transpose_2bit(const uint8_t *__restric
   }
 }
 
+// Fast path (both row pitches multiples of 4 bytes): 256 rows x 512 columns per workgroup.  Full 128-byte runs of 256 input rows
+// go to LDS; every thread transposes two 16 x 16 blocks of 2-bit fields in registers with a 4-stage butterfly (masked swaps at
+// distances 8, 4, 2, 1 -- 192 integer ops per 256 genotypes, no per-field gather); the transposed dwords go back through the same
+// LDS buffer so that the 512 output rows leave as 64-byte runs.
+__device__ __forceinline__ void swap_fields(uint32_t &lo, uint32_t &hi, int sh, uint32_t mask) {
+  const uint32_t t = ((lo >> sh) ^ hi) & mask;   // exchange the high half-blocks of lo with the low half-blocks of hi
+  hi ^= t;
+  lo ^= t << sh;
+}
+__device__ __forceinline__ void transpose16x16_2bit(uint32_t (&a)[16]) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) swap_fields(a[i], a[i + 8], 16, 0x0000FFFFu);
+#pragma unroll
+  for (int i = 0; i < 16; i++) if (!(i & 4)) swap_fields(a[i], a[i + 4], 8, 0x00FF00FFu);
+#pragma unroll
+  for (int i = 0; i < 16; i++) if (!(i & 2)) swap_fields(a[i], a[i + 2], 4, 0x0F0F0F0Fu);
+#pragma unroll
+  for (int i = 0; i < 16; i++) if (!(i & 1)) swap_fields(a[i], a[i + 1], 2, 0x33333333u);
+}
+
+struct __attribute__((packed, aligned(4))) U4 { uint32_t x[4]; };   // 16 bytes with 4-byte alignment: global_load/store_dwordx4
+constexpr int kTrRows = 256, kTrCols = 512;            // genotypes per tile
+constexpr int kTrInPitch = kTrCols / 16 + 1;           // dwords per tile row in LDS (+1: conflict-free column reads)
+constexpr int kTrOutPitch = kTrRows / 16 + 1;
+
+__global__ void __launch_bounds__(256) k_transpose_2bit_tiled(const uint8_t *__restrict__ in, long rows, long cols, uint8_t *__restrict__ out, unsigned nbx) {
+  __shared__ uint32_t lds[(kTrRows * kTrInPitch > kTrCols * kTrOutPitch) ? kTrRows * kTrInPitch : kTrCols * kTrOutPitch];
+  const long bin = (cols + 3) / 4, bout = (rows + 3) / 4;   // multiples of 4 (checked by the launcher)
+  const long r0 = (long)(blockIdx.x / nbx) * kTrRows, c0 = (long)(blockIdx.x % nbx) * kTrCols;
+  const long din = bin / 4, dout = bout / 4;                // dwords per row
+  const uint32_t *in32 = reinterpret_cast<const uint32_t *>(in);
+  uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
+  // phase 1: 256 rows x 32 dwords, 8 threads x 4 dwords per row
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const int idx = threadIdx.x + 256 * it;
+    const int r = idx >> 3, part = idx & 7;
+    const long gr = r0 + r, gd = c0 / 16 + part * 4;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    if (gr < rows) {
+      const uint32_t *p = in32 + (size_t)gr * din + gd;
+      if (gd + 3 < din) { const U4 v = *reinterpret_cast<const U4 *>(p); w[0] = v.x[0]; w[1] = v.x[1]; w[2] = v.x[2]; w[3] = v.x[3]; }   // one 16-byte load, 4-byte aligned
+      else { for (int u = 0; u < 4; u++) if (gd + u < din) w[u] = p[u]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) lds[r * kTrInPitch + part * 4 + u] = w[u];
+  }
+  __syncthreads();
+  // phase 2: block (br, bc) = rows 16 br .. +15, dword column bc
+  uint32_t a[2][16];
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int bc = threadIdx.x & 31, br = (threadIdx.x >> 5) + 8 * pass;
+#pragma unroll
+    for (int i = 0; i < 16; i++) a[pass][i] = lds[(16 * br + i) * kTrInPitch + bc];
+    transpose16x16_2bit(a[pass]);
+  }
+  __syncthreads();
+  // phase 3: a[f] is dword br of output row 16 bc + f
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int bc = threadIdx.x & 31, br = (threadIdx.x >> 5) + 8 * pass;
+#pragma unroll
+    for (int f = 0; f < 16; f++) lds[(16 * bc + f) * kTrOutPitch + br] = a[pass][f];
+  }
+  __syncthreads();
+  // phase 4: 512 output rows x 16 dwords, 4 threads x 4 dwords per row
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const int idx = threadIdx.x + 256 * it;
+    const int orow = idx >> 2, part = idx & 3;
+    const long gc = c0 + orow, gd = r0 / 16 + part * 4;
+    if (gc < cols) {
+      uint32_t *p = out32 + (size_t)gc * dout + gd;
+      U4 v;
+#pragma unroll
+      for (int u = 0; u < 4; u++) v.x[u] = lds[orow * kTrOutPitch + part * 4 + u];
+      if (gd + 3 < dout) *reinterpret_cast<U4 *>(p) = v;
+      else { for (int u = 0; u < 4; u++) if (gd + u < dout) p[u] = v.x[u]; }
+    }
+  }
+}
+
 int launch_transpose_2bit(const uint8_t *d_in, long rows, long cols, uint8_t *d_out, hipStream_t s) {
   if (rows <= 0 || cols <= 0) return 0;
-  const long nbx = (cols + 63) / 64, nby = (rows + 63) / 64;
-  if (nbx * nby > 0x7fffffffL) { set_error(3, "mxa_transpose_2bit: matrix too large for one launch"); return 1; }
   const long bin = (cols + 3) / 4, bout = (rows + 3) / 4;
   const bool aligned = (bin % 4 == 0) && (bout % 4 == 0) && (reinterpret_cast<uintptr_t>(d_in) % 4 == 0) && (reinterpret_cast<uintptr_t>(d_out) % 4 == 0);
+  static const bool no_tiled = getenv("MXA_TRANSPOSE_GENERIC") != nullptr;   // A/B measurement
+  if (aligned && !no_tiled) {
+    // fields beyond `rows` / `cols` inside the last dwords are zero in the input (PLINK padding) and come out as zero padding
+    const long nbx = (cols + kTrCols - 1) / kTrCols, nby = (rows + kTrRows - 1) / kTrRows;
+    if (nbx * nby > 0x7fffffffL) { set_error(3, "mxa_transpose_2bit: matrix too large for one launch"); return 1; }
+    hipLaunchKernelGGL(k_transpose_2bit_tiled, dim3((unsigned)(nbx * nby)), dim3(256), 0, s, d_in, rows, cols, d_out, (unsigned)nbx);
+    MXA_HIP(hipGetLastError());
+    return 0;
+  }
+  const long nbx = (cols + 63) / 64, nby = (rows + 63) / 64;
+  if (nbx * nby > 0x7fffffffL) { set_error(3, "mxa_transpose_2bit: matrix too large for one launch"); return 1; }
   if (aligned) hipLaunchKernelGGL(k_transpose_2bit<true>, dim3((unsigned)(nbx * nby)), dim3(256), 0, s, d_in, rows, cols, d_out, (unsigned)nbx);
   else hipLaunchKernelGGL(k_transpose_2bit<false>, dim3((unsigned)(nbx * nby)), dim3(256), 0, s, d_in, rows, cols, d_out, (unsigned)nbx);
   MXA_HIP(hipGetLastError());

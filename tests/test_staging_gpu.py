@@ -15,7 +15,10 @@ def mx():
     return m
 
 
-@pytest.mark.parametrize("snps,indiv", [(1000, 500), (1003, 501), (64, 64), (130, 1027), (4097, 255)])
+# the last six shapes have both row pitches multiples of 4 bytes: the tiled butterfly kernel (256 x 512 tiles, ragged edges, partial
+# last dwords); the others take the generic kernel
+@pytest.mark.parametrize("snps,indiv", [(1000, 500), (1003, 501), (64, 64), (130, 1027), (4097, 255),
+                                        (16, 16), (1024, 512), (1022, 509), (2064, 784), (272, 4112), (6000, 4000)])
 def test_transpose_and_freq(mx, snps, indiv):
     o = Oracle()
     prob = make_problem(snps, indiv, 1, seed=snps)
