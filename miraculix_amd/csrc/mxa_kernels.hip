@@ -423,11 +423,25 @@ GemmPlan plan_gemm(long m, long k_pad, int n) {
   p.rowblocks = (int)((m + rows_wg - 1) / rows_wg);
   p.m_pad = (long)p.rowblocks * rows_wg;
   p.slabs_total = (int)(k_pad / kSlabK);
-  // aim for >= ~24 rounds of 512 resident workgroups so the tail round is small; keep >= 8 slabs per unit
+  // aim for >= ~24 rounds of 512 resident workgroups (2 per CU) so the tail is small; keep >= 8 slabs per unit.  Around that
+  // target pick the split count whose number of workgroups fills whole rounds best: 391 row blocks x 32 splits = 24.4 rounds
+  // costs a 25th round at 44 % occupancy, 34 splits = 25.96 rounds does not.
   const long units = (long)p.rowblocks * p.nchunks;
-  long want = (12288 + units - 1) / units;
-  long max_splits = std::max<long>(1, p.slabs_total / 8);
-  long splits = std::max<long>(1, std::min<long>(want, max_splits));
+  const long want = (12288 + units - 1) / units;
+  const long max_splits = std::max<long>(1, p.slabs_total / 8);
+  static const long resident = [] { const char *e = getenv("MXA_GEMM_RESIDENT"); return e ? atol(e) : 512L; }();   // 0: no search
+  long best_splits = std::max<long>(1, std::min<long>(want, max_splits));
+  if (resident > 0) {
+    double best_eff = -1.0;
+    for (long cand = std::max<long>(1, want - want / 4); cand <= std::min<long>(max_splits, want + want / 3 + 1); cand++) {
+      const long per = (p.slabs_total + cand - 1) / cand;
+      const long actual = (p.slabs_total + per - 1) / per;
+      const long wgs = units * actual;
+      const double eff = (double)wgs / (double)(resident * ((wgs + resident - 1) / resident));
+      if (eff > best_eff + 1e-9) { best_eff = eff; best_splits = cand; }
+    }
+  }
+  const long splits = best_splits;
   p.slabs_per_split = (int)((p.slabs_total + splits - 1) / splits);
   p.splits = (p.slabs_total + p.slabs_per_split - 1) / p.slabs_per_split;
   if (p.splits < 1) p.splits = 1;
