@@ -254,6 +254,8 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
        unsigned long long *__restrict__ diag = nullptr) {
   using Cfg = GemmCfg<A, C>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long rt_begin = 0;
+  if (DIAG) rt_begin = __builtin_amdgcn_s_memrealtime();
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -382,31 +384,51 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
 
   if (DIAG) {
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0 && diag) { diag[2 * (size_t)blockIdx.x] = t1 - t0; diag[2 * (size_t)blockIdx.x + 1] = r1 - r0; }
-  }
-  // ---- epilogue: add the 4 K-blocks (lane bits 2..3), then lane (j, blk, i) stores column group hq+blk
-  const int j = lane & 3, blk = (lane >> 2) & 3, i = lane >> 4;
-  double *Pbase = P + (size_t)sp * n_pad * m_pad;
-#pragma unroll
-  for (int g = 0; g < A; g++) {
-    const long row = row0 + wave * Cfg::kRowsWave + g * 4 + i;
-#pragma unroll
-    for (int hq = 0; hq < C; hq += 4) {
-      double v[4];
-#pragma unroll
-      for (int t = 0; t < 4; t++) {
-        double x = (hq + t < C) ? acc[g][hq + t] : 0.0;
-        x += __shfl_xor(x, 4);
-        x += __shfl_xor(x, 8);
-        v[t] = x;
-      }
-      const double out = blk == 0 ? v[0] : blk == 1 ? v[1] : blk == 2 ? v[2] : v[3];
-      if (hq + blk < C) {
-        const int col = 4 * (nc * C + hq + blk) + j;
-        Pbase[(size_t)col * m_pad + row] = out;
-      }
+    if (threadIdx.x == 0 && diag) {
+      diag[2 * (size_t)blockIdx.x] = t1 - t0; diag[2 * (size_t)blockIdx.x + 1] = r1 - r0;
+      diag[2 * (size_t)gridDim.x + 2 * (size_t)blockIdx.x] = rt_begin; diag[2 * (size_t)gridDim.x + 2 * (size_t)blockIdx.x + 1] = r0;   // entry, loop start
     }
   }
+  // ---- epilogue: add the 4 K-blocks (lane bits 2..3); lane (j, blk, i) stores column group hq+blk.  The exchange goes through the
+  // (now idle) LDS ring, not through cross-lane VALU shuffles: while this wave is in its epilogue the other workgroup of the CU is
+  // in its MFMA stream, where every VALU instruction of this wave waits for the shared pipe and costs the other one MFMA time
+  // (shuffle version: ~330 VALU per lane, 15 us per workgroup; here 3 v_add_f64 per output).
+  const int j = lane & 3, blk = (lane >> 2) & 3, i = lane >> 4;
+  constexpr int kPitch = 68;                                   // doubles per accumulator image: 64 lanes + pad (2-way conflicts at most)
+  constexpr int kPerWave = Cfg::kLds / kWaves / 8;             // doubles of scratch per wave
+  constexpr int GP = (kPerWave / (C * kPitch)) < A ? (kPerWave / (C * kPitch)) : A;   // row groups per pass
+  static_assert(GP >= 1, "epilogue scratch");
+  double *scr = reinterpret_cast<double *>(smem) + wave * kPerWave;
+  // P[split][row block][n_pad][rows of the block]: the workgroup's results form one contiguous chunk
+  double *Pbase = P + ((size_t)sp * rowblocks + rb) * ((size_t)n_pad * Cfg::kRowsWG);
+#pragma unroll
+  for (int g0 = 0; g0 < A; g0 += GP) {
+#pragma unroll
+    for (int gg = 0; gg < GP; gg++)
+#pragma unroll
+      for (int h = 0; h < C; h++)
+        if (g0 + gg < A) scr[(gg * C + h) * kPitch + lane] = acc[g0 + gg][h];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the wave's own LDS writes are done before any of its lanes reads them
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int gg = 0; gg < GP; gg++) {
+      if (g0 + gg < A) {
+        const int row = wave * Cfg::kRowsWave + (g0 + gg) * 4 + i;   // row inside the block
+#pragma unroll
+        for (int hq = 0; hq < C; hq += 4) {
+          if (hq + blk < C) {
+            const double *q = scr + (gg * C + hq + blk) * kPitch + j + 16 * i;
+            const double out = (q[0] + q[4]) + (q[8] + q[12]);
+            const int col = 4 * (nc * C + hq + blk) + j;
+            Pbase[(size_t)col * Cfg::kRowsWG + row] = out;
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (DIAG && threadIdx.x == 0 && diag) diag[4 * (size_t)gridDim.x + blockIdx.x] = __builtin_amdgcn_s_memrealtime();   // exit
 }
 
 GemmPlan plan_gemm(long m, long k_pad, int n) {
@@ -422,6 +444,7 @@ GemmPlan plan_gemm(long m, long k_pad, int n) {
   const int rows_wg = kWaves * 4 * p.a;
   p.rowblocks = (int)((m + rows_wg - 1) / rows_wg);
   p.m_pad = (long)p.rowblocks * rows_wg;
+  p.p_rows = rows_wg;
   p.slabs_total = (int)(k_pad / kSlabK);
   // aim for >= ~24 rounds of 512 resident workgroups (2 per CU) so the tail is small; keep >= 8 slabs per unit.  Around that
   // target pick the split count whose number of workgroups fills whole rounds best: 391 row blocks x 32 splits = 24.4 rounds
@@ -464,17 +487,30 @@ static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, c
     static bool attr2 = false;
     if (!attr2) { MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm<A, C, MODE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds)); attr2 = true; }
     unsigned long long *d_diag = nullptr;
-    MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_diag), sizeof(unsigned long long) * 2 * grid));
+    MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_diag), sizeof(unsigned long long) * 5 * grid));
     hipLaunchKernelGGL((k_gemm<A, C, MODE, true>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBp, p.n_pad / 4, dP,
                        p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, p.slabs_per_split, xcd_order, d_diag);
     MXA_HIP(hipStreamSynchronize(s));
-    std::vector<unsigned long long> h(2 * grid);
-    MXA_HIP(hipMemcpy(h.data(), d_diag, sizeof(unsigned long long) * 2 * grid, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> h(5 * grid);
+    MXA_HIP(hipMemcpy(h.data(), d_diag, sizeof(unsigned long long) * 5 * grid, hipMemcpyDeviceToHost));
     std::vector<double> ghz, cyc;
     for (long i = 0; i < grid; i++) if (h[2 * i + 1]) { ghz.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1); cyc.push_back((double)h[2 * i] / p.slabs_per_split); }
     std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end());
     if (!ghz.empty()) printf("MXA_DIAG k_gemm<%d,%d,%d>: grid %ld, in-kernel clock median %.3f GHz (min %.3f max %.3f); shader cycles per slab median %.0f (ideal %d)\n",
                              A, C, MODE, grid, ghz[ghz.size() / 2], ghz.front(), ghz.back(), cyc[cyc.size() / 2], kSlabSteps * A * C * 16 * 2);
+    double ticks = 0.0;   // 100 MHz ticks spent inside the K loops, summed over the workgroups
+    for (long i = 0; i < grid; i++) ticks += (double)h[2 * i + 1];
+    printf("MXA_DIAG k_gemm: K loops of all workgroups = %.3f ms if packed perfectly on 512 resident slots (compare with the kernel duration)\n", ticks * 1e-5 / 512.0);
+    {   // workgroup lifetimes (100 MHz real-time counter): entry -> loop start -> loop end -> exit, and the span of the whole grid
+      double pro = 0, epi = 0, life = 0; unsigned long long first = ~0ull, last = 0;
+      for (long i = 0; i < grid; i++) {
+        const unsigned long long b = h[2 * grid + 2 * i], ls = h[2 * grid + 2 * i + 1], e = h[4 * grid + i], le = ls + h[2 * i + 1];
+        pro += (double)(ls - b); epi += (double)(e - le); life += (double)(e - b);
+        first = std::min(first, b); last = std::max(last, e);
+      }
+      printf("MXA_DIAG k_gemm: per workgroup mean prologue %.2f us, epilogue %.2f us, lifetime %.1f us; grid span %.3f ms; sum of lifetimes / 512 = %.3f ms\n",
+             pro / grid * 1e-2, epi / grid * 1e-2, life / grid * 1e-2, (double)(last - first) * 1e-5, life * 1e-5 / 512.0);
+    }
     (void)hipFree(d_diag);
     return 0;
   }
@@ -671,6 +707,7 @@ GemmPlan plan_lut(long m, long k_pad, int n) {
   p.nchunks = 1;
   p.rowblocks = (int)((m + 64 * kLutWaves - 1) / (64 * kLutWaves));
   p.m_pad = (long)p.rowblocks * 64 * kLutWaves;
+  p.p_rows = p.m_pad;
   p.slabs_total = (int)(k_pad / kLutKS);
   const long units = p.rowblocks;
   static const long target = [] { const char *e = getenv("MXA_LUT_UNITS"); return e ? atol(e) : 8192L; }();
@@ -695,7 +732,7 @@ int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double 
 // 'N' (mode_trans=0): C[i,j] = sum_s P + (-2 * sum_k f_k B[k,j])            (x=f, y=1: dgemm_compressed_cuda.cu:426-459)
 // 'T' (mode_trans=1): C[s,j] = sum_s P + (-2 * sum_i B[i,j]) * f_s           (x=1, y=f)
 // rows m..ldc-1 of every column are zero-filled like the reference CPU path does (5codesIntern.h:67).
-__global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, long m_pad, int n_pad, int splits, long m, int n,
+__global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, long m_pad, long p_rows, int n_pad, int splits, long m, int n,
                                                 double *__restrict__ Cout, long ldc, int mode_trans, int centered,
                                                 const double *__restrict__ sumB, const double *__restrict__ sumfB,
                                                 const double *__restrict__ f, const int *__restrict__ E, int back) {
@@ -704,7 +741,8 @@ __global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, lo
   if (r >= ldc) return;
   double v = 0.0;
   if (r < m) {
-    for (int s = 0; s < splits; s++) v += P[((size_t)s * n_pad + j) * m_pad + r];
+    const size_t tile = (size_t)(r / p_rows), within = (size_t)(r % p_rows), ntiles = (size_t)(m_pad / p_rows);
+    for (int s = 0; s < splits; s++) v += P[(((size_t)s * ntiles + tile) * n_pad + j) * p_rows + within];
     if (E) v = ldexp(v, back + E[j]);          // undo the operand scaling of the denormal-operand mode (exact)
     if (centered) {
       if (mode_trans) v = fma(-2.0 * sumB[j], f[r], v);
@@ -717,7 +755,7 @@ __global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, lo
 int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC, long ldc, int mode_trans, bool centered,
                   const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s, const int *d_E) {
   dim3 grid((unsigned)((ldc + 255) / 256), n);
-  hipLaunchKernelGGL(k_finish, grid, dim3(256), 0, s, dP, p.m_pad, p.n_pad, p.splits, m, n, dC, ldc, mode_trans, centered ? 1 : 0,
+  hipLaunchKernelGGL(k_finish, grid, dim3(256), 0, s, dP, p.m_pad, p.p_rows, p.n_pad, p.splits, m, n, dC, ldc, mode_trans, centered ? 1 : 0,
                      d_sumB, d_sumfB, d_f, d_E, 1074 - kDenUp);
   MXA_HIP(hipGetLastError());
   return 0;
