@@ -143,10 +143,11 @@ int mxa_grm(const unsigned char *plink_transposed, int snps, int indiv, double *
 int mxa_ld(const unsigned char *plink, int snps, int indiv, double *R, int is_plink_format, const double *allele_freq);
 
 /* multiply engine of dgemm_compressed (process-wide).  0 (default): fp64 on v_mfma_f64_4x4x4_4b_f64, the arithmetic of the
- * reference (fp64 FMAs).  1 (opt-in, also MXA_ENGINE=i8 in the environment): each column of B is split exactly into 7 radix-256
- * digits relative to the column's largest entry, the digit matrices are multiplied with the 0/1/2 genotypes on the int8
- * matrix cores with exact int32 accumulation, and the 7 integer results are recombined in fp64.  B is thereby represented to
- * 2^-57 of each column's largest |entry| (fixed point per column, not per element); results agree with engine 0 to ~1e-14 of
+ * reference (fp64 FMAs).  1 (opt-in, also MXA_ENGINE=i8 in the environment): each column of B is split exactly into 7 balanced
+ * radix-256 digits relative to the column's largest entry (32 / 16 digits for n = 1 / 2, where they are free), the digit
+ * matrices are multiplied with the 0/1/2 genotypes on the int8 matrix cores with exact int32 accumulation, and the integer
+ * results are recombined in fp64.  B is thereby represented to 2^-54 of each column's largest |entry| (fixed point per column,
+ * not per element); results agree with engine 0 to ~1e-14 of
  * each result column's largest entry on the test problems, at ~4x the throughput.  mxa_set_engine returns the previous value
  * (an invalid argument leaves the engine unchanged). */
 int mxa_set_engine(int engine);

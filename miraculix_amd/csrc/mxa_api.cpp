@@ -152,7 +152,7 @@ static void destroy_handle(Handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void *ptrs[] = {h->snp_major.d, h->ind_major.d, h->snp_major.d_rowsum, h->ind_major.d_rowsum, h->d_f, h->ws.d_Bstage, h->ws.d_Cstage, h->ws.d_Bp, h->ws.d_P, h->ws.d_colpart, h->ws.d_i8, h->ws.d_tmp, h->ws.d_exp};
+  void *ptrs[] = {h->snp_major.d, h->ind_major.d, h->d_f, h->ws.d_Bstage, h->ws.d_Cstage, h->ws.d_Bp, h->ws.d_P, h->ws.d_colpart, h->ws.d_i8, h->ws.d_tmp, h->ws.d_exp};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -249,7 +249,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     const bool prof8 = g_profile_on && timing;
     if (prof8 && !h->ev0) { MXA_HIP(hipEventCreate(&h->ev0)); MXA_HIP(hipEventCreate(&h->ev1)); }
     int splits8 = 1;
-    if (gemm_i8_device(trans ? h->snp_major : h->ind_major, trans, n, dB, ldb, dC, ldc, centered, d_sumB, d_sumfB, h->d_f, w, s, prof8 ? h->ev0 : nullptr, prof8 ? h->ev1 : nullptr, &splits8)) return 1;
+    if (gemm_i8_device(G, trans, n, dB, ldb, dC, ldc, centered, d_sumB, d_sumfB, h->d_f, w, s, prof8 ? h->ev0 : nullptr, prof8 ? h->ev1 : nullptr, &splits8)) return 1;
     geo.splits = splits8; geo.a = 0; geo.c = 0;
     if (prof8) {
       MXA_HIP(hipEventSynchronize(h->ev1));

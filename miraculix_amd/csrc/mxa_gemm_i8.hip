@@ -2,16 +2,18 @@
 //
 // Not the shipped default: the default path computes in fp64 on v_mfma_f64_4x4x4_4b_f64 (mxa_kernels.hip), as the reference
 // does in fp64 FMAs.  This engine exploits that the genotype operand is an exact small integer (0,1,2).  Per column j, with E_j
-// such that |b_kj| * 2^-E_j < 1/2, B is written in radix 256 (two's-complement style: first digit signed, the others unsigned):
-//   b_kj * 2^-E_j = t_0/2^8 + sum_{1<=s<S} u_s/2^(8(s+1)) + r,   t_0 in [-128,127], u_s in [0,255], |r| <= 2^(-8S-1)
-// every step exact in fp64 (the last digit is rounded to nearest).  The unsigned digits are stored as int8 t_s = u_s - 128, so
-//   (Z B)_ij = 2^E_j * [ I_0/2^8 + sum_{s>=1} (I_s + 128 * rowsum_i) / 2^(8(s+1)) ],   I_s = sum_k z_ik t_s(k,j)
-// where the I_s are exact int32 dot products on the int8 MFMA and rowsum_i = sum_k z_ik is computed once per packed matrix (the
-// "Ozaki" error-free splitting of one operand; Z needs no splitting).  With S = 7 digits B is represented to 2^-57 of 2^E_j;
-// all integer sums are exact, only the final S-term fp64 combination rounds.  Error bound per output: K * 2 * 2^(E_j - 57), i.e.
-// <= 1.6e-11 * max_k|b_kj| at K = 1M in the worst case (all residuals aligned), ~7e-15 typical -- at or below the rounding error
-// of an fp64 dot product of that length, but it is a column-wise fixed-point representation, not element-wise fp64, so it stays
-// opt-in and is never what bench.py reports.
+// such that |b_kj| * 2^-E_j < 1/4, B is written in balanced radix 256:
+//   b_kj * 2^-E_j = sum_{s<S} t_s / 2^(8(s+1)) + r,   t_s in [-128, 127],  |r| <= 0.502 * 2^(-8S)
+// (computed exactly in integer arithmetic from the mantissa: sign-extended low byte, subtract, shift -- the digit set has no
+// redundancy, so floating-point digit extraction would have to decide ties at the edge of the remainder range exactly).  Then
+//   (Z B)_ij = sum_s 2^(E_j - 8(s+1)) * I_s,   I_s = sum_k z_ik t_s(k,j)     (exact int32 dot products on the int8 MFMA)
+// -- the "Ozaki" error-free splitting of one operand; Z needs no splitting.  Entries far below the column maximum simply have
+// zero leading digits, so nothing cancels in the recombination.  With S = 7 digits B is represented to 2^-54 of each column's
+// largest entry; all integer sums are exact, only the final S-term fp64 combination rounds.  Error bound per output:
+// 2 K * 2^(E_j - 57): at or below the rounding error of an fp64 dot product of that length for K = 1M, but it is a column-wise
+// fixed-point representation, not element-wise fp64, so the engine stays opt-in and is never what bench.py reports.  For
+// n <= 4 the kernel is HBM-bound with a single tile of 32 expanded columns, so the digits that fit the tile are free: n = 1 uses
+// 32 digits (256 bits -- entries 60 decades below the column maximum still keep their whole mantissa), n = 2 uses 16.
 //
 // Kernel: one workgroup (4 waves, one per SIMD) per 256-row tile of the packed matrix and K range; wave tile 64 rows x
 // (NT x 32) expanded columns (column e = slice * nc + j); accumulators NT x 2 tiles of v_mfma_i32_32x32x32_i8 (<= 256 AGPRs).
@@ -41,25 +43,40 @@ __device__ __forceinline__ v4i iunpack16(uint32_t w) {
   return r;
 }
 
-// ---- row sums of the packed matrix (tiled layout): rowsum[r] = sum_k z_rk.  One thread per row, 32 bytes per slab; the 256 rows of
-// a tile read one contiguous 8 KiB run per slab.
-__global__ void __launch_bounds__(256) k_rowsum(const uint8_t *__restrict__ G, long nslabs, int *__restrict__ rowsum) {
-  const long rb = blockIdx.x;
-  const uint4 *p = reinterpret_cast<const uint4 *>(G + (size_t)rb * nslabs * kTileBytes) + 2 * threadIdx.x;
-  int acc = 0;
-  for (long sl = 0; sl < nslabs; sl++) {
-    const uint4 a = p[sl * (kTileBytes / 16)], b = p[sl * (kTileBytes / 16) + 1];
-    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int i = 0; i < 8; i++) acc += __popc(w[i] & 0x55555555u) + 2 * __popc(w[i] & 0xaaaaaaaau);
-  }
-  rowsum[rb * kTileRows + threadIdx.x] = acc;
-}
-
 // ---- slices in MFMA fragment order.  Bs[chunk][T][nt][lane][16]: T = K-step of 32 genotypes, nt = 32-wide tile of expanded
 // columns e = s * nc + jj (slice s, column jj of the chunk), lane = (col = lane&31, h = lane>>5), byte 4q+i of the lane =
 // digit of B[128(T/4) + 64h + 16(T%4) + 4i + q][chunk*nc + jj]: a lane of half h reads the 16 bytes (64 genotypes) 16h.. of its row
 // per 128-genotype stage and uses dword T%4 of them in K-step T%4; iunpack16 puts field 4i+q of that dword into byte i of register q.
+// Balanced radix-256 digits of one double, exactly, in integer arithmetic.  b = +-m * 2^ex (m < 2^53 an integer).  In units of the
+// last digit, 2^(E - 8S), the value is N = m * 2^p, p = ex - E + 8S: for p >= 0 the low p/8 digits are zero and the rest come from
+// m << (p % 8); for p < 0 the bits below the last digit are rounded off (to nearest).  At most 9 digits are non-zero: they are packed
+// into c[0..8] (least significant first) with d = sign-extended low byte, M = (M - d) >> 8 -- digits in [-128, 127], exact.
+struct Digits9 { unsigned long long lo; unsigned int hi; int low_digits; };   // c[0..7] in lo, c[8] in hi; first digit position
+__device__ __forceinline__ Digits9 balanced_digits(double b, int E, int S) {
+  Digits9 d{0ull, 0u, 0};
+  const long long bits = __double_as_longlong(b);
+  const int ef = (int)((bits >> 52) & 0x7ff);
+  long long m = bits & 0xfffffffffffffll;
+  if (ef == 0x7ff || (ef == 0 && m == 0)) return d;            // non-finite columns are flagged separately; zero has no digits
+  int ex;
+  if (ef) { m |= 1ll << 52; ex = ef - 1075; } else ex = -1074;  // denormal input: no hidden bit
+  const int p = ex - E + 8 * S;
+  long long M;
+  if (p >= 0) { d.low_digits = p >> 3; M = m << (p & 7); }
+  else if (p <= -54) return d;                                  // entirely below the last digit
+  else { const int sh = -p; M = (m + (1ll << (sh - 1))) >> sh; }
+  if (bits < 0) M = -M;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { const long long c = (long long)(signed char)(M & 0xff); d.lo |= (unsigned long long)(c & 0xff) << (8 * i); M = (M - c) >> 8; }
+  d.hi = (unsigned int)(M & 0xff);                              // |M| <= 1 here: the last carry
+  return d;
+}
+__device__ __forceinline__ unsigned int digit_of(const Digits9 &d, int S, int s) {   // digit of slice s (weight 2^(E - 8(s+1))) as a byte
+  const int i = (S - 1 - s) - d.low_digits;
+  if (i < 0 || i > 8) return 0u;
+  return i < 8 ? (unsigned int)(d.lo >> (8 * i)) & 0xffu : d.hi;
+}
+
 __global__ void __launch_bounds__(256) k_slice_B(const double *__restrict__ B, long ldb, long k, int n, const int *__restrict__ E, int S, int nc, int NT,
                                                  long T_total, int ncols, uint32_t *__restrict__ Bs, long total) {
   // one thread per (q, column cj = chunk*nc + jj, h, T): reads the 4 values k = 128(T/4) + 64h + 16(T%4) + 4i + q (i = 0..3), writes dword q of
@@ -72,22 +89,16 @@ __global__ void __launch_bounds__(256) k_slice_B(const double *__restrict__ B, l
     const int h = (int)(hT & 1);
     const long T = hT >> 1;
     const int chunk = cj / nc, jj = cj % nc;
-    double r[4];
+    Digits9 d[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const long kk = 128 * (T >> 2) + 64 * h + 16 * (T & 3) + 4 * i + q;   // K order of the A operand: see k_gemm_i8
-      r[i] = (kk < k && cj < n) ? ldexp(B[kk + (long)cj * ldb], -E[cj]) : 0.0;     // |r| < 1/2, exact scaling
+      d[i] = (kk < k && cj < n) ? balanced_digits(B[kk + (long)cj * ldb], E[cj], S) : Digits9{0ull, 0u, 0};
     }
     for (int s = 0; s < S; s++) {
       uint32_t w = 0;
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const double v = r[i] * 256.0;            // exact; first digit: v in (-128, 128), later digits: v in [0, 256)
-        double t = s + 1 < S ? floor(v) : fmin(floor(v + 0.5), s == 0 ? 127.0 : 255.0);   // last digit rounds to nearest
-        r[i] = v - t;                             // exact, in [0, 1)
-        if (s > 0) t -= 128.0;                    // unsigned digit stored with offset: the kernel multiplies signed int8
-        w |= ((uint32_t)(int)t & 0xffu) << (8 * i);
-      }
+      for (int i = 0; i < 4; i++) w |= digit_of(d[i], S, s) << (8 * i);
       const int e = s * nc + jj;
       const int nt = e >> 5, col = e & 31;
       Bs[((((size_t)chunk * T_total + T) * NT + nt) * 64 + (size_t)(h * 32 + col)) * 4 + q] = w;
@@ -261,7 +272,7 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
 // Block = 32 rows x one chunk of columns; P is read with the expanded column running along the lanes, the result is
 // transposed through LDS so that C is written with the row running along the lanes.
 __global__ void __launch_bounds__(256) k_finish_i8(const int *__restrict__ P, long m_pad, int e_pad, int splits, long m, int n, int S, int nc, int NT,
-                                                   const int *__restrict__ E, const int *__restrict__ rowsum, double *__restrict__ Cout, long ldc,
+                                                   const int *__restrict__ E, const double *__restrict__ colmax_part, double *__restrict__ Cout, long ldc,
                                                    int mode_trans, int centered, const double *__restrict__ sumB, const double *__restrict__ sumfB,
                                                    const double *__restrict__ f) {
   __shared__ double sh[32][33];
@@ -275,10 +286,13 @@ __global__ void __launch_bounds__(256) k_finish_i8(const int *__restrict__ P, lo
       double v = 0.0;
       if (r < m && jj < nc && j < n) {
         const int Ej = E[j];
-        const long long off = 128LL * rowsum[r];    // the unsigned digits were stored minus 128
+        double cm = 0.0;                              // a column holding an inf or a NaN gives a NaN column, like 0 * inf in fp64
+        for (int c = 0; c < 64; c++) cm = fmax(cm, colmax_part[(size_t)j * 64 + c]);
+        if (!(cm <= 1.7976931348623157e308)) v = __longlong_as_double(0x7ff8000000000000ll);
+        else
         for (int s = S - 1; s >= 0; s--) {
           const int e = chunk * (NT * 32) + s * nc + jj;
-          long long t = s > 0 ? off : 0;
+          long long t = 0;
           for (int sp = 0; sp < splits; sp++) t += P[((size_t)sp * m_pad + r) * e_pad + e];
           v += ldexp((double)t, Ej - 8 * (s + 1));
         }
@@ -305,7 +319,12 @@ struct I8Plan { int S, nc, nchunks, NT, e_pad, rowblocks, stages_total, stages_p
 
 static I8Plan plan_i8(long m, long k_pad, int n) {
   I8Plan p{};
-  static const int S = [] { const char *e = getenv("MXA_I8_SLICES"); int s = e ? atoi(e) : 7; return std::min(8, std::max(3, s)); }();   // 8 bits per digit
+  static const int S_env = [] { const char *e = getenv("MXA_I8_SLICES"); return e ? std::min(32, std::max(3, atoi(e))) : 0; }();
+  int S = S_env ? S_env : 7;                                     // 8 bits per digit: 7 digits = 56 bits below 2^E_j
+  // a tile of 32 expanded columns is the unit of work: for n <= 4 the kernel is HBM-bound with one tile, so the digits that fit the
+  // tile are free -- n = 1: 32 digits (256 bits: any entry down to 2^-200 of the column maximum keeps its whole mantissa), n = 2: 16
+  if (!S_env && n * S <= 32) S = std::min(32, 32 / n);
+  if (n * S > 32 && S > 8) S = 8;
   p.S = S;
   const int max_nc = std::min(32, 256 / S);                     // <= 8 tiles of 32 expanded columns per pass; k_finish_i8 handles <= 32 columns per chunk
   p.nchunks = (n + max_nc - 1) / max_nc;
@@ -361,17 +380,12 @@ static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const 
 
 // Whole product on the device; B, C device pointers; asynchronous on s.  The workspace (exponents, slices, partials) lives with the
 // handle and only grows.
-int gemm_i8_device(PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, bool centered, const double *d_sumB,
+int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, bool centered, const double *d_sumB,
                    const double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out) {
   const long m = G.rows, k = G.k;
   const I8Plan p = plan_i8(m, G.k_pad, n);
   if (p.m_pad > G.rows_pad) { set_error(4, "internal: packed matrix smaller than the i8 plan"); return 1; }
   if (splits_out) *splits_out = p.splits;
-  if (!G.d_rowsum) {   // once per packed matrix
-    MXA_HIP(hipMalloc(reinterpret_cast<void **>(&G.d_rowsum), sizeof(int) * (size_t)G.rows_pad));
-    hipLaunchKernelGGL(k_rowsum, dim3((unsigned)(G.rows_pad / kTileRows)), dim3(256), 0, s, G.d, G.nslabs, G.d_rowsum);
-    MXA_HIP(hipGetLastError());
-  }
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
   const size_t part_bytes = up(sizeof(double) * 64 * n), e_bytes = up(sizeof(int) * n);
   const size_t bs_bytes = up((size_t)p.nchunks * p.T_total * p.NT * 1024);
@@ -389,7 +403,7 @@ int gemm_i8_device(PackedMatrix &G, bool trans, int n, const double *dB, long ld
   int8_t *d_Bs = reinterpret_cast<int8_t *>(base + part_bytes + e_bytes);
   int *d_P = reinterpret_cast<int *>(base + part_bytes + e_bytes + bs_bytes);
 
-  if (launch_colexp(dB, ldb, k, n, d_part, d_E, 1, s)) return 1;   // E_j = e + 1: |b| * 2^-E_j < 1/2, the signed first digit fits [-128, 127]
+  if (launch_colexp(dB, ldb, k, n, d_part, d_E, 2, s)) return 1;   // E_j = e + 2: |b| * 2^-E_j < 1/4, inside the remainder range of the balanced digits
   if (p.NT * 32 != p.nc * p.S) MXA_HIP(hipMemsetAsync(d_Bs, 0, bs_bytes, s));   // expanded columns beyond nc*S are never written
   {
     const int ncols = p.nchunks * p.nc;
@@ -414,7 +428,7 @@ int gemm_i8_device(PackedMatrix &G, bool trans, int n, const double *dB, long ld
   if (ev1) MXA_HIP(hipEventRecord(ev1, s));
   {
     dim3 grid((unsigned)((ldc + 31) / 32), p.nchunks);
-    hipLaunchKernelGGL(k_finish_i8, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, G.d_rowsum, dC, ldc, trans ? 1 : 0,
+    hipLaunchKernelGGL(k_finish_i8, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, d_part, dC, ldc, trans ? 1 : 0,
                        centered ? 1 : 0, d_sumB, d_sumfB, d_f);
   }
   MXA_HIP(hipGetLastError());

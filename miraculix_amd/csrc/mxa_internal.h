@@ -38,7 +38,6 @@ struct PackedMatrix {
   long rows_pad = 0, k_pad = 0;
   size_t pitch = 0;
   long nslabs = 0;
-  int *d_rowsum = nullptr;   // sum of the genotypes of each row (rows_pad ints); filled on first use by the int8 engine
 };
 
 struct Workspace {
@@ -116,7 +115,7 @@ int launch_sparse_times_plink(const uint8_t *dP, size_t pitch, long entries, int
                               double *dC_slab, long ldc, long e_base, long e_count, hipStream_t s);
 // opt-in engine (mxa_set_engine(1) / MXA_ENGINE=i8, mxa_gemm_i8.hip): whole product by exact int8 slicing of B.
 // Asynchronous on s; ev0/ev1 (optional) are recorded around the dominant kernel.
-int gemm_i8_device(PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, bool centered, const double *d_sumB,
+int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, bool centered, const double *d_sumB,
                    const double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out);
 
 }  // namespace mxa

@@ -108,7 +108,10 @@ __global__ void __launch_bounds__(256) k_colmax_partial(const double *__restrict
   const long per = (k + 63) / 64;
   const long c0 = c * per, c1 = std::min<long>(k, c0 + per);
   double m = 0.0;
-  for (long r = c0 + threadIdx.x; r < c1; r += 256) m = fmax(m, fabs(B[r + (long)j * ldb]));
+  for (long r = c0 + threadIdx.x; r < c1; r += 256) {
+    const double a = fabs(B[r + (long)j * ldb]);
+    m = (a <= 1.7976931348623157e308) ? fmax(m, a) : __longlong_as_double(0x7ff0000000000000ll);   // NaN counts as non-finite too (fmax would drop it)
+  }
   __shared__ double sh[256];
   sh[threadIdx.x] = m;
   __syncthreads();

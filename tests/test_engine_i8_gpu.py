@@ -78,3 +78,59 @@ def test_i8_engine_integer_B_is_exact(dg):
         assert np.array_equal(C, ref.astype(np.float64))
     finally:
         dg.free_compressed(obj)
+
+
+def test_i8_engine_small_n_uses_the_free_digits(dg):
+    """n = 1, 2: one tile of 32 expanded columns is the unit of work, so 32 / 16 radix-256 digits are used at no cost.  A column
+    that mixes entries 1e+18 and 1e-18 (n = 2: 1e+8 and 1e-8) must then come out as accurately as a column of O(1) entries: rows whose genotypes are 0 at
+    the large entries still get their (tiny) result to full relative precision."""
+    o = Oracle()
+    snps, indiv = 4001, 600
+    prob = make_problem(snps, indiv, 1, seed=21)
+    Z = prob["Z"]
+    dg.set_options(use_gpu=True, not_center=True, verbose=0)
+    obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], 2)
+    try:
+        rng = np.random.default_rng(8)
+        for n in (1, 2):
+            B = rng.standard_normal((n, snps))
+            big = np.zeros(snps, bool); big[[0, 1500, 3000]] = True
+            scale = 1e18 if n == 1 else 1e8      # 32 digits cover 36 decades with full mantissas, 16 digits cover 16
+            B[:, big] *= scale
+            B[:, ~big] /= scale
+            C = dg.dgemm_compressed_main(False, obj, np.asfortranarray(B.T), snps, indiv)          # indiv x n
+            # exact reference in two scales: the part from the big entries and the part from the small ones, each in long double
+            Zl = Z.astype(np.longdouble)
+            ref_big = (Zl[:, big] @ B[:, big].T.astype(np.longdouble))
+            ref_small = (Zl[:, ~big] @ B[:, ~big].T.astype(np.longdouble))
+            rows_without_big = np.abs(Z[:, big]).sum(axis=1) == 0
+            assert rows_without_big.any()
+            got = C.astype(np.longdouble)
+            # rows that never touch a big entry: the result is ~1e-17 and must be right to ~1e-13 relative, not lost below 1e+18 * 2^-57
+            sel = rows_without_big
+            rel = np.abs(got[sel] - ref_small[sel]).max() / np.abs(ref_small[sel]).max()
+            assert rel < 1e-13, (n, float(rel))
+            tot = ref_big + ref_small
+            assert np.abs(got - tot).max() <= 1e-13 * np.abs(tot).max()
+    finally:
+        dg.free_compressed(obj)
+
+
+def test_i8_engine_negative_entries_far_below_the_column_maximum(dg):
+    """Regression: digits are extracted in integer arithmetic.  (A floating-point extraction in two's-complement style rounded
+    -1e-36 + 1 to 1.0 and overflowed the next digit for negative entries more than 2^53 below the column maximum.)"""
+    o = Oracle()
+    snps, indiv, n = 3000, 500, 8
+    prob = make_problem(snps, indiv, n, seed=31)
+    dg.set_options(use_gpu=True, not_center=True, verbose=0)
+    obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], n)
+    try:
+        B = make_B(snps, n, seed=5)
+        B[:, 10:] *= 1e-20            # every column: ten O(1) entries, the rest +-1e-20
+        B[3, :] *= 1e25
+        ref = o.dgemm_dense(0, prob, B, 0)[:, :indiv]
+        C = dg.dgemm_compressed_main(False, obj, np.asfortranarray(B.T), snps, indiv)
+        err = (np.abs(C.T - ref).max(axis=1) / np.abs(ref).max(axis=1)).max()
+        assert err <= 1e-13, err
+    finally:
+        dg.free_compressed(obj)
