@@ -276,8 +276,17 @@ __global__ void __launch_bounds__(256) k_finish_i8(const int *__restrict__ P, lo
                                                    int mode_trans, int centered, const double *__restrict__ sumB, const double *__restrict__ sumfB,
                                                    const double *__restrict__ f) {
   __shared__ double sh[32][33];
+  __shared__ int bad[32];                           // column holds an inf or a NaN: the result column is NaN, like 0 * inf in fp64
   const int chunk = blockIdx.y;
   const long r0 = (long)blockIdx.x * 32;
+  if (threadIdx.x < 32) {
+    const int j = chunk * nc + threadIdx.x;
+    double cm = 0.0;
+    if ((int)threadIdx.x < nc && j < n)
+      for (int c = 0; c < 64; c++) cm = fmax(cm, colmax_part[(size_t)j * 64 + c]);
+    bad[threadIdx.x] = !(cm <= 1.7976931348623157e308);
+  }
+  __syncthreads();
   {
     const int jj = threadIdx.x & 31;
     const int j = chunk * nc + jj;
@@ -286,9 +295,7 @@ __global__ void __launch_bounds__(256) k_finish_i8(const int *__restrict__ P, lo
       double v = 0.0;
       if (r < m && jj < nc && j < n) {
         const int Ej = E[j];
-        double cm = 0.0;                              // a column holding an inf or a NaN gives a NaN column, like 0 * inf in fp64
-        for (int c = 0; c < 64; c++) cm = fmax(cm, colmax_part[(size_t)j * 64 + c]);
-        if (!(cm <= 1.7976931348623157e308)) v = __longlong_as_double(0x7ff8000000000000ll);
+        if (bad[jj]) v = __longlong_as_double(0x7ff8000000000000ll);
         else
         for (int s = S - 1; s >= 0; s--) {
           const int e = chunk * (NT * 32) + s * nc + jj;
