@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--indiv", type=int, default=20_000)
     ap.add_argument("--lam", type=float, default=None, help="ridge term; default = snps (well-conditioned toy system)")
     ap.add_argument("--max-iter", type=int, default=200)
+    ap.add_argument("--engine", choices=["f64", "i8"], default="f64", help="i8: exact radix-256 splitting of the vector on the int8 matrix cores (32 digits at n = 1), HBM-bound")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -62,6 +63,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     L = mx.load_shared_library()
+    mx.dgemm_compressed.set_engine(args.engine)
     b0, e0 = shard_bounds(args.snps, world, rank)
     sl = e0 - b0
     plink = synth_plink_device(torch, sl, (args.indiv + 3) // 4, 42 + rank, dev)
@@ -82,7 +84,7 @@ def main():
     dt = time.perf_counter() - t0
     if rank == 0:
         flops = 2 * 2.0 * args.snps * args.indiv * (it + 1)
-        print(f"CG: {it} iterations, residual {res:.3e}, {dt*1e3:.1f} ms total, {dt/(it+1)*1e3:.3f} ms per G*v, {flops/dt*1e-12:.2f} TFLOP/s effective (n=1)")
+        print(f"CG: {it} iterations, residual {res:.3e}, {dt*1e3:.1f} ms total, {dt/(it+1)*1e3:.3f} ms per G*v, {flops/dt*1e-12:.2f} TFLOP/s effective (n=1, engine {args.engine})")
     eng.close()
     if world > 1:
         dist.destroy_process_group()

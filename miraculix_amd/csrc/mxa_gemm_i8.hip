@@ -269,13 +269,14 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
 }
 
 // ---- finish: sum the splits exactly (int64), combine the slices smallest scale first, centring, ldc store.
-// Block = 32 rows x one chunk of columns; P is read with the expanded column running along the lanes, the result is
-// transposed through LDS so that C is written with the row running along the lanes.
+// Block = 32 rows x one chunk of columns; P is read with the expanded column running along the lanes (one lane per integer sum),
+// the result is transposed through LDS so that C is written with the row running along the lanes.
 __global__ void __launch_bounds__(256) k_finish_i8(const int *__restrict__ P, long m_pad, int e_pad, int splits, long m, int n, int S, int nc, int NT,
                                                    const int *__restrict__ E, const double *__restrict__ colmax_part, double *__restrict__ Cout, long ldc,
                                                    int mode_trans, int centered, const double *__restrict__ sumB, const double *__restrict__ sumfB,
                                                    const double *__restrict__ f) {
   __shared__ double sh[32][33];
+  __shared__ double contrib[8][8 * 32 + 1];        // scaled terms of 8 rows x all expanded columns of the chunk
   __shared__ int bad[32];                           // column holds an inf or a NaN: the result column is NaN, like 0 * inf in fp64
   const int chunk = blockIdx.y;
   const long r0 = (long)blockIdx.x * 32;
@@ -287,9 +288,9 @@ __global__ void __launch_bounds__(256) k_finish_i8(const int *__restrict__ P, lo
     bad[threadIdx.x] = !(cm <= 1.7976931348623157e308);
   }
   __syncthreads();
-  {
-    const int jj = threadIdx.x & 31;
-    const int j = chunk * nc + jj;
+  if (nc >= 16) {
+    // wide chunks: lane jj walks its column's slices itself (the lanes of a row already cover a 64..128-byte run of P)
+    const int jj = threadIdx.x & 31, j = chunk * nc + jj;
     for (int rr = threadIdx.x >> 5; rr < 32; rr += 8) {
       const long r = r0 + rr;
       double v = 0.0;
@@ -297,12 +298,11 @@ __global__ void __launch_bounds__(256) k_finish_i8(const int *__restrict__ P, lo
         const int Ej = E[j];
         if (bad[jj]) v = __longlong_as_double(0x7ff8000000000000ll);
         else
-        for (int s = S - 1; s >= 0; s--) {
-          const int e = chunk * (NT * 32) + s * nc + jj;
-          long long t = 0;
-          for (int sp = 0; sp < splits; sp++) t += P[((size_t)sp * m_pad + r) * e_pad + e];
-          v += ldexp((double)t, Ej - 8 * (s + 1));
-        }
+          for (int s = S - 1; s >= 0; s--) {
+            long long t = 0;
+            for (int sp = 0; sp < splits; sp++) t += P[((size_t)sp * m_pad + r) * e_pad + chunk * (NT * 32) + s * nc + jj];
+            v += ldexp((double)t, Ej - 8 * (s + 1));
+          }
         if (centered) {
           if (mode_trans) v = fma(-2.0 * sumB[j], f[r], v);
           else v += -2.0 * sumfB[j];
@@ -310,8 +310,44 @@ __global__ void __launch_bounds__(256) k_finish_i8(const int *__restrict__ P, lo
       }
       sh[rr][jj] = v;
     }
+    __syncthreads();
+  } else {
+    // 8 rows per pass: lanes run along the expanded column e = s * nc + jj (128-byte runs of P), each lane turns its integer sum into
+    // the scaled fp64 term of (slice s, column jj); then lane jj adds its column's terms, smallest scale first
+    for (int pass = 0; pass < 4; pass++) {
+      const int rr = pass * 8 + (threadIdx.x >> 5);
+      const long r = r0 + rr;
+      for (int nt = 0; nt < NT; nt++) {
+        const int e = nt * 32 + (threadIdx.x & 31);
+        double c = 0.0;
+        if (r < m && e < nc * S) {
+          const int s = e / nc, jj = e - s * nc, j = chunk * nc + jj;
+          if (j < n) {
+            long long t = 0;
+            for (int sp = 0; sp < splits; sp++) t += P[((size_t)sp * m_pad + r) * e_pad + chunk * (NT * 32) + e];
+            c = ldexp((double)t, E[j] - 8 * (s + 1));
+          }
+        }
+        contrib[threadIdx.x >> 5][e] = c;
+      }
+      __syncthreads();
+      {
+        const int jj = threadIdx.x & 31, j = chunk * nc + jj;
+        double v = 0.0;
+        if (r < m && jj < nc && j < n) {
+          if (bad[jj]) v = __longlong_as_double(0x7ff8000000000000ll);
+          else
+            for (int s = S - 1; s >= 0; s--) v += contrib[threadIdx.x >> 5][s * nc + jj];
+          if (centered) {
+            if (mode_trans) v = fma(-2.0 * sumB[j], f[r], v);
+            else v += -2.0 * sumfB[j];
+          }
+        }
+        sh[rr][jj] = v;
+      }
+      __syncthreads();
+    }
   }
-  __syncthreads();
   {
     const int rr = threadIdx.x & 31;
     const long r = r0 + rr;
