@@ -148,8 +148,10 @@ int mxa_ld(const unsigned char *plink, int snps, int indiv, double *R, int is_pl
  * matrices are multiplied with the 0/1/2 genotypes on the int8 matrix cores with exact int32 accumulation, and the integer
  * results are recombined in fp64.  B is thereby represented to 2^-54 of each column's largest |entry| (fixed point per column,
  * not per element); results agree with engine 0 to ~1e-14 of
- * each result column's largest entry on the test problems, at ~4x the throughput.  mxa_set_engine returns the previous value
- * (an invalid argument leaves the engine unchanged). */
+ * each result column's largest entry on the test problems, at ~4x the throughput.
+ * 2 (MXA_ENGINE=small-n-i8): engine 1 for n <= 4 only -- there it is HBM-bound and 32 / 16 / 10 / 8 digits per column fit at no
+ * cost (the CG / GBLUP iteration with n = 1: 2.5 ms instead of 3.6 ms per G*v on a 250k x 100k shard) -- engine 0 otherwise.
+ * mxa_set_engine returns the previous value (an invalid argument leaves the engine unchanged). */
 int mxa_set_engine(int engine);
 int mxa_get_engine(void);
 

@@ -27,7 +27,12 @@ Profile &profile() { static Profile p; return p; }
 Geometry &last_geometry() { static Geometry g; return g; }
 static bool g_profile_on = true;
 // multiply engine: 0 = fp64 MFMA (default), 1 = exact int8 slicing on the int8 MFMA (opt-in; MXA_ENGINE=i8 or mxa_set_engine)
-static std::atomic<int> g_engine{[] { const char *e = getenv("MXA_ENGINE"); return (e && std::string(e) == "i8") ? 1 : 0; }()};
+static std::atomic<int> g_engine{[] {
+  const char *e = getenv("MXA_ENGINE");
+  if (e && std::string(e) == "i8") return 1;
+  if (e && std::string(e) == "small-n-i8") return 2;
+  return 0;
+}()};
 
 int env_print_level() {  // reference: cuda_utils.cu:44-52, env PRINT_LEVEL
   const char *e = getenv("PRINT_LEVEL");
@@ -244,7 +249,8 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c;
   double *d_sumB = w.d_colpart + (size_t)n * 128, *d_sumfB = d_sumB + n;
   static const int mode = [] { const char *e = getenv("MXA_GEMM_MODE"); return e ? atoi(e) : 2; }();
-  if (g_engine.load() == 1) {   // opt-in: exact int8 slicing of B on the int8 matrix cores (mxa_gemm_i8.hip)
+  const int engine = g_engine.load();
+  if (engine == 1 || (engine == 2 && n <= 4)) {   // opt-in: exact int8 slicing of B on the int8 matrix cores (mxa_gemm_i8.hip)
     if (centered && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
     const bool prof8 = g_profile_on && timing;
     if (prof8 && !h->ev0) { MXA_HIP(hipEventCreate(&h->ev0)); MXA_HIP(hipEventCreate(&h->ev1)); }
@@ -551,7 +557,7 @@ int mxa_device_count(void) {
 }
 
 int mxa_set_engine(int engine) {
-  if (engine != 0 && engine != 1) return g_engine.load();
+  if (engine < 0 || engine > 2) return g_engine.load();
   return g_engine.exchange(engine);
 }
 int mxa_get_engine(void) { return g_engine.load(); }

@@ -16,17 +16,18 @@ def set_options(use_gpu=False, cores=0, not_center=False, variant=0, verbose=1):
     L.setOptions_compressed(int(use_gpu), int(cores), floatLoop, meanSubstract, ignore_missings, int(not_center), normalize, use_miraculix_freq, int(variant), int(verbose))
 
 
-_ENGINES = {"f64": 0, "i8": 1}
+_ENGINES = {"f64": 0, "i8": 1, "small-n-i8": 2}
 
 
 def set_engine(name):
     """Additive (no reference counterpart): 'f64' = fp64 matrix cores (default), 'i8' = exact int8 slicing of B on the int8
-    matrix cores (include/miraculix_amd.h, mxa_set_engine).  Returns the previous engine's name."""
+    matrix cores, 'small-n-i8' = 'i8' for n <= 4 and 'f64' otherwise (include/miraculix_amd.h, mxa_set_engine).  Returns the
+    previous engine's name."""
     L = _lib.check_library_handle()
     if name not in _ENGINES:
-        raise ValueError("engine must be 'f64' or 'i8'")
+        raise ValueError("engine must be 'f64', 'i8' or 'small-n-i8'")
     prev = L.mxa_set_engine(_ENGINES[name])
-    return "i8" if prev == 1 else "f64"
+    return {0: "f64", 1: "i8", 2: "small-n-i8"}[prev]
 
 
 def check_dimensions(plink, snps, indiv):
