@@ -263,13 +263,14 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // Workgroups that share a B slab stream are all row blocks of one (column chunk, K split) group.  Plain order: row block fastest.
-  // XCD-aware order (when the number of groups is a multiple of 8): consecutive blockIdx.x are dealt round-robin to the 8 XCDs, each
-  // with its own L2, so group g is given to XCD g % 8 only -- its B slabs cross the fabric once instead of once per XCD.
+  // XCD-aware order: consecutive blockIdx.x are dealt round-robin to the 8 XCDs, each with its own L2, so group g (of the first
+  // 8 * floor(groups / 8)) is given to XCD g % 8 only -- its B slabs cross the fabric once instead of once per XCD.
   int bid = blockIdx.x;
   const int ngroups = (int)(gridDim.x / rowblocks);
   int rb, grp;
-  if (xcd_order && (ngroups & 7) == 0) { const int xcd = bid & 7, slot = bid >> 3; rb = slot % rowblocks; grp = xcd + 8 * (slot / rowblocks); }
-  else { rb = bid % rowblocks; grp = bid / rowblocks; }
+  const int g8 = ngroups & ~7;                       // groups dealt to XCDs whole; the last ngroups % 8 groups keep the plain order
+  if (xcd_order && bid < g8 * rowblocks) { const int xcd = bid & 7, slot = bid >> 3; rb = slot % rowblocks; grp = xcd + 8 * (slot / rowblocks); }
+  else { const int t = bid - g8 * rowblocks * (xcd_order ? 1 : 0); rb = t % rowblocks; grp = (xcd_order ? g8 : 0) + t / rowblocks; }
   const int nc = grp % nchunks;
   const int sp = grp / nchunks;
   const int slab0 = sp * slabs_per_split;
