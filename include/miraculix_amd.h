@@ -78,6 +78,33 @@ void sparse_times_plink(char *transsparse, char *transcompressed, char *plink, c
  * Returns 0 on success, 1 on failure. */
 int snp_multiply_gpu(unsigned char *snp_matrix, int snps, int indiv, double *ans, bool is_plink_format);
 
+/* ---- solver twin (not on the compressed-genotype hot path) behind the reference's solver exports
+ * src/cuda/solve_cuda.cu:927-951 (prototypes src/cuda/solve_cuda.h:61-88; Julia binding src/bindings/Julia/solve.jl:45-180;
+ * Fortran binding src/bindings/Fortran/modmiraculix_gpu.f90:23-80).  Blocked Cholesky and a synchronisation-free sparse
+ * triangular solve written here; rocBLAS (dlopen()ed on first use) does the Level-3 updates.  All matrices column-major fp64;
+ * pointers may be host or device. */
+
+/* replaces solve_cuda.cu:947-951 -> dense_solve (:70-280): X = A^-1 B by Cholesky (lower triangle of the symmetric positive
+ * definite A, input_size x input_size; B, X input_size x rhs_cols) and, if logdet != NULL, *logdet = log det A = sum 2 log L_ii.
+ * oversubscribe: 1 = the matrix lives in managed memory (hipMallocManaged), 0 = device memory; anything else is an error.
+ * *status = 0 on success, 1 on failure (message on stderr; a matrix that is not positive definite reports the failing minor). */
+void potrs_solve_gpu(double *A, unsigned int input_size, double *B, unsigned int rhs_cols, double *X, double *logdet,
+                     int oversubscribe, int *status);
+/* replaces solve_cuda.cu:927-931: the same, status as the return value */
+int potrs_solve(double *A, unsigned int input_size, double *B, unsigned int rhs_cols, double *X, double *logdet,
+                int oversubscribe);
+
+/* replaces solve_cuda.cu:933-936 -> sparse_solve_init (:281-578): stage a sparse triangular m x m matrix given as ONE-based COO
+ * triplets (V, I, J; 64-bit indices; any order -- they are sorted into CSR here) for solves with exactly `ncol` right-hand
+ * sides; is_lower != 0: lower triangular, else upper.  *GPU_obj receives the object (NULL on failure), *status 0 / 1. */
+void sparse2gpu(double *V, long *I, long *J, long nnz, long m, long ncol, int is_lower, void **GPU_obj, int *status);
+/* replaces solve_cuda.cu:938-941 -> sparse_solve_compute (:709-880): X (m x ncol) = op(A)^-1 B, transA in {N,n}: op(A) = A,
+ * {T,t,f}: op(A) = A^T (as the reference); ncol must equal the value given to sparse2gpu. */
+void dcsrtrsv_solve_gpu(void *GPU_obj, char transA, double *B, long ncol, double *X, int *status);
+/* replaces solve_cuda.cu:943-945 -> sparse_solve_destroy (:580-707): releases the object and sets *GPU_obj = NULL (the Julia
+ * test expects a second free to be caught by its NULL check, tests/solve/test.jl:129). */
+void free_sparse_gpu(void **GPU_obj, int *status);
+
 /* ------------------------------------------------------------------ Part 2: additive entry points */
 
 /* status of the most recent fallible API call of the process: 0 = it succeeded (every such entry clears the status first);

@@ -61,6 +61,16 @@ def load_shared_library():
     L.mxa_gram_matvec.restype = ctypes.c_int
     L.mxa_snp_multiply_panel.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_int]
     L.mxa_snp_multiply_panel.restype = ctypes.c_int
+    L.potrs_solve_gpu.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    L.potrs_solve_gpu.restype = None
+    L.potrs_solve.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    L.potrs_solve.restype = ctypes.c_int
+    L.sparse2gpu.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int)]
+    L.sparse2gpu.restype = None
+    L.dcsrtrsv_solve_gpu.argtypes = [ctypes.c_void_p, ctypes.c_char, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    L.dcsrtrsv_solve_gpu.restype = None
+    L.free_sparse_gpu.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int)]
+    L.free_sparse_gpu.restype = None
     L.mxa_set_engine.argtypes = [ctypes.c_int]
     L.mxa_set_engine.restype = ctypes.c_int
     L.mxa_get_engine.restype = ctypes.c_int
