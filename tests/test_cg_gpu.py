@@ -63,3 +63,11 @@ def test_gram_matvec_matches_two_products_and_oracle():
             assert np.array_equal(Gd.cpu().numpy(), G)
         finally:
             dg.free_compressed(obj)
+
+
+def test_gblup_dense_route_equals_iterative_route():
+    """examples/gblup_small.py: (G + lambda I) a = y through mxa_grm + potrs_solve_gpu equals the CG solve through mxa_gram_matvec --
+    the crossproduct, the post-processing, the solver twin and the fp64 GEMM path tie up."""
+    from gblup_small import run
+    diff, it = run(snps=6000, indiv=700, lam=0.5, verbose=False)
+    assert diff <= 1e-9 and it < 1000
