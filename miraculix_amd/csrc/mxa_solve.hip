@@ -29,7 +29,7 @@ namespace mxa {
 
 // ------------------------------------------------------------------------------------------------ lazy library binding
 static void *open_rocm_lib(const char *name) {
-  void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+  void *h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
   if (h) return h;
   Dl_info info;   // next to the HIP runtime this library is already linked against
   if (dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &info) && info.dli_fname) {
@@ -37,7 +37,7 @@ static void *open_rocm_lib(const char *name) {
     const size_t slash = dir.rfind('/');
     if (slash != std::string::npos) {
       const std::string path = dir.substr(0, slash + 1) + name;
-      h = dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL);
+      h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
     }
   }
   return h;
