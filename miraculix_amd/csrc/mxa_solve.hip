@@ -7,8 +7,9 @@
 // initialised (the normal case: plink2compressed has run) takes 130 s to > 4 min (their thousands of code objects are loaded
 // eagerly), while librocblas.so takes 2.4 s.  So only rocBLAS is used (dlopen()ed on first use: libmiraculix_amd.so itself
 // carries no dependency on it), for the Level-3 updates, and the rest is written here:
-//   dense   blocked right-looking Cholesky: k_potrf_block (64 x 64 diagonal block in LDS) + rocblas_dtrsm / rocblas_dsyrk per
-//           block column; the two triangular solves by rocblas_dtrsm; k_logdet (the reference's trace_kernel, :884-909)
+//   dense   two-level blocked right-looking Cholesky: k_potrf_block (64 x 64 diagonal block in LDS) + rocblas_dtrsm / rocblas_dgemm
+//           inside a 512-column panel, one rocblas_dsyrk per panel; the two triangular solves by rocblas_dtrsm; k_logdet (the
+//           reference's trace_kernel, :884-909)
 //   sparse  k_sptrsm: synchronisation-free triangular solve, one wave per row, rows in dependency order, a flag per row
 //           (host side: COO -> sorted CSR of A and of A^T, diagonal check)
 #include "../../include/miraculix_amd.h"
@@ -19,6 +20,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
@@ -50,12 +52,13 @@ struct BlasLib {
   decltype(&::rocblas_destroy_handle) rocblas_destroy_handle = nullptr;
   decltype(&::rocblas_dtrsm) rocblas_dtrsm = nullptr;
   decltype(&::rocblas_dsyrk) rocblas_dsyrk = nullptr;
+  decltype(&::rocblas_dgemm) rocblas_dgemm = nullptr;
   bool ok = false;
   bool load() {
     if (ok) return true;
     void *blas = open_rocm_lib("librocblas.so");
     if (!blas) { set_error(20, "potrs_solve_gpu: cannot load rocBLAS (%s)", dlerror()); return false; }
-    MXA_SYM(blas, rocblas_create_handle) MXA_SYM(blas, rocblas_destroy_handle) MXA_SYM(blas, rocblas_dtrsm) MXA_SYM(blas, rocblas_dsyrk)
+    MXA_SYM(blas, rocblas_create_handle) MXA_SYM(blas, rocblas_destroy_handle) MXA_SYM(blas, rocblas_dtrsm) MXA_SYM(blas, rocblas_dsyrk) MXA_SYM(blas, rocblas_dgemm)
     return ok = true;
   }
 };
@@ -77,7 +80,8 @@ static int solve_select_device(const char *who) {
 }
 
 // ------------------------------------------------------------------------------------------------ dense: Cholesky solve + logdet
-constexpr int kPotrfNB = 64;
+constexpr int kPotrfNB = 64;        // diagonal block factored in LDS
+constexpr int kPotrfPanel = 512;    // columns per outer panel
 
 // Cholesky of one NB x NB diagonal block (lower triangle, column-major, ld) in LDS, right-looking, one workgroup.
 // *info = (1-based global index of the first non-positive pivot) if the block is not positive definite, untouched otherwise.
@@ -142,6 +146,10 @@ static int dense_solve_impl(const double *A, unsigned int input_size, const doub
   MXA_HIP(hipMemset(dInfo.p, 0, sizeof(int)));
   MXA_HIP(hipMemcpy(dA.p, A, sizeof(double) * n * n, solve_is_device_ptr(A) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
   MXA_HIP(hipMemcpy(dB.p, B, sizeof(double) * n * nrhs, solve_is_device_ptr(B) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  const auto tick = [] { (void)hipDeviceSynchronize(); return std::chrono::steady_clock::now(); };
+  const auto secs = [](std::chrono::steady_clock::time_point a0, std::chrono::steady_clock::time_point a1) { return std::chrono::duration<double>(a1 - a0).count(); };
+  const bool verbose = env_print_level() > 0;   // timings like the reference's debug_info lines (solve_cuda.cu:157-259)
+  auto t_start = verbose ? tick() : std::chrono::steady_clock::time_point();
   rocblas_handle h = nullptr;
   if (L.rocblas_create_handle(&h) != rocblas_status_success) { set_error(21, "potrs_solve_gpu: rocblas_create_handle failed"); return 1; }
   double *a = static_cast<double *>(dA.p), *b = static_cast<double *>(dB.p);
@@ -150,19 +158,31 @@ static int dense_solve_impl(const double *A, unsigned int input_size, const doub
   int rc = 0;
   do {
     // lower triangle of the column-major image, as the reference (CUBLAS_FILL_MODE_LOWER, solve_cuda.cu:84); A is symmetric.
-    // Right-looking: factor the diagonal block, solve the panel below it, update the trailing matrix.
-    for (size_t k = 0; k < n && !rc; k += kPotrfNB) {
-      const int nb = (int)std::min<size_t>(kPotrfNB, n - k);
-      hipLaunchKernelGGL(k_potrf_block, dim3(1), dim3(256), 0, nullptr, a + k + k * n, (long)n, nb, (long)k, static_cast<int *>(dInfo.p));
-      const rocblas_int below = (rocblas_int)(n - k - nb);
-      if (below > 0) {
+    // Two-level right-looking Cholesky.  Outer panels of kPotrfPanel columns; inside a panel, per 64-column step: factor the
+    // diagonal block, solve the block column below it (full height), update only the REST OF THE PANEL with a gemm; after the
+    // panel one syrk with k = kPotrfPanel updates the whole trailing matrix (a syrk per 64 columns re-reads it 8x as often and
+    // is memory-bound).
+    for (size_t K = 0; K < n && !rc; K += kPotrfPanel) {
+      const size_t pw = std::min<size_t>(kPotrfPanel, n - K);          // panel width
+      for (size_t k = K; k < K + pw && !rc; k += kPotrfNB) {
+        const int nb = (int)std::min<size_t>(kPotrfNB, K + pw - k);
+        hipLaunchKernelGGL(k_potrf_block, dim3(1), dim3(256), 0, nullptr, a + k + k * n, (long)n, nb, (long)k, static_cast<int *>(dInfo.p));
+        const rocblas_int below = (rocblas_int)(n - k - nb);           // rows under the diagonal block
+        if (below <= 0) continue;
         if (L.rocblas_dtrsm(h, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, below, nb, &one, a + k + k * n, N,
-                            a + (k + nb) + k * n, N) != rocblas_status_success ||
-            L.rocblas_dsyrk(h, rocblas_fill_lower, rocblas_operation_none, below, nb, &minus_one, a + (k + nb) + k * n, N, &one, a + (k + nb) + (k + nb) * n, N) !=
-                rocblas_status_success) { set_error(21, "potrs_solve_gpu: rocBLAS trsm / syrk failed"); rc = 1; }
+                            a + (k + nb) + k * n, N) != rocblas_status_success) { set_error(21, "potrs_solve_gpu: rocBLAS trsm failed"); rc = 1; break; }
+        const rocblas_int rest = (rocblas_int)(K + pw - k - nb);       // columns of the panel still to the right
+        if (rest > 0 &&
+            L.rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_transpose, below, rest, nb, &minus_one, a + (k + nb) + k * n, N, a + (k + nb) + k * n, N, &one,
+                            a + (k + nb) + (k + nb) * n, N) != rocblas_status_success) { set_error(21, "potrs_solve_gpu: rocBLAS gemm failed"); rc = 1; break; }
       }
+      const rocblas_int trailing = (rocblas_int)(n - K - pw);
+      if (!rc && trailing > 0 &&
+          L.rocblas_dsyrk(h, rocblas_fill_lower, rocblas_operation_none, trailing, (rocblas_int)pw, &minus_one, a + (K + pw) + K * n, N, &one,
+                          a + (K + pw) + (K + pw) * n, N) != rocblas_status_success) { set_error(21, "potrs_solve_gpu: rocBLAS syrk failed"); rc = 1; }
     }
     if (rc) break;
+    if (verbose) { const auto t1 = tick(); debug_info("Time for potrf: %.3fs", secs(t_start, t1)); t_start = t1; }
     int info = 0;
     if (!check_hip(hipMemcpy(&info, dInfo.p, sizeof(int), hipMemcpyDeviceToHost), __func__, __LINE__)) { rc = 1; break; }
     if (info != 0) {   // wording of the reference (solve_cuda.cu:196-199); no device reset here
@@ -173,6 +193,7 @@ static int dense_solve_impl(const double *A, unsigned int input_size, const doub
         L.rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, N, (rocblas_int)nrhs, &one, a, N, b, N) != rocblas_status_success) {
       set_error(21, "potrs_solve_gpu: rocBLAS trsm failed"); rc = 1; break;
     }
+    if (verbose) { const auto t1 = tick(); debug_info("Time for potrs: %.3fs", secs(t_start, t1)); t_start = t1; }
     if (logdet) {
       if (!check_hip(hipMalloc(&dLog.p, sizeof(double)), __func__, __LINE__)) { rc = 1; break; }
       hipLaunchKernelGGL(k_logdet, dim3(1), dim3(1024), 0, nullptr, static_cast<const double *>(dA.p), (long)n, static_cast<double *>(dLog.p));
