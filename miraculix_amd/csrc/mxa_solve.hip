@@ -257,11 +257,12 @@ __global__ void __launch_bounds__(256) k_sptrsm(const int64_t *__restrict__ rowp
   for (int64_t e = o0 + lane; e < o1; e += 64) {
     const int64_t j = col[e];
     long spins = 0;
-    while (__hip_atomic_load(flag + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-      __builtin_amdgcn_s_sleep(2);
+    while (__hip_atomic_load(flag + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {   // relaxed polls: no cache invalidate per poll
+      __builtin_amdgcn_s_sleep(1);
       if (++spins > (1L << 24)) { atomicExch(err, 1); break; }
     }
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                  // one acquire after all the flags were seen
   __builtin_amdgcn_wave_barrier();
   for (long c0 = 0; c0 < ncol; c0 += kSpRhs) {
     double acc[kSpRhs];
@@ -287,9 +288,11 @@ __global__ void __launch_bounds__(256) k_sptrsm(const int64_t *__restrict__ rowp
       __hip_atomic_store(X + r + (c0 + lane) * m, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  __threadfence();
   __builtin_amdgcn_wave_barrier();
-  if (lane == 0) __hip_atomic_store(flag + r, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                // the X stores of the whole wave (same wave: program order) are visible first
+    __hip_atomic_store(flag + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // COO (one-based, any order) -> CSR (zero-based, rows ascending, columns ascending inside a row) of A (t = 0) or A^T (t = 1)
