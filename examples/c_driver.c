@@ -2,6 +2,8 @@
  * '_t' twin) restated as a plain C program against the C ABI: synthetic PLINK data, ncol = 10 ('n') / 15 ('t'),
  * B = -(10 i + j) resp. -(1000 i + j), centred by f, result compared with a dense matmul on the decoded genotypes,
  * failure if any |difference| > 1e-4 (the reference's own acceptance threshold; observed ~1e-10).
+ * Then one call each of the other reference entries: snp_multiply_gpu, sparse_times_plink, potrs_solve_gpu, sparse2gpu /
+ * dcsrtrsv_solve_gpu / free_sparse_gpu, each checked against a loop in this file.
  * Shows that compiled callers only need to link libmiraculix_amd.so:
  *   gcc -O2 -Iinclude examples/c_driver.c -o c_driver -Lmiraculix_amd/lib -lmiraculix_amd -Wl,-rpath,$PWD/miraculix_amd/lib -lm
  */
@@ -61,6 +63,64 @@ int main(int argc, char **argv) {
   }
   free_compressed(&obj);
   if (obj != NULL) { fprintf(stderr, "handle not cleared\n"); bad = 1; }
+
+  /* integer crossproduct (crossproduct.jl:54-58): indiv x indiv, exact */
+  {
+    const int ni = indiv < 300 ? indiv : 300;          /* the first ni individuals */
+    double *M = malloc(sizeof(double) * (size_t)ni * ni);
+    if (snp_multiply_gpu((unsigned char *)plink_t, snps, ni, M, 1) != 0) { fprintf(stderr, "snp_multiply_gpu failed\n"); bad = 1; }
+    long wrong = 0;
+    for (int a = 0; a < ni; a += 7)
+      for (int b = 0; b < ni; b += 5) {
+        long acc = 0;
+        for (int s = 0; s < snps; s++) acc += (long)Z[(size_t)s * indiv + a] * Z[(size_t)s * indiv + b];
+        if (M[(size_t)a * ni + b] != (double)acc) wrong++;
+      }
+    printf("snp_multiply_gpu: %d x %d, mismatches on the sampled entries: %ld\n", ni, ni, wrong);
+    if (wrong) bad = 1;
+    free(M);
+  }
+
+  /* sparse_times_plink (test_sparse_plink.f90:99; zero-based CSR): 2 sparse rows over the SNPs, result 2 x indiv */
+  {
+    int ia[3] = {0, 3, 5}, ja[5] = {0, 2, snps - 1, 1, 3};
+    double a[5] = {0.5, -1.0, 2.0, 1.5, -0.25}, *C = malloc(sizeof(double) * 2 * (size_t)indiv);
+    sparse_times_plink("N", "N", plink, plink_t, snps, indiv, 2, ia, ja, a, C, 2);
+    double maxdiff = 0;
+    for (int i = 0; i < indiv; i++)
+      for (int j = 0; j < 2; j++) {
+        double acc = 0;
+        for (int t = ia[j]; t < ia[j + 1]; t++) acc += a[t] * Z[(size_t)ja[t] * indiv + i];
+        const double d = fabs(acc - C[j + 2 * (size_t)i]);
+        if (d > maxdiff) maxdiff = d;
+      }
+    printf("sparse_times_plink: max |diff| = %.3e\n", maxdiff);
+    if (mxa_last_error() || !(maxdiff <= 1e-12)) bad = 1;
+    free(C);
+  }
+
+  /* solver twin (tests/solve/test.jl): a 3 x 3 Cholesky solve with log-determinant and an upper triangular sparse solve */
+  {
+    double A[9] = {4, 2, 0, 2, 5, 3, 0, 3, 6}, B[3] = {2, 1, 3}, X[3], logdet = 0;
+    int status = 7;
+    potrs_solve_gpu(A, 3, B, 1, X, &logdet, 0, &status);
+    double r = 0;
+    for (int i = 0; i < 3; i++) { double acc = -B[i]; for (int j = 0; j < 3; j++) acc += A[i + 3 * j] * X[j]; if (fabs(acc) > r) r = fabs(acc); }
+    printf("potrs_solve_gpu: status %d, residual %.1e, logdet %.12f (log 60 = %.12f)\n", status, r, logdet, log(60.0));
+    if (status != 0 || r > 1e-13 || fabs(logdet - log(60.0)) > 1e-12) bad = 1;
+    double V[5] = {2, 1, 4, -1, 5}, Xs[3], Bs[3] = {3, 2, 10};      /* U = [2 1 0; 0 4 -1; 0 0 5], one-based COO */
+    long I[5] = {1, 1, 2, 2, 3}, J[5] = {1, 2, 2, 3, 3};
+    void *sp = NULL;
+    sparse2gpu(V, I, J, 5, 3, 1, /*is_lower*/0, &sp, &status);
+    if (status != 0 || !sp) { fprintf(stderr, "sparse2gpu failed\n"); bad = 1; }
+    else {
+      dcsrtrsv_solve_gpu(sp, 'n', Bs, 1, Xs, &status);             /* x = (1, 1, 2) */
+      printf("dcsrtrsv_solve_gpu: status %d, x = (%g, %g, %g)\n", status, Xs[0], Xs[1], Xs[2]);
+      if (status != 0 || fabs(Xs[0] - 1) > 1e-14 || fabs(Xs[1] - 1) > 1e-14 || fabs(Xs[2] - 2) > 1e-14) bad = 1;
+      free_sparse_gpu(&sp, &status);
+      if (sp != NULL || status != 0) bad = 1;
+    }
+  }
   printf(bad ? "FAILED\n" : "c_driver ok\n");
   return bad;
 }
