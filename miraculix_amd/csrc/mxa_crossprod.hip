@@ -93,6 +93,7 @@ k_crossprod2(const uint8_t *__restrict__ X, size_t pitch, int stages, const int4
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wi = wave >> 1, wj = wave & 1;      // wave tile: rows [128*wi, +128) of the I block x rows [128*wj, +128) of the J block
   const int4 t = tiles[blockIdx.x];             // (I tile, J tile, images to store: 1 = M[gj, gi] "direct", 2 = M[gi, gj] "mirror")
+  if (t.z == 0) return;                         // padding entry of the XCD-aware tile order (whole workgroup, before any barrier)
   const long i0 = (long)t.x * kXT, j0 = (long)t.y * kXT;
   const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
   const uint32_t v_lane = (uint32_t)(lane >> 1) * (uint32_t)pitch + (lane & 1) * 16;
@@ -256,6 +257,30 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
       if (flags) tiles.push_back(make_int4(i, j, flags, 0));
     }
   if (tiles.empty()) return 0;
+  // XCD-aware order: consecutive workgroups are dealt round-robin to the 8 XCDs (own L2 each).  In plain i-major order the 32 tiles
+  // an XCD works on at a time share one I block and need 32 different J blocks; here the tiles are grouped into super-tiles of 8 x 8
+  // (one I-range and one J-range of 8 row blocks each), whole super-tiles are dealt to the XCDs, and the lists are interleaved
+  // (list index = 8 * slot + xcd, padded with no-op entries) so that an XCD streams 16 row blocks for 64 tiles.
+  static const bool xcd_tiles = [] { const char *e = getenv("MXA_XPROD_XCD"); return e ? atoi(e) != 0 : true; }();
+  if (xcd_tiles && tiles.size() >= 8 * 64) {
+    std::vector<std::vector<int4>> per_xcd(8);
+    const int nsb = (nb + 7) / 8;
+    std::vector<std::vector<int4>> super((size_t)nsb * nsb);
+    for (const int4 &t : tiles) super[(size_t)(t.x / 8) * nsb + t.y / 8].push_back(t);
+    for (auto &st : super) {   // each super-tile goes to the XCD with the shortest list so far (diagonal super-tiles hold 36 tiles, others 64)
+      if (st.empty()) continue;
+      int best = 0;
+      for (int x = 1; x < 8; x++) if (per_xcd[x].size() < per_xcd[best].size()) best = x;
+      per_xcd[best].insert(per_xcd[best].end(), st.begin(), st.end());
+    }
+    size_t longest = 0;
+    for (auto &v : per_xcd) longest = std::max(longest, v.size());
+    std::vector<int4> inter;
+    inter.reserve(longest * 8);
+    for (size_t slot = 0; slot < longest; slot++)
+      for (int x = 0; x < 8; x++) inter.push_back(slot < per_xcd[x].size() ? per_xcd[x][slot] : make_int4(0, 0, 0, 0));
+    tiles.swap(inter);
+  }
   int4 *d_tiles = nullptr;
   MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_tiles), tiles.size() * sizeof(int4)));
   MXA_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, s));
