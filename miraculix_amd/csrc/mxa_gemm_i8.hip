@@ -149,10 +149,15 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave / WC, wc = wave % WC;
-  int bid = blockIdx.x;
-  const int rb = bid % rowblocks; bid /= rowblocks;
-  const int nc = bid % nchunks;
-  const int sp = bid / nchunks;
+  // XCD-aware order as in k_gemm: the row blocks of one (chunk, split) group stream the same digit slabs; whole groups (the first
+  // 8 * floor(groups / 8)) are dealt to the 8 XCDs, blockIdx.x & 7 = XCD, so a group's slabs cross the fabric once
+  const int bid = blockIdx.x;
+  const int ngroups = (int)(gridDim.x / rowblocks), g8 = ngroups & ~7;
+  int rb, grp;
+  if (bid < g8 * rowblocks) { const int xcd = bid & 7, slot = bid >> 3; rb = slot % rowblocks; grp = xcd + 8 * (slot / rowblocks); }
+  else { const int t = bid - g8 * rowblocks; rb = t % rowblocks; grp = g8 + t / rowblocks; }
+  const int nc = grp % nchunks;
+  const int sp = grp / nchunks;
   const int st0 = sp * stages_per_split, st1 = min(st0 + stages_per_split, stages_total);
   const int stages = st1 - st0;
   const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
