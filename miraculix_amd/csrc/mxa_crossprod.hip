@@ -233,6 +233,35 @@ int launch_plink_lut(uint8_t *d, size_t nbytes, hipStream_t s) {
   return 0;
 }
 
+// XCD-aware order of a tile list.  Consecutive workgroups are dealt round-robin to the 8 XCDs (own L2 each).  In plain i-major
+// order the 32 tiles an XCD works on at a time share one I block and need 32 different J blocks; here the tiles are grouped into
+// super-tiles of sr x 8 tiles (sr tile rows, 8 tile columns), whole super-tiles go to the XCD with the shortest list so far, and the
+// lists are interleaved (list index = 8 * slot + xcd, padded with no-op entries {0,0,0,0}) so that an XCD streams sr + 8 row blocks
+// for 8 * sr tiles.  MXA_XPROD_XCD=0 keeps the plain order (A/B measurement).
+static void xcd_order_tiles(std::vector<int4> &tiles, int nb, int sr) {
+  static const bool on = [] { const char *e = getenv("MXA_XPROD_XCD"); return e ? atoi(e) != 0 : true; }();
+  if (!on || tiles.size() < 8 * 64 || sr < 1) return;
+  int i_min = tiles[0].x;
+  for (const int4 &t : tiles) i_min = std::min(i_min, t.x);
+  const int ncb = (nb + 7) / 8;
+  std::vector<std::vector<int4>> super((size_t)((nb - i_min + sr - 1) / sr) * ncb);
+  for (const int4 &t : tiles) super[(size_t)((t.x - i_min) / sr) * ncb + t.y / 8].push_back(t);
+  std::vector<std::vector<int4>> per_xcd(8);
+  for (auto &st : super) {
+    if (st.empty()) continue;
+    int best = 0;
+    for (int x = 1; x < 8; x++) if (per_xcd[x].size() < per_xcd[best].size()) best = x;
+    per_xcd[best].insert(per_xcd[best].end(), st.begin(), st.end());
+  }
+  size_t longest = 0;
+  for (auto &v : per_xcd) longest = std::max(longest, v.size());
+  std::vector<int4> inter;
+  inter.reserve(longest * 8);
+  for (size_t slot = 0; slot < longest; slot++)
+    for (int x = 0; x < 8; x++) inter.push_back(slot < per_xcd[x].size() ? per_xcd[x][slot] : make_int4(0, 0, 0, 0));
+  tiles.swap(inter);
+}
+
 // X: device, padded: rows_pad (multiple of 256) x pitch (multiple of 32 B), zero padded
 // Columns [c_begin, c_end) of M = X X^T into d_ans (leading dimension ld; c_begin a multiple of the 256-row tile, c_end a multiple
 // or the matrix end).  upper_only: only rows [0, c_end) are written -- everything above the panel's diagonal block and the block
@@ -257,30 +286,7 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
       if (flags) tiles.push_back(make_int4(i, j, flags, 0));
     }
   if (tiles.empty()) return 0;
-  // XCD-aware order: consecutive workgroups are dealt round-robin to the 8 XCDs (own L2 each).  In plain i-major order the 32 tiles
-  // an XCD works on at a time share one I block and need 32 different J blocks; here the tiles are grouped into super-tiles of 8 x 8
-  // (one I-range and one J-range of 8 row blocks each), whole super-tiles are dealt to the XCDs, and the lists are interleaved
-  // (list index = 8 * slot + xcd, padded with no-op entries) so that an XCD streams 16 row blocks for 64 tiles.
-  static const bool xcd_tiles = [] { const char *e = getenv("MXA_XPROD_XCD"); return e ? atoi(e) != 0 : true; }();
-  if (xcd_tiles && tiles.size() >= 8 * 64) {
-    std::vector<std::vector<int4>> per_xcd(8);
-    const int nsb = (nb + 7) / 8;
-    std::vector<std::vector<int4>> super((size_t)nsb * nsb);
-    for (const int4 &t : tiles) super[(size_t)(t.x / 8) * nsb + t.y / 8].push_back(t);
-    for (auto &st : super) {   // each super-tile goes to the XCD with the shortest list so far (diagonal super-tiles hold 36 tiles, others 64)
-      if (st.empty()) continue;
-      int best = 0;
-      for (int x = 1; x < 8; x++) if (per_xcd[x].size() < per_xcd[best].size()) best = x;
-      per_xcd[best].insert(per_xcd[best].end(), st.begin(), st.end());
-    }
-    size_t longest = 0;
-    for (auto &v : per_xcd) longest = std::max(longest, v.size());
-    std::vector<int4> inter;
-    inter.reserve(longest * 8);
-    for (size_t slot = 0; slot < longest; slot++)
-      for (int x = 0; x < 8; x++) inter.push_back(slot < per_xcd[x].size() ? per_xcd[x][slot] : make_int4(0, 0, 0, 0));
-    tiles.swap(inter);
-  }
+  xcd_order_tiles(tiles, nb, 8);
   int4 *d_tiles = nullptr;
   MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_tiles), tiles.size() * sizeof(int4)));
   MXA_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, s));
@@ -330,23 +336,27 @@ static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch
   const int nb = (int)((rows + kXT - 1) / kXT);
   const int stages = (int)((k + kXStageK - 1) / kXStageK);
   if ((size_t)stages * kXStageBytes > pitch) { set_error(4, "internal: crossproduct pitch too small"); return 1; }
+  const char *slab_env = getenv("MXA_XPROD_SLAB_MB");                                        // tests use small slabs
+  const long slab_bytes = (slab_env && atol(slab_env) > 0 ? atol(slab_env) : 1024L) << 20;
+  const int rows_per_chunk = (int)std::max<long>(1, slab_bytes / (rows * 8 * kXT));         // ~1 GiB column slabs
+  const int nchunks = (nb + rows_per_chunk - 1) / rows_per_chunk;
+  // one tile list per chunk of tile rows, each in XCD-aware order (super-tiles = the chunk's rows x 8 tile columns)
   std::vector<int4> tiles;
-  std::vector<size_t> first(nb + 1, 0);
-  tiles.reserve((size_t)nb * (nb + 1) / 2);
-  for (int i = 0; i < nb; i++) {
-    first[i] = tiles.size();
-    for (int j = i; j < nb; j++) tiles.push_back(make_int4(i, j, i == j ? 1 : 3, 0));
+  std::vector<size_t> first((size_t)nchunks + 1, 0);
+  for (int c = 0; c < nchunks; c++) {
+    first[(size_t)c] = tiles.size();
+    std::vector<int4> part;
+    for (int i = c * rows_per_chunk; i < std::min(nb, (c + 1) * rows_per_chunk); i++)
+      for (int j = i; j < nb; j++) part.push_back(make_int4(i, j, i == j ? 1 : 3, 0));
+    xcd_order_tiles(part, nb, std::min(rows_per_chunk, 8));
+    tiles.insert(tiles.end(), part.begin(), part.end());
   }
-  first[nb] = tiles.size();
+  first[(size_t)nchunks] = tiles.size();
   int4 *d_tiles = nullptr;
   MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_tiles), tiles.size() * sizeof(int4)));
   MXA_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, s));
   static bool attr2 = false;
   if (!attr2) { MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_crossprod2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kX2Lds)); attr2 = true; }
-  const char *slab_env = getenv("MXA_XPROD_SLAB_MB");                                        // tests use small slabs
-  const long slab_bytes = (slab_env && atol(slab_env) > 0 ? atol(slab_env) : 1024L) << 20;
-  const int rows_per_chunk = (int)std::max<long>(1, slab_bytes / (rows * 8 * kXT));         // ~1 GiB column slabs
-  const int nchunks = (nb + rows_per_chunk - 1) / rows_per_chunk;
   std::vector<hipEvent_t> ev((size_t)nchunks, nullptr);
   int dev = 0;
   MXA_HIP(hipGetDevice(&dev));
@@ -377,9 +387,8 @@ static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch
   int rc = 0;
   if (hipEventRecord(e0, s) != hipSuccess) rc = 1;
   for (int c = 0; c < nchunks && !rc; c++) {
-    const int i0 = c * rows_per_chunk, i1 = std::min(nb, i0 + rows_per_chunk);
-    const size_t cnt = first[i1] - first[i0];
-    hipLaunchKernelGGL(k_crossprod2<false>, dim3((unsigned)cnt), dim3(256), kX2Lds, s, d_X, pitch, stages, d_tiles + first[i0], rows, d_ans, rows, 0L, (unsigned long long *)nullptr);
+    const size_t cnt = first[(size_t)c + 1] - first[(size_t)c];
+    hipLaunchKernelGGL(k_crossprod2<false>, dim3((unsigned)cnt), dim3(256), kX2Lds, s, d_X, pitch, stages, d_tiles + first[(size_t)c], rows, d_ans, rows, 0L, (unsigned long long *)nullptr);
     if (hipGetLastError() != hipSuccess || hipEventRecord(ev[c], s) != hipSuccess) { rc = 1; break; }
     launched.store(c + 1);
   }
