@@ -37,6 +37,31 @@ def synth_plink_device(torch, rows, row_bytes, seed, device):
     return out
 
 
+def synth_genotypes_device(torch, rows, cols, seed, device, p_along="rows"):
+    """PLINK 2-bit rows (rows x ceil(cols/4) bytes) with the distribution of SURVEY.md 8(d) (mirrors the reference's
+    create_sim_file.jl:12): allele frequency p ~ U(0.1, 0.6) per SNP, genotype g ~ Binomial(2, p) i.i.d., no missings, codes
+    0 -> 00, 1 -> 10, 2 -> 11, row padding bits zero.  p_along = "rows": one p per row (SNP-major matrix); "cols": one p per
+    column (individual-major matrix).  Generated on the device in chunks."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    rb = (cols + 3) // 4
+    out = torch.empty((rows, rb), dtype=torch.uint8, device=device)
+    p_all = torch.rand(rows if p_along == "rows" else cols, device=device, generator=g) * 0.5 + 0.1
+    w = torch.tensor([1, 4, 16, 64], dtype=torch.uint8, device=device)
+    chunk = max(1, (128 << 20) // max(1, 4 * rb))
+    for r0 in range(0, rows, chunk):
+        r1 = min(rows, r0 + chunk)
+        u = torch.rand((r1 - r0, 4 * rb), device=device, generator=g)
+        p = p_all[r0:r1, None] if p_along == "rows" else torch.nn.functional.pad(p_all, (0, 4 * rb - cols))[None, :]
+        q0 = (1.0 - p) ** 2                       # P(g = 0)
+        q1 = q0 + 2.0 * p * (1.0 - p)             # P(g <= 1)
+        code = (u >= q0).to(torch.uint8) * 2 + (u >= q1).to(torch.uint8)   # 0 -> 00, 1 -> 10 (2), 2 -> 11 (3)
+        if 4 * rb > cols:
+            code[:, cols:] = 0
+        out[r0:r1] = (code.view(r1 - r0, rb, 4) * w).sum(dim=2, dtype=torch.uint8)
+    return out
+
+
 def cpu_baseline(seconds_budget=20.0):
     """CPU 5codes baseline on a bounded sample of the same workload (same n, both ops), timed on this host's cores.
     kind 'reference' when oracle/_ref (the reference's own library built from its sources) travelled with the repo,

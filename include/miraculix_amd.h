@@ -23,9 +23,11 @@ extern "C" {
 
 /* replaces src/miraculix/5codesAPI.c:43-70 (prototype src/miraculix/5codes.h:137-153; doc
  * docs/genotype_matrix_multiplication.md:5-17; Fortran binding src/bindings/Fortran/mod5codesapi.f90:22-40).
- * Process-global options.  This engine is GPU-only: use_gpu == 0 is a fatal error (stderr + exit), as are the
- * combinations the reference rejects for its GPU path (5codesChar.cc:192-193): use_miraculix_freq != 0,
- * ignore_missings == 0, do_normalize != 0.  cores, floatLoop, meanSubstract, variant have no GPU meaning and are
+ * Process-global options.  This engine is GPU-only: use_gpu == 0 prints a message, sets mxa_last_error() (code 14) and
+ * makes every later plink2compressed leave its handle NULL until setOptions_compressed is called again with use_gpu != 0 --
+ * the host process (a Julia / R session) is not terminated and no CPU engine is substituted.  The combinations the
+ * reference rejects for its GPU path (5codesChar.cc:192-193: use_miraculix_freq != 0, ignore_missings == 0,
+ * do_normalize != 0) are fatal (stderr + exit) exactly as there.  cores, floatLoop, meanSubstract, variant have no GPU meaning and are
  * accepted and ignored (src/miraculix/GPUapi.h:38). */
 void setOptions_compressed(int use_gpu, int cores, int floatLoop, int meanSubstract, int ignore_missings,
                            int do_not_center, int do_normalize, int use_miraculix_freq, int variant,
@@ -125,7 +127,11 @@ void mxa_plink2compressed_shard(char *plink, char *plink_transposed, int snps_to
                                 int snp_end, double *f, int max_n, void **compressed);
 
 /* dgemm_compressed with 64-bit leading dimensions on an explicit HIP stream (NULL = the object's own stream),
- * device pointers only, asynchronous when sync == 0.  Returns 0 / 1. */
+ * device pointers only, asynchronous when sync == 0.  Returns 0 / 1.
+ * ONE CALL IN FLIGHT PER OBJECT: every multiply on an object uses that object's workspace (fragment-ordered B, split-K
+ * partials, column sums).  Calls on the same object must therefore be serialised on ONE stream (or the caller must wait
+ * for the previous call before issuing the next on another stream); this includes mxa_gram_matvec and dgemm_compressed.
+ * Different objects are independent.  Not available on multi-device objects (MIRACULIX_NUM_GPUS > 1). */
 int mxa_dgemm_compressed_device(char trans, void *compressed, int n, const double *dB, long ldb, double *dC,
                                 long ldc, void *hip_stream, int sync);
 
@@ -139,6 +145,10 @@ int mxa_gram_matvec(void *compressed, int n, const double *V, long ldv, double *
  * transpose_genotype_matrix src/bindings/Julia/compressed_operations.jl:45-66, popcount frequencies
  * src/bindings/Julia/read_plink.jl:199-203).  Pointers may be host or device. */
 int mxa_transpose_2bit(const unsigned char *in, long rows, long cols, unsigned char *out);
+/* f_s = (sum of the allele counts of SNP s) / (2 indiv) with the decode the multiply uses: 00 -> 0, 10 -> 1, 11 -> 2 and the
+ * missing code 01 -> 0, so that f is exactly the column mean / 2 of the matrix dgemm_compressed multiplies with.
+ * DEVIATION on data with missing genotypes: the reference binding counts set bits (read_plink.jl:199-203), i.e. a missing
+ * 01 adds 1; on missing-free data (the only data the reference's tests and crossproduct accept, read_plink.jl:213) both agree. */
 int mxa_allele_freq(const unsigned char *plink, long snps, long indiv, double *f);
 
 /* PLINK .bed staging owned by the library: reads the SNP-major .bed file `bed_path` (3-byte magic 6c 1b 01, then snps rows of

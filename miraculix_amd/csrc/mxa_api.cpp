@@ -192,6 +192,7 @@ static int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t
   if (!o.set) {  // reference default before any user call: gpu when compiled with CUDA, centred (5codesChar.cc:127-143)
     o.gpu = true; o.centered = true; o.set = true;
   }
+  if (!o.gpu) { set_error(14, "plink2compressed: setOptions_compressed was called with use_gpu=0; this library has no CPU engine"); return 1; }
   const int dev = select_device();
   if (dev < 0) return 1;
   if (env_print_level() > 0 || o.print_level > 0) {
@@ -368,10 +369,16 @@ void setOptions_compressed(int use_gpu, int cores, int floatLoop, int meanSubstr
                            int do_normalize, int use_miraculix_freq, int variant, int print_details) {
   (void)cores; (void)floatLoop; (void)meanSubstract; (void)variant;
   if (print_details > 0 || env_print_level() > 0) printf("get started\n");  // the reference prints this unconditionally (5codesAPI.c:56)
+  clear_error();
   if (!use_gpu) {
-    fprintf(stderr, "miraculix_amd: setOptions_compressed(use_gpu=0): this library is the MI355X engine only; the CPU 5codes engine is "
-                    "not part of it. Load the reference library for CPU runs.\n");
-    exit(EXIT_FAILURE);
+    // GPU-only engine.  The host process (a Julia / R session) must survive: report, remember, and let every later
+    // plink2compressed leave its handle NULL (the Julia binding throws on a NULL handle, miraculix.jl:29-35).
+    Options &o = options();
+    o.gpu = false; o.set = true;
+    set_error(14, "setOptions_compressed(use_gpu=0): this library is the MI355X engine only; the CPU 5codes engine is not part of "
+                  "it. Objects cannot be created until setOptions_compressed is called with use_gpu=1; load the reference library "
+                  "for CPU runs.");
+    return;
   }
   // same fatal combination as the reference (5codesChar.cc:192-193, ERR0 -> fprintf(stderr)+exit)
   if (use_miraculix_freq || !ignore_missings || do_normalize) {
@@ -407,6 +414,7 @@ void mxa_plink2compressed_shard(char *plink, char *plink_transposed, int snps_to
 }
 
 static int trans_flag(const char *trans) {  // 5codesAPI.c:73-77
+  if (!trans) exit(99);   // the reference dereferences it; a NULL letter is "anything else"
   if (*trans == 'T' || *trans == 't' || *trans == 'Y' || *trans == 'y') return 1;
   if (*trans != 'N' && *trans != 'n') exit(99);
   return 0;

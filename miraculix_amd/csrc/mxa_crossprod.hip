@@ -21,7 +21,6 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 using gptr_t = const __attribute__((address_space(1))) void *;
 using lptr_t = __attribute__((address_space(3))) void *;
-__device__ __forceinline__ void xdma16(const void *g, void *l) { __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0); }
 
 // ---- the reference's PLINK -> 2-bit byte table (snp_multiply_cuda.h:202-210): 00->0, 10->1, 11->2, and a byte that
 // holds a missing pair (01) anywhere becomes 0xFF.  SWAR on 4 bytes at a time.
@@ -81,7 +80,7 @@ constexpr int kX2Bufs = 3;
 constexpr int kX2Lds = kX2Bufs * kXBufBytes;      // 48 KiB
 
 __device__ __forceinline__ void xdma16_s(const void *sbase, uint32_t voff, uint32_t lds_addr) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
 }
 
 template <bool DIAG>

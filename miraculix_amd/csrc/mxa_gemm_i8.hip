@@ -32,7 +32,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 using lptr_t = __attribute__((address_space(3))) void *;
 
 __device__ __forceinline__ void idma16_s(const void *sbase, uint32_t voff, uint32_t lds_addr) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
 }
 __device__ __forceinline__ v4i iunpack16(uint32_t w) {
   v4i r;

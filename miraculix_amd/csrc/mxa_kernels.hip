@@ -210,14 +210,11 @@ int launch_colsums(const double *dB, long ldb, long k, int n, const double *d_f,
 using gptr_t = const __attribute__((address_space(1))) void *;
 using lptr_t = __attribute__((address_space(3))) void *;
 
-__device__ __forceinline__ void dma16(const void *g, void *l) {
-  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
-}
 // LDS-DMA with a wave-uniform 64-bit base in SGPRs, a per-lane 32-bit byte offset and a wave-uniform LDS byte address
 // (M0).  Written as asm so that the per-slab address arithmetic stays on the scalar unit; hipcc does not count this
 // load: the kernel waits with its own s_waitcnt vmcnt(0) before the barrier that precedes the first ds_read of the data.
 __device__ __forceinline__ void dma16_s(const void *sbase, uint32_t voff, uint32_t lds_addr) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
 }
 
 template <int A, int C>

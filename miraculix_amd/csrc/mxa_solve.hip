@@ -312,10 +312,18 @@ static void coo_to_csr(const double *V, const long *I, const long *J, long nnz, 
 static int sparse_init_impl(const double *V, const long *I, const long *J, long nnz, long m, long ncol, int is_lower, void **GPU_obj) {
   if (GPU_obj) *GPU_obj = nullptr;
   if (!V || !I || !J || !GPU_obj || nnz <= 0 || m <= 0 || ncol <= 0) { set_error(1, "sparse2gpu: invalid argument"); return 1; }
+  // The reference only sets CUSPARSE_SPMAT_FILL_MODE on the descriptor (solve_cuda.cu:306-308, 376-412): cuSPARSE then reads the
+  // selected triangle and ignores everything else, so a caller may pass a full symmetric / general matrix.  Same here: entries
+  // outside the selected triangle are dropped while the CSR is built.
+  std::vector<double> Vk; std::vector<long> Ik, Jk;
+  Vk.reserve((size_t)nnz); Ik.reserve((size_t)nnz); Jk.reserve((size_t)nnz);
   for (long e = 0; e < nnz; e++) {
     if (I[e] < 1 || I[e] > m || J[e] < 1 || J[e] > m) { set_error(1, "sparse2gpu: entry %ld has index (%ld, %ld) outside 1..%ld (one-based COO expected)", e, I[e], J[e], m); return 1; }
-    if (is_lower ? J[e] > I[e] : J[e] < I[e]) { set_error(1, "sparse2gpu: entry %ld (%ld, %ld) lies outside the %s triangle", e, I[e], J[e], is_lower ? "lower" : "upper"); return 1; }
+    if (is_lower ? J[e] > I[e] : J[e] < I[e]) continue;
+    Vk.push_back(V[e]); Ik.push_back(I[e]); Jk.push_back(J[e]);
   }
+  V = Vk.data(); I = Ik.data(); J = Jk.data(); nnz = (long)Vk.size();
+  if (nnz <= 0) { set_error(1, "sparse2gpu: no entry lies in the %s triangle", is_lower ? "lower" : "upper"); return 1; }
   if (solve_select_device("sparse2gpu")) return 1;
   SparseSolve *s = new SparseSolve();
   (void)hipGetDevice(&s->device);

@@ -9,11 +9,15 @@ import numpy as np
 from . import lib as _lib
 
 
-def set_options(use_gpu=False, cores=0, not_center=False, variant=0, verbose=1):
-    """dgemm_compressed.jl:42-58.  use_gpu=False is a fatal error in this GPU-only engine (see include/miraculix_amd.h)."""
+def set_options(use_gpu=True, cores=0, not_center=False, variant=0, verbose=1):
+    """dgemm_compressed.jl:42-58.  The Julia binding defaults to use_gpu=false (its CPU engine); this library is the GPU engine
+    only, so the default here is True and use_gpu=False raises (the C entry reports the error, leaves the process alive and makes
+    later plink2compressed calls return a NULL handle -- see include/miraculix_amd.h)."""
     L = _lib.check_library_handle()
     floatLoop, meanSubstract, ignore_missings, normalize, use_miraculix_freq = 0, 0, 1, 0, 0
     L.setOptions_compressed(int(use_gpu), int(cores), floatLoop, meanSubstract, ignore_missings, int(not_center), normalize, use_miraculix_freq, int(variant), int(verbose))
+    if L.mxa_last_error():
+        raise RuntimeError("setOptions_compressed failed: " + _lib.last_error()[1])
 
 
 _ENGINES = {"f64": 0, "i8": 1, "small-n-i8": 2}

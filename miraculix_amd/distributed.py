@@ -14,7 +14,8 @@ import torch.distributed as dist
 
 
 def shard_bounds(snps, world_size, rank):
-    """contiguous SNP block of `rank`; boundaries are multiples of 4"""
+    """contiguous SNP block of `rank`; boundaries are multiples of 4.  With 4 * world_size > snps the last ranks get an empty
+    block (b == e): callers either skip such a rank or raise -- HipLocalEngine refuses an empty shard with a clear message."""
     per = ((snps + world_size - 1) // world_size + 3) // 4 * 4
     b = min(snps, rank * per)
     e = min(snps, b + per)
@@ -27,6 +28,8 @@ class HipLocalEngine:
     def __init__(self, plink_local, plink_t_local, snps_local, indiv, freq_local, max_ncol, centered):
         from . import dgemm_compressed as dg
         self.dg = dg
+        if snps_local <= 0:
+            raise ValueError("empty SNP shard: fewer than 4 SNPs per rank (shard_bounds returned b == e); use fewer ranks for this matrix")
         dg.set_options(use_gpu=True, not_center=not centered, verbose=0)
         self.obj = dg.init_compressed(plink_local, plink_t_local, snps_local, indiv, freq_local, max_ncol)
         self.snps, self.indiv = snps_local, indiv

@@ -33,7 +33,7 @@ def _run(mx, prob, trans, B, centered, ldc=None):
     return C
 
 
-@pytest.mark.parametrize("snps,indiv,n", [(1000, 500, 1), (1003, 501, 2), (2047, 771, 3), (5000, 1203, 4), (1003, 501, 5), (2000, 1000, 7), (777, 1301, 10), (4100, 515, 15), (3001, 2050, 32), (1500, 700, 40)])
+@pytest.mark.parametrize("snps,indiv,n", [(1000, 500, 1), (1003, 501, 2), (2047, 771, 3), (5000, 1203, 4), (1003, 501, 5), (2000, 1000, 7), (777, 1301, 10), (4100, 515, 15), (3001, 2050, 32), (1500, 700, 40), (900, 1100, 65), (1200, 640, 128)])
 @pytest.mark.parametrize("trans", [0, 1])
 @pytest.mark.parametrize("centered", [0, 1])
 def test_dgemm_vs_oracle(mx, snps, indiv, n, trans, centered):

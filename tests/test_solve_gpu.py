@@ -94,8 +94,15 @@ def test_dense_not_positive_definite_and_bad_arguments(sv):
     assert L.potrs_solve(m.lib.ptr(np.eye(2)), 2, m.lib.ptr(np.ones((2, 1))), 1, m.lib.ptr(X), None, 7) == 1   # oversubscribe not 0/1
     assert L.potrs_solve(m.lib.ptr(np.asfortranarray(2.0 * np.eye(2))), 2, m.lib.ptr(np.ones((2, 1))), 1, m.lib.ptr(X), None, 0) == 0
     assert np.allclose(X, 0.5, rtol=1e-15, atol=0)
-    with pytest.raises(RuntimeError):                 # an entry in the wrong triangle
-        sv.sparse_init(np.array([1.0, 1.0, 3.0]), np.array([1, 2, 2]), np.array([1, 2, 1]), 3, 2, 1, False)
+    # an entry outside the selected triangle is ignored, as cuSPARSE's fill mode does in the reference (solve_cuda.cu:306-308):
+    # upper triangle of [[1, 0], [3, 1]] is the identity
+    obj = sv.sparse_init(np.array([1.0, 1.0, 3.0]), np.array([1, 2, 2]), np.array([1, 2, 1]), 3, 2, 1, False)
+    try:
+        assert np.array_equal(sv.sparse_solve(obj, "n", np.array([[5.0], [7.0]]), 2)[:, 0], np.array([5.0, 7.0]))
+    finally:
+        sv.sparse_free(obj)
+    with pytest.raises(RuntimeError):                 # nothing at all in the selected triangle
+        sv.sparse_init(np.array([3.0]), np.array([2]), np.array([1]), 1, 2, 1, False)
     st = ctypes.c_int(5)
     L.dcsrtrsv_solve_gpu(None, b"n", m.lib.ptr(X), 1, m.lib.ptr(X), ctypes.byref(st))
     assert st.value == 1
