@@ -160,6 +160,28 @@ int mxa_allele_freq(const unsigned char *plink, long snps, long indiv, double *f
 int mxa_bed2compressed(const char *bed_path, int snps, int indiv, int max_n, void **compressed, double *f_out, int *snps_out,
                        int *indiv_out);
 
+/* The same for SNP rows [snp_begin, snp_end) of the file only: ONLY those rows are read (fseek), the individual-major block and
+ * the frequencies of the range are produced on the device, and the object behaves like one made by mxa_plink2compressed_shard --
+ * without any process ever holding the full SNP-major or individual-major matrix (one-process-per-GPU jobs: every rank stages
+ * its own range; the in-process sharder below does the same per device).  snps / indiv <= 0: from .bim / .fam.  f_out
+ * (optional, host) receives the snp_end - snp_begin frequencies of the range.  Returns 0 / 1. */
+int mxa_bed2compressed_range(const char *bed_path, int snps, int indiv, int snp_begin, int snp_end, int max_n, void **compressed,
+                             double *f_out);
+
+/* ---- several GPUs behind the reference ABI (single process).  With MIRACULIX_NUM_GPUS=G (> 1) in the environment,
+ * plink2compressed and mxa_bed2compressed return ONE handle that owns G per-device objects over contiguous SNP blocks
+ * (boundaries at multiples of 4; devices HIP_DEVICE/CUDA_DEVICE (default 0) + 0..G-1 modulo the visible device count -- more
+ * shards than devices puts several blocks on one GPU).  dgemm_compressed / mxa_gram_matvec / get_compressed_freq /
+ * free_compressed accept it unchanged: 'N' multiplies every block on its own device (one host thread per device, so host
+ * operands travel over every GPU's own PCIe link side by side) and sum-reduces the indiv x n partials onto the first device --
+ * by default with peer-to-peer pushes over xGMI and ONE addition kernel in ascending block order (bitwise reproducible),
+ * with MXA_REDUCE=rccl by ncclReduce (RCCL is dlopen()ed; needs distinct devices); 'T' writes disjoint row blocks, no exchange.
+ * B / C may be host memory or memory of any of the devices.  mxa_dgemm_compressed_device is not available on such a handle.
+ * mxa_num_shards: number of per-device objects behind a handle (1 for an ordinary one).  mxa_shard_bounds: block g of the
+ * partition of `snps` into `shards` blocks; returns the number of non-empty blocks. */
+int mxa_num_shards(void *compressed);
+int mxa_shard_bounds(long snps, int shards, int g, long *begin, long *end);
+
 /* Output-tile sharding of the crossproduct for one-process-per-GPU use (packed matrix replicated, independent
  * units, no collective): columns [col_begin, col_end) of the symmetric result of snp_multiply_gpu, i.e. the contiguous slab
  * ans + col_begin*indiv of the full column-major matrix, into `panel` (indiv rows, col_end - col_begin columns, leading

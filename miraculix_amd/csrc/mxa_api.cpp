@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -39,15 +40,20 @@ int env_print_level() {  // reference: cuda_utils.cu:44-52, env PRINT_LEVEL
   return e ? atoi(e) : 0;
 }
 
-void clear_error() { g_err = 0; g_errmsg[0] = 0; }
+// The status is per process, like the reference's (its entries return void and print).  Worker threads of a multi-device object
+// report through the same state: the mutex keeps the message intact, the first error of a call wins.
+static std::mutex g_err_mutex;
+void clear_error() { std::lock_guard<std::mutex> lk(g_err_mutex); g_err = 0; g_errmsg[0] = 0; }
 
 void set_error(int code, const char *fmt, ...) {
-  g_err = code;
+  char msg[512];
   va_list ap;
   va_start(ap, fmt);
-  vsnprintf(g_errmsg, sizeof(g_errmsg), fmt, ap);
+  vsnprintf(msg, sizeof(msg), fmt, ap);
   va_end(ap);
-  fprintf(stderr, "miraculix_amd: %s\n", g_errmsg);
+  fprintf(stderr, "miraculix_amd: %s\n", msg);
+  std::lock_guard<std::mutex> lk(g_err_mutex);
+  if (g_err == 0) { g_err = code; memcpy(g_errmsg, msg, sizeof(g_errmsg)); }
 }
 
 bool check_hip(hipError_t e, const char *func, int line) {
@@ -76,17 +82,20 @@ static Handle *as_handle(void *p, const char *who) {
   return h;
 }
 
-static bool is_device_ptr(const void *p) {
-  if (!p) return false;
+int ptr_location(const void *p, int *dev) {
+  if (dev) *dev = -1;
+  if (!p) return 0;
   hipPointerAttribute_t attr;
   hipError_t e = hipPointerGetAttributes(&attr, p);
-  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
-  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+  if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged) { if (dev) *dev = attr.device; return 1; }
+  return 0;
 }
+static bool is_device_ptr(const void *p) { return ptr_location(p, nullptr) == 1; }
 
 // device selection: env CUDA_DEVICE is honoured like the reference (cuda_utils.cu:187-247) but visibility variables
 // need not be set; HIP_DEVICE takes precedence.
-static int select_device() {
+int select_device() {
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0) {
@@ -128,7 +137,16 @@ static int stage_matrix(PackedMatrix &M, const uint8_t *src, size_t src_pitch, l
   MXA_HIP(hipMalloc(reinterpret_cast<void **>(&M.d), bytes));
   MXA_HIP(hipMemsetAsync(M.d, 0, bytes, s));
   const long row_bytes = (k + 3) / 4;
-  if (is_device_ptr(src)) {
+  int src_dev = -1;
+  if (ptr_location(src, &src_dev) == 1) {
+    int cur = 0;
+    MXA_HIP(hipGetDevice(&cur));
+    if (src_dev != cur) {   // the recode kernel reads the other GPU's memory over xGMI
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, cur, src_dev) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+      if (!can) { set_error(15, "plink2compressed: device %d cannot read the source matrix in the memory of device %d (no peer access)", cur, src_dev); return 1; }
+      if (hipDeviceEnablePeerAccess(src_dev, 0) != hipSuccess) (void)hipGetLastError();
+    }
     if (launch_recode(src, src_pitch, 0, rows, k, 0, M, s)) return 1;
     MXA_HIP(hipStreamSynchronize(s));
     return 0;
@@ -153,7 +171,7 @@ static int stage_matrix(PackedMatrix &M, const uint8_t *src, size_t src_pitch, l
   return rc;
 }
 
-static void destroy_handle(Handle *h) {
+void destroy_handle(Handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -182,8 +200,8 @@ static int ensure_workspace(Handle *h, int n) {
   return 0;
 }
 
-static int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink_t, size_t plink_t_pitch, long snps,
-                         long indiv, const double *f, int max_n, void **out) {
+int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink_t, size_t plink_t_pitch, long snps, long indiv, const double *f,
+                  int max_n, void **out, int device) {
   if (out) *out = nullptr;
   if (!out) { set_error(1, "plink2compressed: compressed is NULL"); return 1; }
   if (!plink || !plink_t) { set_error(1, "plink2compressed: both plink and plink_transposed are required on the GPU path"); return 1; }
@@ -193,7 +211,9 @@ static int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t
     o.gpu = true; o.centered = true; o.set = true;
   }
   if (!o.gpu) { set_error(14, "plink2compressed: setOptions_compressed was called with use_gpu=0; this library has no CPU engine"); return 1; }
-  const int dev = select_device();
+  int dev = device;
+  if (dev < 0) dev = select_device();
+  else if (!check_hip(hipSetDevice(dev), __func__, __LINE__)) dev = -1;
   if (dev < 0) return 1;
   if (env_print_level() > 0 || o.print_level > 0) {
     hipDeviceProp_t prop;
@@ -219,7 +239,7 @@ static int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t
   if (!check_hip(hipMalloc(reinterpret_cast<void **>(&h->d_f), sizeof(double) * snps), __func__, __LINE__)) { destroy_handle(h); return 1; }
   h->h_f = (double *)calloc((size_t)snps, sizeof(double));
   if (f) {
-    hipError_t e = hipMemcpy(h->d_f, f, sizeof(double) * snps, is_device_ptr(f) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpy(h->d_f, f, sizeof(double) * snps, hipMemcpyDefault);
     if (!check_hip(e, __func__, __LINE__)) { destroy_handle(h); return 1; }
     e = hipMemcpy(h->h_f, h->d_f, sizeof(double) * snps, hipMemcpyDeviceToHost);
     if (!check_hip(e, __func__, __LINE__)) { destroy_handle(h); return 1; }
@@ -233,37 +253,54 @@ static int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t
 }
 
 // ------------------------------------------------------------------------------------------------ multiply
-static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, hipStream_t s, bool timing = true) {
+static std::mutex g_prof_mutex;   // profile() / last_geometry() are written by the worker threads of multi-device objects too
+
+void harvest_profile(Handle *h) {
+  if (!h || !h->prof_pending) return;
+  h->prof_pending = false;
+  if (hipEventSynchronize(h->ev1) != hipSuccess) { (void)hipGetLastError(); return; }
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) { (void)hipGetLastError(); return; }
+  std::lock_guard<std::mutex> lk(g_prof_mutex);
+  profile().launches += 1; profile().total_ms += ms;
+}
+
+// Device operands only; asynchronous on s.  With timing, ev0/ev1 bracket the dominant kernel and harvest_profile() reads them later.
+static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, hipStream_t s, bool timing = true) {
   const PackedMatrix &G = trans ? h->snp_major : h->ind_major;   // reference picks d_plink for 'T' (dgemm_compressed_cuda.cu:270)
   const long m = G.rows, k = G.k;
   const bool centered = options().centered;
   if (centered && !h->has_f) { set_error(6, "dgemm_compressed: centring requested but no allele frequencies were supplied to plink2compressed"); return 1; }
   if (ldb < k || ldc < m) { set_error(7, "dgemm_compressed: leading dimension too small (ldb %ld < %ld or ldc %ld < %ld)", ldb, k, ldc, m); return 1; }
+  if (fill_rows < m || fill_rows > ldc) { set_error(7, "internal: fill_rows %ld outside [%ld, %ld]", fill_rows, m, ldc); return 1; }
   if (n > 65535) { set_error(7, "dgemm_compressed: n = %d exceeds the supported 65535 columns per call", n); return 1; }
   if (n > h->max_n) { h->max_n = n; }
   if (ensure_workspace(h, n)) return 1;
+  harvest_profile(h);   // a previous asynchronous call's events are reused below
   Workspace &w = h->ws;
   static const int lut_max_n = [] { const char *e = getenv("MXA_LUT_MAX_N"); return e ? atoi(e) : 2; }();
   const bool use_lut = n <= lut_max_n && n <= 4;
   GemmPlan p = use_lut ? plan_lut(m, G.k_pad, n) : plan_gemm(m, G.k_pad, n);
-  Geometry &geo = last_geometry();
-  geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c;
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mutex);
+    Geometry &geo = last_geometry();
+    geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c;
+  }
   double *d_sumB = w.d_colpart + (size_t)n * 128, *d_sumfB = d_sumB + n;
   static const int mode = [] { const char *e = getenv("MXA_GEMM_MODE"); return e ? atoi(e) : 2; }();
   const int engine = g_engine.load();
+  const bool prof = g_profile_on && timing;
+  if (prof && !h->ev0) { MXA_HIP(hipEventCreate(&h->ev0)); MXA_HIP(hipEventCreate(&h->ev1)); }
   if (engine == 1 || (engine == 2 && n <= 4)) {   // opt-in: exact int8 slicing of B on the int8 matrix cores (mxa_gemm_i8.hip)
     if (centered && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
-    const bool prof8 = g_profile_on && timing;
-    if (prof8 && !h->ev0) { MXA_HIP(hipEventCreate(&h->ev0)); MXA_HIP(hipEventCreate(&h->ev1)); }
     int splits8 = 1;
-    if (gemm_i8_device(G, trans, n, dB, ldb, dC, ldc, centered, d_sumB, d_sumfB, h->d_f, w, s, prof8 ? h->ev0 : nullptr, prof8 ? h->ev1 : nullptr, &splits8)) return 1;
-    geo.splits = splits8; geo.a = 0; geo.c = 0;
-    if (prof8) {
-      MXA_HIP(hipEventSynchronize(h->ev1));
-      float ms = 0.f;
-      MXA_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-      profile().launches += 1; profile().total_ms += ms;
+    if (gemm_i8_device(G, trans, n, dB, ldb, dC, ldc, fill_rows, centered, d_sumB, d_sumfB, h->d_f, w, s, prof ? h->ev0 : nullptr, prof ? h->ev1 : nullptr, &splits8)) return 1;
+    {
+      std::lock_guard<std::mutex> lk(g_prof_mutex);
+      Geometry &geo = last_geometry();
+      geo.splits = splits8; geo.a = 0; geo.c = 0;
     }
+    h->prof_pending = prof;
     return 0;
   }
   // MODE 2 (default): genotype operand as the denormal z * 2^-1074 (one VALU per fragment instead of two); B scaled per column
@@ -280,27 +317,14 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   }
   if (!use_lut && launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, d_E)) return 1;
   if (centered && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
-  const bool prof = g_profile_on && timing;   // the asynchronous entry must not block on an event
-  hipEvent_t e0 = h->ev0, e1 = h->ev1;
-  if (prof) {
-    if (!e0) { MXA_HIP(hipEventCreate(&h->ev0)); MXA_HIP(hipEventCreate(&h->ev1)); e0 = h->ev0; e1 = h->ev1; }
-    MXA_HIP(hipEventRecord(e0, s));
-  }
+  if (prof) MXA_HIP(hipEventRecord(h->ev0, s));
   int rc = use_lut ? launch_lut(G, dB, ldb, n, w.d_P, p, s) : launch_gemm(G, w.d_Bp, w.d_P, p, mode, s);
-  if (prof && !rc) MXA_HIP(hipEventRecord(e1, s));
-  if (!rc) rc = launch_finish(w.d_P, p, m, n, dC, ldc, trans ? 1 : 0, centered, d_sumB, d_sumfB, h->d_f, s, d_E);
-  if (prof) {
-    if (!rc) {
-      MXA_HIP(hipEventSynchronize(e1));
-      float ms = 0.f;
-      MXA_HIP(hipEventElapsedTime(&ms, e0, e1));
-      profile().launches += 1; profile().total_ms += ms;
-    }
-  }
+  if (prof && !rc) { MXA_HIP(hipEventRecord(h->ev1, s)); h->prof_pending = true; }
+  if (!rc) rc = launch_finish(w.d_P, p, m, n, dC, ldc, fill_rows, trans ? 1 : 0, centered, d_sumB, d_sumfB, h->d_f, s, d_E);
   return rc;
 }
 
-static int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, double *C, long ldc) {
+int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, double *C, long ldc, long fill_rows, bool sync, bool timing) {
   MXA_HIP(hipSetDevice(h->device));
   const PackedMatrix &G = trans ? h->snp_major : h->ind_major;
   const long m = G.rows, k = G.k;
@@ -308,28 +332,33 @@ static int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, dou
   if (!B || !C) { set_error(1, "dgemm_compressed: B and C must not be NULL"); return 1; }
   if (ldb < k || ldc < m) { set_error(7, "dgemm_compressed: leading dimension too small (ldb %ld < %ld or ldc %ld < %ld)", ldb, k, ldc, m); return 1; }
   hipStream_t s = h->stream;
-  const bool b_dev = is_device_ptr(B), c_dev = is_device_ptr(C);
+  int b_devno = -1, c_devno = -1;
+  const bool b_local = ptr_location(B, &b_devno) == 1 && b_devno == h->device;
+  const bool c_local = ptr_location(C, &c_devno) == 1 && c_devno == h->device;
   const double *dB = B; long dldb = ldb;
   double *dC = C; long dldc = ldc;
   Workspace &w = h->ws;
-  if (!b_dev) {
+  if (!b_local) {   // host memory, or memory of another device (peer copy over xGMI): dense k x n copy into this device's staging buffer
     if (grow(&w.d_Bstage, &w.cap_Bstage, (size_t)k * n)) return 1;
-    if (ldb == k) MXA_HIP(hipMemcpyAsync(w.d_Bstage, B, sizeof(double) * (size_t)k * n, hipMemcpyHostToDevice, s));
-    else MXA_HIP(hipMemcpy2DAsync(w.d_Bstage, sizeof(double) * k, B, sizeof(double) * ldb, sizeof(double) * k, n, hipMemcpyHostToDevice, s));
+    if (ldb == k) MXA_HIP(hipMemcpyAsync(w.d_Bstage, B, sizeof(double) * (size_t)k * n, hipMemcpyDefault, s));
+    else MXA_HIP(hipMemcpy2DAsync(w.d_Bstage, sizeof(double) * k, B, sizeof(double) * ldb, sizeof(double) * k, n, hipMemcpyDefault, s));
     dB = w.d_Bstage; dldb = k;
   }
-  if (!c_dev) {
-    if (grow(&w.d_Cstage, &w.cap_Cstage, (size_t)ldc * n)) return 1;
-    dC = w.d_Cstage; dldc = ldc;
+  if (!c_local) {
+    if (grow(&w.d_Cstage, &w.cap_Cstage, (size_t)fill_rows * n)) return 1;
+    dC = w.d_Cstage; dldc = fill_rows;
   }
-  if (gemm_device(h, trans, n, dB, dldb, dC, dldc, s)) return 1;
-  if (!c_dev) MXA_HIP(hipMemcpyAsync(C, dC, sizeof(double) * (size_t)ldc * n, hipMemcpyDeviceToHost, s));
-  MXA_HIP(hipStreamSynchronize(s));
+  if (gemm_device(h, trans, n, dB, dldb, dC, dldc, fill_rows, s, timing)) return 1;
+  if (!c_local) {
+    if (ldc == fill_rows) MXA_HIP(hipMemcpyAsync(C, dC, sizeof(double) * (size_t)fill_rows * n, hipMemcpyDefault, s));
+    else MXA_HIP(hipMemcpy2DAsync(C, sizeof(double) * ldc, dC, sizeof(double) * fill_rows, sizeof(double) * fill_rows, n, hipMemcpyDefault, s));
+  }
+  if (sync) { MXA_HIP(hipStreamSynchronize(s)); harvest_profile(h); }
   return 0;
 }
 
 // out (indiv x n) = Zc * (Zc^T * V): the 'T' then the 'N' product with the snps x n intermediate kept in HBM
-static int gram_any(Handle *h, int n, const double *V, long ldv, double *out, long ldo) {
+int gram_any(Handle *h, int n, const double *V, long ldv, double *out, long ldo, bool sync) {
   MXA_HIP(hipSetDevice(h->device));
   const long snps = h->snps, indiv = h->indiv;
   if (n <= 0) return 0;
@@ -337,24 +366,26 @@ static int gram_any(Handle *h, int n, const double *V, long ldv, double *out, lo
   if (ldv < indiv || ldo < indiv) { set_error(7, "mxa_gram_matvec: leading dimension too small (ldv %ld, ldo %ld < %ld)", ldv, ldo, indiv); return 1; }
   hipStream_t s = h->stream;
   Workspace &w = h->ws;
-  const bool v_dev = is_device_ptr(V), o_dev = is_device_ptr(out);
+  int v_devno = -1, o_devno = -1;
+  const bool v_local = ptr_location(V, &v_devno) == 1 && v_devno == h->device;
+  const bool o_local = ptr_location(out, &o_devno) == 1 && o_devno == h->device;
   const double *dV = V; long dldv = ldv;
   double *dO = out; long dldo = ldo;
-  if (!v_dev) {
+  if (!v_local) {
     if (grow(&w.d_Bstage, &w.cap_Bstage, (size_t)std::max(snps, indiv) * n)) return 1;
-    if (ldv == indiv) MXA_HIP(hipMemcpyAsync(w.d_Bstage, V, sizeof(double) * (size_t)indiv * n, hipMemcpyHostToDevice, s));
-    else MXA_HIP(hipMemcpy2DAsync(w.d_Bstage, sizeof(double) * indiv, V, sizeof(double) * ldv, sizeof(double) * indiv, n, hipMemcpyHostToDevice, s));
+    if (ldv == indiv) MXA_HIP(hipMemcpyAsync(w.d_Bstage, V, sizeof(double) * (size_t)indiv * n, hipMemcpyDefault, s));
+    else MXA_HIP(hipMemcpy2DAsync(w.d_Bstage, sizeof(double) * indiv, V, sizeof(double) * ldv, sizeof(double) * indiv, n, hipMemcpyDefault, s));
     dV = w.d_Bstage; dldv = indiv;
   }
-  if (!o_dev) {
+  if (!o_local) {
     if (grow(&w.d_Cstage, &w.cap_Cstage, (size_t)ldo * n)) return 1;
     dO = w.d_Cstage; dldo = ldo;
   }
   if (grow(&w.d_tmp, &w.cap_tmp, (size_t)snps * n)) return 1;
-  if (gemm_device(h, true, n, dV, dldv, w.d_tmp, snps, s, false)) return 1;
-  if (gemm_device(h, false, n, w.d_tmp, snps, dO, dldo, s, false)) return 1;
-  if (!o_dev) MXA_HIP(hipMemcpyAsync(out, dO, sizeof(double) * (size_t)ldo * n, hipMemcpyDeviceToHost, s));
-  MXA_HIP(hipStreamSynchronize(s));
+  if (gemm_device(h, true, n, dV, dldv, w.d_tmp, snps, snps, s, false)) return 1;
+  if (gemm_device(h, false, n, w.d_tmp, snps, dO, dldo, dldo, s, false)) return 1;
+  if (!o_local) MXA_HIP(hipMemcpyAsync(out, dO, sizeof(double) * (size_t)ldo * n, hipMemcpyDefault, s));
+  if (sync) MXA_HIP(hipStreamSynchronize(s));
   return 0;
 }
 
@@ -395,6 +426,11 @@ void setOptions_compressed(int use_gpu, int cores, int floatLoop, int meanSubstr
 void plink2compressed(char *plink, char *plink_transposed, int snps, int indiv, double *f, int max_n, void **compressed) {
   clear_error();
   const size_t ps = ((size_t)indiv + 3) / 4, pi = ((size_t)snps + 3) / 4;
+  const int shards = multi_requested();
+  if (shards > 1 || getenv("MXA_FORCE_MULTI")) {   // MIRACULIX_NUM_GPUS > 1: SNP blocks over several devices behind the same handle
+    (void)multi_create(reinterpret_cast<const uint8_t *>(plink), reinterpret_cast<const uint8_t *>(plink_transposed), snps, indiv, f, max_n, shards, compressed);
+    return;
+  }
   (void)create_handle(reinterpret_cast<const uint8_t *>(plink), ps, reinterpret_cast<const uint8_t *>(plink_transposed), pi, snps, indiv, f,
                       max_n, compressed);
 }
@@ -423,34 +459,38 @@ static int trans_flag(const char *trans) {  // 5codesAPI.c:73-77
 void dgemm_compressed(char *trans, void *compressed, int n, double *B, int Ldb, double *C, int Ldc) {
   clear_error();
   const int t = trans_flag(trans);
+  if (is_multi(compressed)) { (void)multi_gemm(compressed, t != 0, n, B, Ldb, C, Ldc); return; }
   Handle *h = as_handle(compressed, "dgemm_compressed");
   if (!h) return;
-  (void)gemm_any(h, t != 0, n, B, Ldb, C, Ldc);
+  (void)gemm_any(h, t != 0, n, B, Ldb, C, Ldc, Ldc, true, true);
 }
 
 int mxa_dgemm_compressed_device(char trans, void *compressed, int n, const double *dB, long ldb, double *dC, long ldc, void *hip_stream,
                                 int sync) {
   clear_error();
   const int t = trans_flag(&trans);
+  if (is_multi(compressed)) { set_error(16, "mxa_dgemm_compressed_device: not available on a multi-device object (MIRACULIX_NUM_GPUS > 1); use dgemm_compressed"); return 1; }
   Handle *h = as_handle(compressed, "mxa_dgemm_compressed_device");
   if (!h) return 1;
   if (n <= 0) return 0;
   MXA_HIP(hipSetDevice(h->device));
   hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->stream;
-  if (gemm_device(h, t != 0, n, dB, ldb, dC, ldc, s, sync != 0)) return 1;
-  if (sync) MXA_HIP(hipStreamSynchronize(s));
+  if (gemm_device(h, t != 0, n, dB, ldb, dC, ldc, ldc, s, sync != 0)) return 1;
+  if (sync) { MXA_HIP(hipStreamSynchronize(s)); harvest_profile(h); }
   return 0;
 }
 
 int mxa_gram_matvec(void *compressed, int n, const double *V, long ldv, double *out, long ldo) {
   clear_error();
+  if (is_multi(compressed)) return multi_gram(compressed, n, V, ldv, out, ldo);
   Handle *h = as_handle(compressed, "mxa_gram_matvec");
   if (!h) return 1;
-  return gram_any(h, n, V, ldv, out, ldo);
+  return gram_any(h, n, V, ldv, out, ldo, true);
 }
 
 void free_compressed(void **compressed) {
   if (!compressed || !*compressed) return;
+  if (is_multi(*compressed)) { multi_destroy(*compressed); *compressed = nullptr; return; }
   Handle *h = as_handle(*compressed, "free_compressed");
   if (h) destroy_handle(h);
   *compressed = nullptr;
@@ -550,6 +590,7 @@ void sparse_times_plink(char *transsparse, char *transcompressed, char *plink, c
 }
 
 void get_compressed_freq(void *compressed, double *f) {
+  if (is_multi(compressed)) { if (f) multi_freq(compressed, f); return; }
   Handle *h = as_handle(compressed, "get_compressed_freq");
   if (!h || !f) return;
   memcpy(f, h->h_f, sizeof(double) * (size_t)h->snps);
@@ -591,15 +632,27 @@ static long count_lines(const char *path) {
   return n;
 }
 
-int mxa_bed2compressed(const char *bed_path, int snps, int indiv, int max_n, void **compressed, double *f_out, int *snps_out, int *indiv_out) {
-  clear_error();
-  if (compressed) *compressed = nullptr;
-  if (!bed_path || !compressed) { set_error(1, "mxa_bed2compressed: bad arguments"); return 1; }
+static std::string bed_base(const char *bed_path) {
   std::string base(bed_path);
   if (base.size() > 4 && base.compare(base.size() - 4, 4, ".bed") == 0) base.resize(base.size() - 4);
-  if (snps <= 0) snps = (int)count_lines((base + ".bim").c_str());
-  if (indiv <= 0) indiv = (int)count_lines((base + ".fam").c_str());
-  if (snps <= 0 || indiv <= 0) { set_error(1, "mxa_bed2compressed: dimensions unknown (no .bim/.fam next to %s)", bed_path); return 1; }
+  return base;
+}
+
+}  // extern "C"
+
+namespace mxa {
+// SNP rows [snp_begin, snp_end) of the SNP-major file `base`.bed -> object on `device`.  Only those rows are read (the reference
+// reader streams the whole file row by row, read_plink.jl:161-222); the individual-major block and the allele frequencies of the
+// range are produced on the device (k_transpose_2bit*, k_allele_freq), so no process ever needs the full individual-major matrix.
+// File chunks go through two pinned buffers so that reading chunk c+1 overlaps the upload of chunk c.
+int bed_range_to_handle(const char *base_c, long snps_total, long indiv, long snp_begin, long snp_end, int max_n, int device, void **out,
+                        double *f_out_local) {
+  if (out) *out = nullptr;
+  const std::string base(base_c);
+  if (!out || snps_total <= 0 || indiv <= 0 || snp_begin < 0 || snp_end > snps_total || snp_begin >= snp_end) {
+    set_error(1, "bed staging: need 0 <= snp_begin < snp_end <= snps (got [%ld, %ld) of %ld) and indiv > 0", snp_begin, snp_end, snps_total);
+    return 1;
+  }
   FILE *fh = fopen((base + ".bed").c_str(), "rb");
   if (!fh) { set_error(1, "mxa_bed2compressed: cannot open %s.bed", base.c_str()); return 1; }
   unsigned char magic[3];
@@ -608,37 +661,95 @@ int mxa_bed2compressed(const char *bed_path, int snps, int indiv, int max_n, voi
     set_error(1, "mxa_bed2compressed: %s.bed is not a SNP-major PLINK .bed file (magic bytes 6c 1b 01 expected)", base.c_str());
     return 1;
   }
-  if (select_device() < 0) { fclose(fh); return 1; }
-  const size_t bps = ((size_t)indiv + 3) / 4, bpi = ((size_t)snps + 3) / 4;
-  uint8_t *d_plink = nullptr, *d_plink_t = nullptr;
-  double *d_f = nullptr;
-  int rc = 0;
-  auto bad = [&](hipError_t e, int line) { if (e != hipSuccess) { check_hip(e, "mxa_bed2compressed", line); rc = 1; } return rc; };
-  std::vector<uint8_t> chunk;
-  if (bad(hipMalloc((void **)&d_plink, (size_t)snps * bps), __LINE__) || bad(hipMalloc((void **)&d_plink_t, (size_t)indiv * bpi), __LINE__) ||
-      bad(hipMalloc((void **)&d_f, sizeof(double) * snps), __LINE__)) goto out;
-  {
-    const size_t rows_per_chunk = std::max<size_t>(1, ((size_t)64 << 20) / bps);
-    chunk.resize(rows_per_chunk * bps);
-    for (size_t r0 = 0; r0 < (size_t)snps && !rc; r0 += rows_per_chunk) {
-      const size_t nr = std::min(rows_per_chunk, (size_t)snps - r0);
-      if (fread(chunk.data(), 1, nr * bps, fh) != nr * bps) { set_error(1, "mxa_bed2compressed: %s.bed is shorter than %d x ceil(%d/4) bytes", base.c_str(), snps, indiv); rc = 1; break; }
-      bad(hipMemcpy(d_plink + r0 * bps, chunk.data(), nr * bps, hipMemcpyHostToDevice), __LINE__);
+  const size_t bps = ((size_t)indiv + 3) / 4;
+  const long rows = snp_end - snp_begin;
+  const size_t bpi = ((size_t)rows + 3) / 4;
+  // the reference reader fails on a file that is too short and asserts eof afterwards ("Too large .bed file", read_plink.jl:190-193)
+  if (fseeko(fh, 0, SEEK_END) == 0) {
+    const off_t sz = ftello(fh);
+    if (sz >= 0 && (size_t)sz != 3 + (size_t)snps_total * bps) {
+      fclose(fh);
+      set_error(1, "mxa_bed2compressed: %s.bed has %lld bytes, expected 3 + %ld x ceil(%ld/4) = %zu", base.c_str(), (long long)sz, snps_total, indiv, 3 + (size_t)snps_total * bps);
+      return 1;
     }
   }
-  if (!rc) rc = launch_transpose_2bit(d_plink, snps, indiv, d_plink_t, nullptr);
-  if (!rc) rc = launch_allele_freq(d_plink, snps, indiv, d_f, nullptr);
+  if (fseeko(fh, (off_t)(3 + (size_t)snp_begin * bps), SEEK_SET) != 0) { fclose(fh); set_error(1, "mxa_bed2compressed: cannot seek in %s.bed", base.c_str()); return 1; }
+  int dev = device;
+  if (dev < 0) dev = select_device();
+  else if (!check_hip(hipSetDevice(dev), __func__, __LINE__)) dev = -1;
+  if (dev < 0) { fclose(fh); return 1; }
+  uint8_t *d_plink = nullptr, *d_plink_t = nullptr;
+  double *d_f = nullptr;
+  void *pin[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  hipStream_t cs = nullptr;
+  int rc = 0;
+  auto bad = [&](hipError_t e, int line) { if (e != hipSuccess) { check_hip(e, "mxa_bed2compressed", line); rc = 1; } return rc; };
+  const size_t rows_per_chunk = std::max<size_t>(1, ((size_t)64 << 20) / bps);
+  const size_t chunk_bytes = std::min(rows_per_chunk, (size_t)rows) * bps;
+  if (bad(hipMalloc((void **)&d_plink, (size_t)rows * bps), __LINE__) || bad(hipMalloc((void **)&d_plink_t, (size_t)indiv * bpi), __LINE__) ||
+      bad(hipMalloc((void **)&d_f, sizeof(double) * rows), __LINE__) || bad(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking), __LINE__)) goto out;
+  for (int i = 0; i < 2; i++)
+    if (bad(hipHostMalloc(&pin[i], chunk_bytes, hipHostMallocDefault), __LINE__) || bad(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming), __LINE__)) goto out;
+  {
+    int slot = 0;
+    bool used[2] = {false, false};
+    for (size_t r0 = 0; r0 < (size_t)rows && !rc; r0 += rows_per_chunk, slot ^= 1) {
+      const size_t nr = std::min(rows_per_chunk, (size_t)rows - r0);
+      if (used[slot] && bad(hipEventSynchronize(ev[slot]), __LINE__)) break;     // the upload that last used this buffer is done
+      if (fread(pin[slot], 1, nr * bps, fh) != nr * bps) { set_error(1, "mxa_bed2compressed: %s.bed is shorter than %ld x ceil(%ld/4) bytes", base.c_str(), snps_total, indiv); rc = 1; break; }
+      if (bad(hipMemcpyAsync(d_plink + r0 * bps, pin[slot], nr * bps, hipMemcpyHostToDevice, cs), __LINE__) || bad(hipEventRecord(ev[slot], cs), __LINE__)) break;
+      used[slot] = true;
+    }
+    if (!rc) bad(hipStreamSynchronize(cs), __LINE__);
+  }
+  if (!rc) rc = launch_transpose_2bit(d_plink, rows, indiv, d_plink_t, nullptr);
+  if (!rc) rc = launch_allele_freq(d_plink, rows, indiv, d_f, nullptr);
   if (!rc) bad(hipDeviceSynchronize(), __LINE__);
-  if (!rc) rc = create_handle(d_plink, bps, d_plink_t, bpi, snps, indiv, d_f, max_n, compressed);
-  if (!rc && f_out) bad(hipMemcpy(f_out, d_f, sizeof(double) * snps, hipMemcpyDeviceToHost), __LINE__);
-  if (!rc) { if (snps_out) *snps_out = snps; if (indiv_out) *indiv_out = indiv; }
+  if (!rc) rc = create_handle(d_plink, bps, d_plink_t, bpi, rows, indiv, d_f, max_n, out, dev);
+  if (!rc && f_out_local) bad(hipMemcpy(f_out_local, d_f, sizeof(double) * rows, hipMemcpyDeviceToHost), __LINE__);
 out:
   fclose(fh);
+  for (int i = 0; i < 2; i++) { if (pin[i]) (void)hipHostFree(pin[i]); if (ev[i]) (void)hipEventDestroy(ev[i]); }
+  if (cs) (void)hipStreamDestroy(cs);
   if (d_plink) (void)hipFree(d_plink);
   if (d_plink_t) (void)hipFree(d_plink_t);
   if (d_f) (void)hipFree(d_f);
-  if (rc && compressed && *compressed) free_compressed(compressed);
+  if (rc && out && *out) { destroy_handle(reinterpret_cast<Handle *>(*out)); *out = nullptr; }
   return rc;
+}
+}  // namespace mxa
+
+extern "C" {
+
+static int bed_dims(const char *who, const std::string &base, int *snps, int *indiv) {
+  if (*snps <= 0) *snps = (int)count_lines((base + ".bim").c_str());
+  if (*indiv <= 0) *indiv = (int)count_lines((base + ".fam").c_str());
+  if (*snps <= 0 || *indiv <= 0) { set_error(1, "%s: dimensions unknown (no .bim/.fam next to %s.bed)", who, base.c_str()); return 1; }
+  return 0;
+}
+
+int mxa_bed2compressed(const char *bed_path, int snps, int indiv, int max_n, void **compressed, double *f_out, int *snps_out, int *indiv_out) {
+  clear_error();
+  if (compressed) *compressed = nullptr;
+  if (!bed_path || !compressed) { set_error(1, "mxa_bed2compressed: bad arguments"); return 1; }
+  const std::string base = bed_base(bed_path);
+  if (bed_dims("mxa_bed2compressed", base, &snps, &indiv)) return 1;
+  int rc;
+  const int shards = multi_requested();
+  if (shards > 1 || getenv("MXA_FORCE_MULTI")) rc = multi_create_from_bed(base.c_str(), snps, indiv, max_n, shards, compressed, f_out);
+  else rc = bed_range_to_handle(base.c_str(), snps, indiv, 0, snps, max_n, -1, compressed, f_out);
+  if (!rc) { if (snps_out) *snps_out = snps; if (indiv_out) *indiv_out = indiv; }
+  return rc;
+}
+
+int mxa_bed2compressed_range(const char *bed_path, int snps, int indiv, int snp_begin, int snp_end, int max_n, void **compressed, double *f_out) {
+  clear_error();
+  if (compressed) *compressed = nullptr;
+  if (!bed_path || !compressed) { set_error(1, "mxa_bed2compressed_range: bad arguments"); return 1; }
+  const std::string base = bed_base(bed_path);
+  if (bed_dims("mxa_bed2compressed_range", base, &snps, &indiv)) return 1;
+  return bed_range_to_handle(base.c_str(), snps, indiv, snp_begin, snp_end, max_n, -1, compressed, f_out);
 }
 
 // ---- staging helpers

@@ -278,7 +278,7 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
 // the result is transposed through LDS so that C is written with the row running along the lanes.
 __global__ void __launch_bounds__(256) k_finish_i8(const int *__restrict__ P, long m_pad, int e_pad, int splits, long m, int n, int S, int nc, int NT,
                                                    const int *__restrict__ E, const double *__restrict__ colmax_part, double *__restrict__ Cout, long ldc,
-                                                   int mode_trans, int centered, const double *__restrict__ sumB, const double *__restrict__ sumfB,
+                                                   long fill_rows, int mode_trans, int centered, const double *__restrict__ sumB, const double *__restrict__ sumfB,
                                                    const double *__restrict__ f) {
   __shared__ double sh[32][33];
   __shared__ double contrib[8][8 * 32 + 1];        // scaled terms of 8 rows x all expanded columns of the chunk
@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(256) k_finish_i8(const int *__restrict__ P, lo
     const long r = r0 + rr;
     for (int jj = threadIdx.x >> 5; jj < nc; jj += 8) {
       const int j = chunk * nc + jj;
-      if (r < ldc && j < n) Cout[r + (long)j * ldc] = sh[rr][jj];
+      if (r < fill_rows && j < n) Cout[r + (long)j * ldc] = sh[rr][jj];
     }
   }
 }
@@ -396,12 +396,9 @@ static I8Plan plan_i8(long m, long k_pad, int n) {
 template <int NT, int MT, int WC>
 static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const I8Plan &p, hipStream_t s) {
   using Cfg = I8Cfg<NT>;
-  static bool attr = false;
-  if (!attr) {
-    MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_i8<NT, MT, WC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds));
-    MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_i8<NT, MT, WC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds));
-    attr = true;
-  }
+  static unsigned long long attr_a = 0, attr_b = 0;   // function attributes are per device
+  if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8<NT, MT, WC, false>), Cfg::kLds, &attr_a) ||
+      ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8<NT, MT, WC, true>), Cfg::kLds, &attr_b)) return 1;
   const long grid = (long)p.rowblocks * p.nchunks * p.splits;
   static const bool diag_on = getenv("MXA_DIAG") != nullptr;
   if (diag_on) {   // in-kernel clocks: shader cycles and 100 MHz ticks per workgroup K loop
@@ -428,7 +425,7 @@ static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const 
 
 // Whole product on the device; B, C device pointers; asynchronous on s.  The workspace (exponents, slices, partials) lives with the
 // handle and only grows.
-int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, bool centered, const double *d_sumB,
+int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool centered, const double *d_sumB,
                    const double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out) {
   const long m = G.rows, k = G.k;
   const I8Plan p = plan_i8(m, G.k_pad, n);
@@ -475,8 +472,8 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   if (rc) return rc;
   if (ev1) MXA_HIP(hipEventRecord(ev1, s));
   {
-    dim3 grid((unsigned)((ldc + 31) / 32), p.nchunks);
-    hipLaunchKernelGGL(k_finish_i8, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, d_part, dC, ldc, trans ? 1 : 0,
+    dim3 grid((unsigned)((fill_rows + 31) / 32), p.nchunks);
+    hipLaunchKernelGGL(k_finish_i8, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, d_part, dC, ldc, fill_rows, trans ? 1 : 0,
                        centered ? 1 : 0, d_sumB, d_sumfB, d_f);
   }
   MXA_HIP(hipGetLastError());

@@ -52,6 +52,7 @@ struct Workspace {
 };
 
 constexpr uint32_t kMagic = 0x4d584131u;  // "MXA1"
+constexpr uint32_t kMagicMulti = 0x4d58414du;  // "MXAM": SNP-sharded object over several devices (mxa_multi.cpp)
 
 struct Handle {
   uint32_t magic = kMagic;
@@ -66,6 +67,7 @@ struct Handle {
   Workspace ws;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // timing of the dominant kernel (created once, not per call)
+  bool prof_pending = false;                 // ev0/ev1 were recorded by the last call and have not been read yet
 };
 
 struct Profile {
@@ -76,6 +78,39 @@ Profile &profile();
 
 struct Geometry { long m = 0, k = 0; int n = 0, splits = 0, a = 0, c = 0; };
 Geometry &last_geometry();
+
+// ---- host-side engine entry points shared by mxa_api.cpp (single device) and mxa_multi.cpp (SNP shards over several devices)
+// device < 0: taken from HIP_DEVICE / CUDA_DEVICE / the current device
+int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink_t, size_t plink_t_pitch, long snps, long indiv,
+                  const double *f, int max_n, void **out, int device = -1);
+void destroy_handle(Handle *h);
+// pointer classification: 0 = host, 1 = device / managed memory (its device in *dev)
+int ptr_location(const void *p, int *dev);
+// One product on one device object, operands anywhere: B (k x n, ld ldb) and C (m x n, ld ldc) may be host memory, memory of this
+// object's device, or memory of another device (then they are staged through this object's buffers).  fill_rows (>= m): rows
+// [m, fill_rows) of every column of C are written as zeros (the plain ABI passes ldc, like the reference's CPU path; a SNP shard
+// of a 'T' product passes its own row count so that it does not touch its neighbours' rows).  Asynchronous on the object's stream
+// unless sync; with timing the caller reads the events later with harvest_profile().
+int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, double *C, long ldc, long fill_rows, bool sync, bool timing);
+int gram_any(Handle *h, int n, const double *V, long ldv, double *out, long ldo, bool sync);
+void harvest_profile(Handle *h);
+int select_device();                       // honours HIP_DEVICE / CUDA_DEVICE; -1 + error when no device
+// SNP-sharded objects (mxa_multi.cpp)
+int multi_requested();                     // MIRACULIX_NUM_GPUS (>= 1)
+int multi_create(const uint8_t *plink, const uint8_t *plink_t, long snps, long indiv, const double *f, int max_n, int shards, void **out);
+int multi_create_from_bed(const char *base, long snps, long indiv, int max_n, int shards, void **out, double *f_out);
+int multi_gemm(void *obj, bool trans, int n, const double *B, long ldb, double *C, long ldc);
+int multi_gram(void *obj, int n, const double *V, long ldv, double *out, long ldo);
+void multi_freq(void *obj, double *f);
+void multi_destroy(void *obj);
+bool is_multi(const void *obj);
+// one SNP range of a .bed file -> object on `device` (rows [snp_begin, snp_end) are read, transposed and counted on the device)
+int bed_range_to_handle(const char *base, long snps_total, long indiv, long snp_begin, long snp_end, int max_n, int device, void **out,
+                        double *f_out_local);
+// C[r + j ldc] = sum_g parts[g][r + j m] (ascending g: fixed order), rows [m, fill_rows) zero
+constexpr int kMaxShards = 64;
+struct PartList { const double *p[kMaxShards]; int count; };
+int launch_reduce_parts(const PartList &parts, long m, int n, double *dC, long ldc, long fill_rows, hipStream_t s);
 
 // ---- error handling: print + remember (reference: cuda_utils.cu:83-90 prints "Internal error in function ...")
 void set_error(int code, const char *fmt, ...);
@@ -103,8 +138,11 @@ GemmPlan plan_gemm(long m, long k_pad, int n);
 int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, int mode, hipStream_t s);
 GemmPlan plan_lut(long m, long k_pad, int n);
 int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double *dP, const GemmPlan &p, hipStream_t s);
-int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC, long ldc, int mode_trans,
+// fill_rows: rows [m, fill_rows) of every column are zero-filled (fill_rows <= ldc)
+int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC, long ldc, long fill_rows, int mode_trans,
                   bool centered, const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s, const int *d_E = nullptr);
+// per-device one-time hipFuncSetAttribute(MaxDynamicSharedMemorySize): function attributes are per device, `mask` has one bit per device
+int ensure_dyn_lds(const void *func, int bytes, unsigned long long *mask);
 int launch_transpose_2bit(const uint8_t *d_in, long rows, long cols, uint8_t *d_out, hipStream_t s);
 int launch_allele_freq(const uint8_t *d_plink, long snps, long indiv, double *d_f, hipStream_t s);
 // crossproduct
@@ -115,7 +153,7 @@ int launch_sparse_times_plink(const uint8_t *dP, size_t pitch, long entries, int
                               double *dC_slab, long ldc, long e_base, long e_count, hipStream_t s);
 // opt-in engine (mxa_set_engine(1) / MXA_ENGINE=i8, mxa_gemm_i8.hip): whole product by exact int8 slicing of B.
 // Asynchronous on s; ev0/ev1 (optional) are recorded around the dominant kernel.
-int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, bool centered, const double *d_sumB,
+int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool centered, const double *d_sumB,
                    const double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out);
 
 }  // namespace mxa

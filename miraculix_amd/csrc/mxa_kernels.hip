@@ -24,6 +24,8 @@ namespace mxa {
 // staging: recode
 // =====================================================================================================
 // PLINK code c -> allele count z = max(c-1,0): 00->00, 01->00 (missing), 10->01, 11->10, SWAR on 16 fields.
+constexpr long kMaxBlocksPerLaunch = 1L << 23;   // x 256 threads = 2^31 threads per launch (the runtime's limit is 2^32 - 1)
+
 __device__ __forceinline__ uint32_t recode16(uint32_t w) {
   const uint32_t H = (w >> 1) & 0x55555555u, L = w & 0x55555555u;
   return ((H & L) << 1) | (H & ~L);
@@ -33,8 +35,9 @@ __device__ __forceinline__ uint32_t recode16(uint32_t w) {
 // dword loads when the address allows), and the 64 threads of a slab write one contiguous 1 KiB run of the tiled layout
 // (mxa_internal.h: byte b of row R -> ((R/256)*nslabs + b/32)*8192 + (R%256)*32 + b%32).
 __global__ void __launch_bounds__(256) k_recode(const uint8_t *__restrict__ src, size_t src_pitch, long src_row_bytes,
-                                                long nrows, long k, uint8_t *__restrict__ dst, long dst_row0, long nslabs, long rows_blocks) {
-  const long rblk = blockIdx.x % rows_blocks, sgrp = blockIdx.x / rows_blocks;
+                                                long nrows, long k, uint8_t *__restrict__ dst, long dst_row0, long nslabs, long rows_blocks, long blk0) {
+  const long bid = blk0 + blockIdx.x;
+  const long rblk = bid % rows_blocks, sgrp = bid / rows_blocks;
   const int rr = threadIdx.x >> 3, part = threadIdx.x & 7;
   const long r = rblk * 32 + rr;
   const long slab = sgrp * 4 + (part >> 1);
@@ -67,8 +70,11 @@ int launch_recode(const uint8_t *d_src, size_t src_pitch, long row0, long nrows,
   if (nrows <= 0) return 0;
   const long rows_blocks = (nrows + 31) / 32, slab_groups = (dst.nslabs + 3) / 4;
   const long grid = rows_blocks * slab_groups;
-  if (grid > 0x7fffffffL) { set_error(4, "internal: recode grid too large"); return 1; }
-  hipLaunchKernelGGL(k_recode, dim3((unsigned)grid), dim3(256), 0, s, d_src, src_pitch, (k + 3) / 4, nrows, k, dst.d, row0, dst.nslabs, rows_blocks);
+  // a launch may not exceed 2^32 threads (grid x block): larger grids are silently truncated by the runtime -> chunks of 2^23 blocks
+  for (long b0 = 0; b0 < grid; b0 += kMaxBlocksPerLaunch) {
+    const long nb = std::min(kMaxBlocksPerLaunch, grid - b0);
+    hipLaunchKernelGGL(k_recode, dim3((unsigned)nb), dim3(256), 0, s, d_src, src_pitch, (k + 3) / 4, nrows, k, dst.d, row0, dst.nslabs, rows_blocks, b0);
+  }
   MXA_HIP(hipGetLastError());
   return 0;
 }
@@ -475,18 +481,15 @@ GemmPlan plan_gemm(long m, long k_pad, int n) {
 template <int A, int C, int MODE>
 static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, hipStream_t s) {
   using Cfg = GemmCfg<A, C>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm<A, C, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds));
-    attr_set = true;
-  }
+  static unsigned long long attr_mask = 0;   // function attributes are per device
+  if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm<A, C, MODE>), Cfg::kLds, &attr_mask)) return 1;
   const long grid = (long)p.rowblocks * p.nchunks * p.splits;
   if (grid > 0x7fffffffL) { set_error(3, "grid too large"); return 1; }
   static const int xcd_order = [] { const char *e = getenv("MXA_XCD_ORDER"); return e ? atoi(e) : 1; }();   // 0: plain order (A/B measurement)
   static const bool diag_on = getenv("MXA_DIAG") != nullptr;
   if (diag_on && A == 8 && C == 8) {   // diagnostic instantiation: in-kernel clock + cycles per slab
-    static bool attr2 = false;
-    if (!attr2) { MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm<A, C, MODE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds)); attr2 = true; }
+    static unsigned long long attr2 = 0;
+    if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm<A, C, MODE, true>), Cfg::kLds, &attr2)) return 1;
     unsigned long long *d_diag = nullptr;
     MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_diag), sizeof(unsigned long long) * 5 * grid));
     hipLaunchKernelGGL((k_gemm<A, C, MODE, true>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBp, p.n_pad / 4, dP,
@@ -687,11 +690,8 @@ constexpr int kLutWaves = 8;   // 512 lanes = 512 rows per workgroup share one s
 template <int NV, int KS>
 static int launch_lut_t(const PackedMatrix &G, const double *dB, long ldb, int n, double *dP, const GemmPlan &p, hipStream_t s) {
   using Cfg = LutCfg<NV, KS, kLutWaves>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lut<NV, KS, kLutWaves>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::kLds));
-    attr_set = true;
-  }
+  static unsigned long long attr_mask = 0;
+  if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_lut<NV, KS, kLutWaves>), Cfg::kLds, &attr_mask)) return 1;
   const long grid = (long)p.rowblocks * p.splits;
   hipLaunchKernelGGL((k_lut<NV, KS, kLutWaves>), dim3((unsigned)grid), dim3(Cfg::kThreads), Cfg::kLds, s, G.d, G.pitch, dB, ldb, G.k, n, dP, p.m_pad,
                      p.rowblocks, p.slabs_total, p.slabs_per_split);
@@ -732,14 +732,14 @@ int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double 
 // =====================================================================================================
 // 'N' (mode_trans=0): C[i,j] = sum_s P + (-2 * sum_k f_k B[k,j])            (x=f, y=1: dgemm_compressed_cuda.cu:426-459)
 // 'T' (mode_trans=1): C[s,j] = sum_s P + (-2 * sum_i B[i,j]) * f_s           (x=1, y=f)
-// rows m..ldc-1 of every column are zero-filled like the reference CPU path does (5codesIntern.h:67).
+// rows m..fill_rows-1 of every column are zero-filled (plain ABI: fill_rows = ldc, like the reference CPU path, 5codesIntern.h:67).
 __global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, long m_pad, long p_rows, int n_pad, int splits, long m, int n,
-                                                double *__restrict__ Cout, long ldc, int mode_trans, int centered,
+                                                double *__restrict__ Cout, long ldc, long fill_rows, int mode_trans, int centered,
                                                 const double *__restrict__ sumB, const double *__restrict__ sumfB,
                                                 const double *__restrict__ f, const int *__restrict__ E, int back) {
   const int j = blockIdx.y;
   const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= ldc) return;
+  if (r >= fill_rows) return;
   double v = 0.0;
   if (r < m) {
     const size_t tile = (size_t)(r / p_rows), within = (size_t)(r % p_rows), ntiles = (size_t)(m_pad / p_rows);
@@ -753,12 +753,44 @@ __global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, lo
   Cout[r + (long)j * ldc] = v;
 }
 
-int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC, long ldc, int mode_trans, bool centered,
+int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC, long ldc, long fill_rows, int mode_trans, bool centered,
                   const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s, const int *d_E) {
-  dim3 grid((unsigned)((ldc + 255) / 256), n);
-  hipLaunchKernelGGL(k_finish, grid, dim3(256), 0, s, dP, p.m_pad, p.p_rows, p.n_pad, p.splits, m, n, dC, ldc, mode_trans, centered ? 1 : 0,
+  dim3 grid((unsigned)((fill_rows + 255) / 256), n);
+  hipLaunchKernelGGL(k_finish, grid, dim3(256), 0, s, dP, p.m_pad, p.p_rows, p.n_pad, p.splits, m, n, dC, ldc, fill_rows, mode_trans, centered ? 1 : 0,
                      d_sumB, d_sumfB, d_f, d_E, 1074 - kDenUp);
   MXA_HIP(hipGetLastError());
+  return 0;
+}
+
+
+// sum of per-shard partial results in ascending shard order (fixed order: bitwise reproducible), ld-padded store
+__global__ void __launch_bounds__(256) k_reduce_parts(PartList parts, long m, double *__restrict__ Cout, long ldc, long fill_rows) {
+  const int j = blockIdx.y;
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= fill_rows) return;
+  double v = 0.0;
+  if (r < m) {
+    v = parts.p[0][r + (size_t)j * m];
+    for (int g = 1; g < parts.count; g++) v += parts.p[g][r + (size_t)j * m];
+  }
+  Cout[r + (size_t)j * ldc] = v;
+}
+
+int launch_reduce_parts(const PartList &parts, long m, int n, double *dC, long ldc, long fill_rows, hipStream_t s) {
+  if (n <= 0 || parts.count <= 0) return 0;
+  dim3 grid((unsigned)((fill_rows + 255) / 256), n);
+  hipLaunchKernelGGL(k_reduce_parts, grid, dim3(256), 0, s, parts, m, dC, ldc, fill_rows);
+  MXA_HIP(hipGetLastError());
+  return 0;
+}
+
+int ensure_dyn_lds(const void *func, int bytes, unsigned long long *mask) {
+  int dev = 0;
+  MXA_HIP(hipGetDevice(&dev));
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (__atomic_load_n(mask, __ATOMIC_ACQUIRE) & bit) return 0;
+  MXA_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  __atomic_fetch_or(mask, bit, __ATOMIC_RELEASE);
   return 0;
 }
 
@@ -769,11 +801,12 @@ int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC
 // ALIGNED: both row pitches are multiples of 4 bytes -> dword loads and stores (4x fewer memory instructions).
 template <bool ALIGNED>
 __global__ void __launch_bounds__(256) k_transpose_2bit(const uint8_t *__restrict__ in, long rows, long cols,
-                                                        uint8_t *__restrict__ out, unsigned nbx) {
+                                                        uint8_t *__restrict__ out, long nbx, long blk0) {
   __shared__ uint8_t tile[64][20];
   const long bin = (cols + 3) / 4, bout = (rows + 3) / 4;
-  // 1-D grid (either dimension may exceed the 65535 limit of gridDim.y): block = by * nbx + bx
-  const long r0 = (long)(blockIdx.x / nbx) * 64, c0 = (long)(blockIdx.x % nbx) * 64;
+  // 1-D grid (either dimension may exceed the 65535 limit of gridDim.y): block = by * nbx + bx; blk0 = first block of this launch
+  const long bid = blk0 + blockIdx.x;
+  const long r0 = (bid / nbx) * 64, c0 = (bid % nbx) * 64;
   {
     const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
     const long byte0 = c0 / 4 + part * 4;
@@ -839,10 +872,11 @@ constexpr int kTrRows = 256, kTrCols = 512;            // genotypes per tile
 constexpr int kTrInPitch = kTrCols / 16 + 1;           // dwords per tile row in LDS (+1: conflict-free column reads)
 constexpr int kTrOutPitch = kTrRows / 16 + 1;
 
-__global__ void __launch_bounds__(256) k_transpose_2bit_tiled(const uint8_t *__restrict__ in, long rows, long cols, uint8_t *__restrict__ out, unsigned nbx) {
+__global__ void __launch_bounds__(256) k_transpose_2bit_tiled(const uint8_t *__restrict__ in, long rows, long cols, uint8_t *__restrict__ out, long nbx, long blk0) {
   __shared__ uint32_t lds[(kTrRows * kTrInPitch > kTrCols * kTrOutPitch) ? kTrRows * kTrInPitch : kTrCols * kTrOutPitch];
   const long bin = (cols + 3) / 4, bout = (rows + 3) / 4;   // multiples of 4 (checked by the launcher)
-  const long r0 = (long)(blockIdx.x / nbx) * kTrRows, c0 = (long)(blockIdx.x % nbx) * kTrCols;
+  const long bid = blk0 + blockIdx.x;
+  const long r0 = (bid / nbx) * kTrRows, c0 = (bid % nbx) * kTrCols;
   const long din = bin / 4, dout = bout / 4;                // dwords per row
   const uint32_t *in32 = reinterpret_cast<const uint32_t *>(in);
   uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
@@ -902,18 +936,22 @@ int launch_transpose_2bit(const uint8_t *d_in, long rows, long cols, uint8_t *d_
   const long bin = (cols + 3) / 4, bout = (rows + 3) / 4;
   const bool aligned = (bin % 4 == 0) && (bout % 4 == 0) && (reinterpret_cast<uintptr_t>(d_in) % 4 == 0) && (reinterpret_cast<uintptr_t>(d_out) % 4 == 0);
   static const bool no_tiled = getenv("MXA_TRANSPOSE_GENERIC") != nullptr;   // A/B measurement
+  // a launch may not exceed 2^32 threads: the grid is issued in chunks of 2^23 blocks (found by the 625k x 200k full-size test:
+  // 30.5 M blocks x 256 threads were silently truncated to the grid modulo 2^24)
   if (aligned && !no_tiled) {
     // fields beyond `rows` / `cols` inside the last dwords are zero in the input (PLINK padding) and come out as zero padding
     const long nbx = (cols + kTrCols - 1) / kTrCols, nby = (rows + kTrRows - 1) / kTrRows;
-    if (nbx * nby > 0x7fffffffL) { set_error(3, "mxa_transpose_2bit: matrix too large for one launch"); return 1; }
-    hipLaunchKernelGGL(k_transpose_2bit_tiled, dim3((unsigned)(nbx * nby)), dim3(256), 0, s, d_in, rows, cols, d_out, (unsigned)nbx);
+    for (long b0 = 0; b0 < nbx * nby; b0 += kMaxBlocksPerLaunch)
+      hipLaunchKernelGGL(k_transpose_2bit_tiled, dim3((unsigned)std::min(kMaxBlocksPerLaunch, nbx * nby - b0)), dim3(256), 0, s, d_in, rows, cols, d_out, nbx, b0);
     MXA_HIP(hipGetLastError());
     return 0;
   }
   const long nbx = (cols + 63) / 64, nby = (rows + 63) / 64;
-  if (nbx * nby > 0x7fffffffL) { set_error(3, "mxa_transpose_2bit: matrix too large for one launch"); return 1; }
-  if (aligned) hipLaunchKernelGGL(k_transpose_2bit<true>, dim3((unsigned)(nbx * nby)), dim3(256), 0, s, d_in, rows, cols, d_out, (unsigned)nbx);
-  else hipLaunchKernelGGL(k_transpose_2bit<false>, dim3((unsigned)(nbx * nby)), dim3(256), 0, s, d_in, rows, cols, d_out, (unsigned)nbx);
+  for (long b0 = 0; b0 < nbx * nby; b0 += kMaxBlocksPerLaunch) {
+    const unsigned nb = (unsigned)std::min(kMaxBlocksPerLaunch, nbx * nby - b0);
+    if (aligned) hipLaunchKernelGGL(k_transpose_2bit<true>, dim3(nb), dim3(256), 0, s, d_in, rows, cols, d_out, nbx, b0);
+    else hipLaunchKernelGGL(k_transpose_2bit<false>, dim3(nb), dim3(256), 0, s, d_in, rows, cols, d_out, nbx, b0);
+  }
   MXA_HIP(hipGetLastError());
   return 0;
 }

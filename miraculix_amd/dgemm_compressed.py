@@ -79,6 +79,23 @@ def init_compressed_from_bed(bed_path, max_ncol, snps=0, indiv=0):
     return obj_ref, f, s_out.value, i_out.value
 
 
+def init_compressed_from_bed_range(bed_path, snp_begin, snp_end, max_ncol, snps=0, indiv=0):
+    """SNP rows [snp_begin, snp_end) of a .bed file only (C entry mxa_bed2compressed_range): a rank of a one-process-per-GPU job
+    stages its own block without anybody holding the full matrices.  Returns (obj_ref, freq of the range)."""
+    L = _lib.check_library_handle()
+    obj_ref = ctypes.c_void_p(None)
+    f = np.zeros(snp_end - snp_begin, dtype=np.float64)
+    rc = L.mxa_bed2compressed_range(bed_path.encode(), int(snps), int(indiv), int(snp_begin), int(snp_end), int(max_ncol), ctypes.byref(obj_ref), _lib.ptr(f))
+    if rc != 0 or not obj_ref.value:
+        raise RuntimeError("mxa_bed2compressed_range failed: " + _lib.last_error()[1])
+    return obj_ref, f
+
+
+def num_shards(obj_ref):
+    """number of per-device objects behind a handle: > 1 for one created under MIRACULIX_NUM_GPUS > 1 (include/miraculix_amd.h)"""
+    return _lib.check_library_handle().mxa_num_shards(obj_ref)
+
+
 def init_compressed_shard(plink, plink_transposed, snps_total, indiv, snp_begin, snp_end, freq, max_ncol):
     """SNP-sharded variant (mxa_plink2compressed_shard): this object holds SNPs [snp_begin, snp_end) only."""
     obj_ref = ctypes.c_void_p(None)

@@ -43,6 +43,12 @@ def load_shared_library():
     L.snp_multiply_gpu.restype = ctypes.c_int
     L.mxa_bed2compressed.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     L.mxa_bed2compressed.restype = ctypes.c_int
+    L.mxa_bed2compressed_range.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]
+    L.mxa_bed2compressed_range.restype = ctypes.c_int
+    L.mxa_num_shards.argtypes = [ctypes.c_void_p]
+    L.mxa_num_shards.restype = ctypes.c_int
+    L.mxa_shard_bounds.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]
+    L.mxa_shard_bounds.restype = ctypes.c_int
     L.mxa_grm.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     L.mxa_grm.restype = ctypes.c_int
     L.mxa_ld.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]

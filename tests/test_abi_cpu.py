@@ -127,3 +127,26 @@ def test_bed_reader_rejects_bad_magic(built, tmp_path):
     rc = L.mxa_bed2compressed(str(p).encode(), 5, 8, 1, ctypes.byref(obj), None, None, None)
     assert rc == 1 and not obj.value
     assert "magic" in (L.mxa_last_error_string() or b"").decode()
+
+
+def test_shard_partition_covers_all_snps_at_multiples_of_4(built):
+    """mxa_shard_bounds (the partition behind MIRACULIX_NUM_GPUS, mxa_multi.cpp): contiguous, disjoint, covering, boundaries at
+    multiples of 4, empty blocks dropped, and identical to the Python-side rule (miraculix_amd.distributed.shard_bounds)"""
+    import miraculix_amd as m
+    from miraculix_amd.distributed import shard_bounds
+    L = m.load_shared_library()
+    for snps in (1, 3, 4, 10, 1003, 4096, 1_000_000, 5_000_001):
+        for shards in (1, 2, 3, 7, 8, 64):
+            b, e = ctypes.c_long(-1), ctypes.c_long(-1)
+            cnt = L.mxa_shard_bounds(snps, shards, 0, ctypes.byref(b), ctypes.byref(e))
+            assert 1 <= cnt <= shards
+            pos = 0
+            for g in range(cnt):
+                assert L.mxa_shard_bounds(snps, shards, g, ctypes.byref(b), ctypes.byref(e)) == cnt
+                assert b.value == pos and e.value > b.value and b.value % 4 == 0
+                assert (b.value, e.value) == shard_bounds(snps, shards, g)
+                pos = e.value
+            assert pos == snps
+            for g in range(cnt, shards):
+                pb, pe = shard_bounds(snps, shards, g)
+                assert pb == pe
