@@ -27,3 +27,37 @@ def test_bench_two_ranks_one_gpu_gloo():
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert "cpu_baseline" not in out                                       # rank 0 at N = 1 only
     assert out["opt_in_engine"]["max_colwise_rel_diff_vs_f64_engine"] <= 1e-11
+
+
+def _run_bench(extra, env=None):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--snps", "60002", "--indiv", "8000", "--ncol", "32"] + extra
+    r = subprocess.run(cmd, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-1500:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_line_is_complete():
+    """the N = 1 line at a small size: roofline (with traffic measured by the run's own rocprofv3 --pmc children, or null with the
+    reason), cpu_baseline with the core count and how it was obtained, the ABI end-to-end leg (host B / C, bitwise the
+    device-resident results) and the in-run parity checks against the CPU library and the dense oracle"""
+    out = _run_bench([])
+    assert out["n_gpus"] == 1 and out["unit"] == "GFLOP/s" and out["dtype"] == "f64" and out["vs_baseline"] is None
+    rf = out["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert (isinstance(rf["traffic"], float) and rf["traffic"] > 0 and rf["traffic_detail"]["launches"] == 2) or "skipped" in rf["traffic_detail"]
+    cb = out["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and "cores_counted_as" in cb
+    ab = out["abi_end_to_end"]
+    assert ab["bitwise_equal_to_device_resident_results"] is True and ab["max_GFLOPs"] >= ab["mean_GFLOPs"] > 0
+    ck = out["check"]
+    assert ck["gpu_T_rows_vs_cpu_library_max_rel_err"] <= 1e-11 and ck["gpu_N_64_sampled_rows_vs_dense_oracle_max_rel_err"] <= 1e-11
+
+
+def test_bench_inprocess_two_shards_behind_the_c_abi():
+    """python bench.py --gpus 2 without a launcher: the SNP shards live behind the C ABI (MIRACULIX_NUM_GPUS); on a one-GPU box the
+    two shards share the device (virtual shards)"""
+    out = _run_bench(["--gpus", "2", "--no-alt-engine"])
+    assert out["n_gpus"] == 2 and "behind the C ABI" in out["config"]["workload"]
+    assert out["check"]["adjoint_identity_max_rel_err"] <= 1e-10 and out["roofline"]["launches"] == 8
+    assert out["abi_end_to_end"]["bitwise_equal_to_device_resident_results"] is True
