@@ -201,18 +201,25 @@ int mxa_grm(const unsigned char *plink_transposed, int snps, int indiv, double *
             const double *allele_freq);
 int mxa_ld(const unsigned char *plink, int snps, int indiv, double *R, int is_plink_format, const double *allele_freq);
 
-/* multiply engine of dgemm_compressed (process-wide).  0 (default): fp64 on v_mfma_f64_4x4x4_4b_f64, the arithmetic of the
- * reference (fp64 FMAs).  1 (opt-in, also MXA_ENGINE=i8 in the environment): each column of B is split exactly into 7 balanced
- * radix-256 digits relative to the column's largest entry (32 / 16 digits for n = 1 / 2, where they are free), the digit
- * matrices are multiplied with the 0/1/2 genotypes on the int8 matrix cores with exact int32 accumulation, and the integer
- * results are recombined in fp64.  B is thereby represented to 2^-54 of each column's largest |entry| (fixed point per column,
- * not per element); results agree with engine 0 to ~1e-14 of
- * each result column's largest entry on the test problems, at ~4x the throughput.
- * 2 (MXA_ENGINE=small-n-i8): engine 1 for n <= 4 only -- there it is HBM-bound and 32 / 16 / 10 / 8 digits per column fit at no
- * cost (the CG / GBLUP iteration with n = 1: 2.5 ms instead of 3.6 ms per G*v on a 250k x 100k shard) -- engine 0 otherwise.
- * mxa_set_engine returns the previous value (an invalid argument leaves the engine unchanged). */
+/* multiply engine of dgemm_compressed (process-wide).
+ * 0 (default): fp64 on v_mfma_f64_4x4x4_4b_f64, the arithmetic of the reference (fp64 FMAs), for n >= 3.  For n <= 2 -- the CG /
+ *    GBLUP iteration, which is HBM-bound -- each column of B is split into balanced radix-256 digits (32 digits for n = 1, 16 for
+ *    n = 2), the 0/1/2 genotypes are multiplied with the digit planes on the int8 matrix cores with exact int32/int64 sums and the
+ *    planes are recombined in fp64, PROVIDED a per-call check on the device finds the split EXACT: every entry finite, and the
+ *    binary-exponent span of the non-zero entries of each column at most 201 (n = 1) / 73 (n = 2).  Then no bit of B is dropped,
+ *    the only roundings are the <= 31 additions of the recombination, and |error| <= 3.02 * 31 * 2^-53 * sum_k |z_k b_k| per
+ *    output -- tighter than the K * 2^-53 * sum_k |z_k b_k| of any fp64 FMA chain of length K >= 128.  If the check fails (or
+ *    K < 128) the fp64 pair-table kernel runs instead; results then and with engine 3 are fp64 lookup-add sums.
+ * 1 (opt-in, also MXA_ENGINE=i8 in the environment): the int8 slicing for every n with 7 digits (32 / 16 for n = 1 / 2) and NO
+ *    exactness check: B is represented to 2^-54 of each column's largest |entry| (fixed point per column, not per element);
+ *    results agree with engine 0 to ~1e-14 of each result column's largest entry on the test problems, at ~4x the throughput.
+ * 2 (MXA_ENGINE=small-n-i8): engine 1 for n <= 4 only, engine 0's fp64 path otherwise.
+ * 3 (MXA_ENGINE=f64-strict): fp64 arithmetic for every n (n <= 2: the pair-table kernel, never the int8 route).
+ * mxa_set_engine returns the previous value (an invalid argument leaves the engine unchanged).  mxa_last_path: kernel family of
+ * the most recent product: 0 = fp64 MFMA (k_gemm), 1 = fp64 pair tables (k_lut), 2 = int8 slicing (k_gemm_i8). */
 int mxa_set_engine(int engine);
 int mxa_get_engine(void);
+int mxa_last_path(void);
 
 /* measurement: HIP-event timing of the dominant kernel on the stream it is launched on.
  * mxa_profile_reset() clears the counters; after some dgemm_compressed / snp_multiply_gpu calls

@@ -32,6 +32,7 @@ static std::atomic<int> g_engine{[] {
   const char *e = getenv("MXA_ENGINE");
   if (e && std::string(e) == "i8") return 1;
   if (e && std::string(e) == "small-n-i8") return 2;
+  if (e && std::string(e) == "f64-strict") return 3;
   return 0;
 }()};
 
@@ -284,24 +285,32 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   {
     std::lock_guard<std::mutex> lk(g_prof_mutex);
     Geometry &geo = last_geometry();
-    geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c;
+    geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c; geo.path = use_lut ? 1 : 0;
   }
   double *d_sumB = w.d_colpart + (size_t)n * 128, *d_sumfB = d_sumB + n;
   static const int mode = [] { const char *e = getenv("MXA_GEMM_MODE"); return e ? atoi(e) : 2; }();
   const int engine = g_engine.load();
   const bool prof = g_profile_on && timing;
   if (prof && !h->ev0) { MXA_HIP(hipEventCreate(&h->ev0)); MXA_HIP(hipEventCreate(&h->ev1)); }
-  if (engine == 1 || (engine == 2 && n <= 4)) {   // opt-in: exact int8 slicing of B on the int8 matrix cores (mxa_gemm_i8.hip)
-    if (centered && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
+  if (centered && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
+  // Engine 0 at n <= 2 (the CG / GBLUP iteration, HBM-bound): the exact int8 slicing is used WHEN IT IS EXACT -- every column of B
+  // finite with an exponent span that fits its 32 (n = 1) / 16 (n = 2) digits, checked on the device per call (gemm_i8_device,
+  // guard).  Then B is represented without any error, all dot products are exact integers and the only roundings are the S - 1
+  // additions of the recombination: |error| <= 3.02 (S - 1) 2^-53 sum_k |z_k b_k|, below the K 2^-53 sum |z b| of
+  // an fp64 chain for K >= 128.  Otherwise (and always with engine 3) the fp64 pair-table kernel k_lut runs.
+  const bool auto_i8 = engine == 0 && n <= 2 && k >= 128;
+  if (engine == 1 || (engine == 2 && n <= 4) || auto_i8) {   // exact int8 slicing of B on the int8 matrix cores (mxa_gemm_i8.hip)
     int splits8 = 1;
-    if (gemm_i8_device(G, trans, n, dB, ldb, dC, ldc, fill_rows, centered, d_sumB, d_sumfB, h->d_f, w, s, prof ? h->ev0 : nullptr, prof ? h->ev1 : nullptr, &splits8)) return 1;
-    {
+    const int rc8 = gemm_i8_device(G, trans, n, dB, ldb, dC, ldc, fill_rows, centered, d_sumB, d_sumfB, h->d_f, w, s, prof ? h->ev0 : nullptr, prof ? h->ev1 : nullptr,
+                                   &splits8, auto_i8);
+    if (rc8 == 0) {
       std::lock_guard<std::mutex> lk(g_prof_mutex);
       Geometry &geo = last_geometry();
-      geo.splits = splits8; geo.a = 0; geo.c = 0;
+      geo.splits = splits8; geo.a = 0; geo.c = 0; geo.path = 2;
+      h->prof_pending = prof;
+      return 0;
     }
-    h->prof_pending = prof;
-    return 0;
+    if (rc8 != 2) return 1;   // 2: the guard declined (B not exactly representable): fp64 path below
   }
   // MODE 2 (default): genotype operand as the denormal z * 2^-1074 (one VALU per fragment instead of two); B scaled per column
   const int *d_E = nullptr;
@@ -316,7 +325,6 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     d_E = w.d_exp;
   }
   if (!use_lut && launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, d_E)) return 1;
-  if (centered && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
   if (prof) MXA_HIP(hipEventRecord(h->ev0, s));
   int rc = use_lut ? launch_lut(G, dB, ldb, n, w.d_P, p, s) : launch_gemm(G, w.d_Bp, w.d_P, p, mode, s);
   if (prof && !rc) { MXA_HIP(hipEventRecord(h->ev1, s)); h->prof_pending = true; }
@@ -606,7 +614,7 @@ int mxa_device_count(void) {
 }
 
 int mxa_set_engine(int engine) {
-  if (engine < 0 || engine > 2) return g_engine.load();
+  if (engine < 0 || engine > 3) return g_engine.load();
   return g_engine.exchange(engine);
 }
 int mxa_get_engine(void) { return g_engine.load(); }
@@ -616,6 +624,7 @@ void mxa_profile_get(int *launches, double *total_ms) {
   if (launches) *launches = profile().launches;
   if (total_ms) *total_ms = profile().total_ms;
 }
+int mxa_last_path(void) { return last_geometry().path; }
 void mxa_last_geometry(long *m, long *k, int *n, int *splits, int *a_tile, int *c_tile) {
   const Geometry &g = last_geometry();
   if (m) *m = g.m; if (k) *k = g.k; if (n) *n = g.n; if (splits) *splits = g.splits; if (a_tile) *a_tile = g.a; if (c_tile) *c_tile = g.c;

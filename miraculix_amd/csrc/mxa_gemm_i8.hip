@@ -426,13 +426,13 @@ static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const 
 // Whole product on the device; B, C device pointers; asynchronous on s.  The workspace (exponents, slices, partials) lives with the
 // handle and only grows.
 int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool centered, const double *d_sumB,
-                   const double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out) {
+                   const double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out, bool guard) {
   const long m = G.rows, k = G.k;
   const I8Plan p = plan_i8(m, G.k_pad, n);
   if (p.m_pad > G.rows_pad) { set_error(4, "internal: packed matrix smaller than the i8 plan"); return 1; }
   if (splits_out) *splits_out = p.splits;
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
-  const size_t part_bytes = up(sizeof(double) * 64 * n), e_bytes = up(sizeof(int) * n);
+  const size_t part_bytes = up(sizeof(double) * 128 * n), e_bytes = up(sizeof(int) * (n + 1));   // column maxima + minima; exponents + the guard flag
   const size_t bs_bytes = up((size_t)p.nchunks * p.T_total * p.NT * 1024);
   const size_t p_bytes = up(sizeof(int) * (size_t)p.splits * p.m_pad * p.e_pad);
   const size_t need = part_bytes + e_bytes + bs_bytes + p_bytes;
@@ -448,7 +448,19 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   int8_t *d_Bs = reinterpret_cast<int8_t *>(base + part_bytes + e_bytes);
   int *d_P = reinterpret_cast<int *>(base + part_bytes + e_bytes + bs_bytes);
 
-  if (launch_colexp(dB, ldb, k, n, d_part, d_E, 2, s)) return 1;   // E_j = e + 2: |b| * 2^-E_j < 1/4, inside the remainder range of the balanced digits
+  // E_j = e + 2: |b| * 2^-E_j < 1/4, inside the remainder range of the balanced digits
+  if (!guard) {
+    if (launch_colexp(dB, ldb, k, n, d_part, d_E, 2, s)) return 1;
+  } else {
+    // Exactness guard of the default small-n route.  With |b| = f 2^e, f in [1/2, 1), an entry is the integer m 2^(e-53);
+    // the last digit has weight 2^(E_j - 8S) = 2^(e_max + 2 - 8S).  Every entry is an exact multiple of it iff e_min - 53 >= e_max + 2 - 8S,
+    // i.e. the exponent span e_max - e_min <= 8S - 55; the recombination ldexp(t, E_j - 8(s+1)) stays normal iff e_max + 2 - 8S >= -1021.
+    int *d_flag = d_E + n, h_flag = 1;
+    if (launch_colexp(dB, ldb, k, n, d_part, d_E, 2, s, d_flag, 8 * p.S - 55, 8 * p.S - 1023)) return 1;
+    MXA_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    MXA_HIP(hipStreamSynchronize(s));
+    if (h_flag) return 2;
+  }
   if (p.NT * 32 != p.nc * p.S) MXA_HIP(hipMemsetAsync(d_Bs, 0, bs_bytes, s));   // expanded columns beyond nc*S are never written
   {
     const int ncols = p.nchunks * p.nc;

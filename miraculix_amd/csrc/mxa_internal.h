@@ -76,7 +76,7 @@ struct Profile {
 };
 Profile &profile();
 
-struct Geometry { long m = 0, k = 0; int n = 0, splits = 0, a = 0, c = 0; };
+struct Geometry { long m = 0, k = 0; int n = 0, splits = 0, a = 0, c = 0, path = 0; };   // path: 0 k_gemm, 1 k_lut, 2 k_gemm_i8
 Geometry &last_geometry();
 
 // ---- host-side engine entry points shared by mxa_api.cpp (single device) and mxa_multi.cpp (SNP shards over several devices)
@@ -126,7 +126,9 @@ int launch_recode(const uint8_t *d_src, size_t src_pitch, long row0, long nrows,
 // denormal-operand mode of k_gemm (MODE 2): B columns are scaled to just below 2^kDenUp, the genotype operand is z * 2^-1074
 constexpr int kDenUp = 900;
 // E[j] = binary exponent of the largest |entry| of column j (frexp convention) + bias; d_part: 64 * n doubles of scratch
-int launch_colexp(const double *dB, long ldb, long k, int n, double *d_part, int *d_E, int bias, hipStream_t s);
+// d_flag (nullable, device int): range guard of the exact int8 slicing, see k_colexp_final; then d_part needs 128 * n doubles
+int launch_colexp(const double *dB, long ldb, long k, int n, double *d_part, int *d_E, int bias, hipStream_t s, int *d_flag = nullptr, int max_span = 0,
+                  int min_emax = 0);
 // d_E (nullable): per-column exponents for the denormal-operand mode
 int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k_pad, int n_pad, int c, hipStream_t s, const int *d_E = nullptr);
 int launch_colsums(const double *dB, long ldb, long k, int n, const double *d_f /*nullable*/, double *d_part,
@@ -153,7 +155,9 @@ int launch_sparse_times_plink(const uint8_t *dP, size_t pitch, long entries, int
                               double *dC_slab, long ldc, long e_base, long e_count, hipStream_t s);
 // opt-in engine (mxa_set_engine(1) / MXA_ENGINE=i8, mxa_gemm_i8.hip): whole product by exact int8 slicing of B.
 // Asynchronous on s; ev0/ev1 (optional) are recorded around the dominant kernel.
+// guard: first check on the device that every column of B is represented EXACTLY by the slicing (finite, dynamic range inside the
+// digits, no underflow in the recombination); if not, nothing is computed and 2 is returned (the caller takes the fp64 path).
 int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool centered, const double *d_sumB,
-                   const double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out);
+                   const double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out, bool guard = false);
 
 }  // namespace mxa

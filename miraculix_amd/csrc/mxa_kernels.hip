@@ -109,22 +109,31 @@ __global__ void __launch_bounds__(256) k_pack_B(const double *__restrict__ B, lo
 }
 
 // ---- per-column binary exponent: E[j] = e + bias with max_k |B[k,j]| = f * 2^e, f in [0.5, 1)  (0 + bias for a zero or non-finite column)
-__global__ void __launch_bounds__(256) k_colmax_partial(const double *__restrict__ B, long ldb, long k, double *__restrict__ part) {
+// part[j*64 + c] = max |b| of chunk c (inf if a non-finite entry was seen); part[(n + j)*64 + c] = smallest NON-ZERO |b| of the chunk
+// (inf if there is none) when want_min.
+__global__ void __launch_bounds__(256) k_colmax_partial(const double *__restrict__ B, long ldb, long k, double *__restrict__ part, int n, int want_min) {
   const int j = blockIdx.y, c = blockIdx.x;
   const long per = (k + 63) / 64;
   const long c0 = c * per, c1 = std::min<long>(k, c0 + per);
-  double m = 0.0;
+  const double inf = __longlong_as_double(0x7ff0000000000000ll);
+  double m = 0.0, lo = inf;
   for (long r = c0 + threadIdx.x; r < c1; r += 256) {
     const double a = fabs(B[r + (long)j * ldb]);
-    m = (a <= 1.7976931348623157e308) ? fmax(m, a) : __longlong_as_double(0x7ff0000000000000ll);   // NaN counts as non-finite too (fmax would drop it)
+    m = (a <= 1.7976931348623157e308) ? fmax(m, a) : inf;   // NaN counts as non-finite too (fmax would drop it)
+    if (a > 0.0) lo = fmin(lo, a);
   }
-  __shared__ double sh[256];
-  sh[threadIdx.x] = m;
+  __shared__ double sh[256], sl[256];
+  sh[threadIdx.x] = m; sl[threadIdx.x] = lo;
   __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + w]); __syncthreads(); }
-  if (threadIdx.x == 0) part[(size_t)j * 64 + c] = sh[0];
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + w]); sl[threadIdx.x] = fmin(sl[threadIdx.x], sl[threadIdx.x + w]); }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[(size_t)j * 64 + c] = sh[0]; if (want_min) part[((size_t)n + j) * 64 + c] = sl[0]; }
 }
-__global__ void k_colexp_final(const double *__restrict__ part, int n, int bias, int *__restrict__ E) {
+// range guard (flag != nullptr): *flag |= 1 unless every column is finite, its largest exponent e_max >= min_emax, and its smallest
+// non-zero entry has exponent e_min >= e_max - max_span (then every entry is an exact multiple of the last digit of the int8 slicing)
+__global__ void k_colexp_final(const double *__restrict__ part, int n, int bias, int *__restrict__ E, int *__restrict__ flag, int max_span, int min_emax) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   double m = 0.0;
@@ -132,10 +141,22 @@ __global__ void k_colexp_final(const double *__restrict__ part, int n, int bias,
   int e = 0;
   if (m > 0.0 && isfinite(m)) (void)frexp(m, &e);
   E[j] = e + bias;
+  if (flag) {
+    bool ok = isfinite(m);
+    if (ok && m > 0.0) {
+      double lo = m;
+      for (int c = 0; c < 64; c++) lo = fmin(lo, part[((size_t)n + j) * 64 + c]);
+      int el = 0;
+      (void)frexp(lo, &el);
+      ok = e >= min_emax && el >= e - max_span;
+    }
+    if (!ok) atomicOr(flag, 1);
+  }
 }
-int launch_colexp(const double *dB, long ldb, long k, int n, double *d_part, int *d_E, int bias, hipStream_t s) {
-  hipLaunchKernelGGL(k_colmax_partial, dim3(64, n), dim3(256), 0, s, dB, ldb, k, d_part);
-  hipLaunchKernelGGL(k_colexp_final, dim3((n + 63) / 64), dim3(64), 0, s, d_part, n, bias, d_E);
+int launch_colexp(const double *dB, long ldb, long k, int n, double *d_part, int *d_E, int bias, hipStream_t s, int *d_flag, int max_span, int min_emax) {
+  if (d_flag) MXA_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), s));
+  hipLaunchKernelGGL(k_colmax_partial, dim3(64, n), dim3(256), 0, s, dB, ldb, k, d_part, n, d_flag ? 1 : 0);
+  hipLaunchKernelGGL(k_colexp_final, dim3((n + 63) / 64), dim3(64), 0, s, d_part, n, bias, d_E, d_flag, max_span, min_emax);
   MXA_HIP(hipGetLastError());
   return 0;
 }

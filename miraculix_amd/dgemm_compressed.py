@@ -20,18 +20,23 @@ def set_options(use_gpu=True, cores=0, not_center=False, variant=0, verbose=1):
         raise RuntimeError("setOptions_compressed failed: " + _lib.last_error()[1])
 
 
-_ENGINES = {"f64": 0, "i8": 1, "small-n-i8": 2}
+_ENGINES = {"f64": 0, "i8": 1, "small-n-i8": 2, "f64-strict": 3}
 
 
 def set_engine(name):
-    """Additive (no reference counterpart): 'f64' = fp64 matrix cores (default), 'i8' = exact int8 slicing of B on the int8
-    matrix cores, 'small-n-i8' = 'i8' for n <= 4 and 'f64' otherwise (include/miraculix_amd.h, mxa_set_engine).  Returns the
-    previous engine's name."""
+    """Additive (no reference counterpart): 'f64' = default (fp64 matrix cores; for n <= 2 the exact int8 slicing when a per-call
+    check proves it exact, else fp64 pair tables), 'i8' = int8 slicing of B for every n, 'small-n-i8' = 'i8' for n <= 4,
+    'f64-strict' = fp64 arithmetic for every n (include/miraculix_amd.h, mxa_set_engine).  Returns the previous engine's name."""
     L = _lib.check_library_handle()
     if name not in _ENGINES:
-        raise ValueError("engine must be 'f64', 'i8' or 'small-n-i8'")
+        raise ValueError("engine must be one of " + ", ".join(_ENGINES))
     prev = L.mxa_set_engine(_ENGINES[name])
-    return {0: "f64", 1: "i8", 2: "small-n-i8"}[prev]
+    return {v: k for k, v in _ENGINES.items()}[prev]
+
+
+def last_path():
+    """kernel family of the most recent product: 'k_gemm' (fp64 MFMA), 'k_lut' (fp64 pair tables) or 'k_gemm_i8' (int8 slicing)"""
+    return {0: "k_gemm", 1: "k_lut", 2: "k_gemm_i8"}[_lib.check_library_handle().mxa_last_path()]
 
 
 def check_dimensions(plink, snps, indiv):
