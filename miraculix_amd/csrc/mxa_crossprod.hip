@@ -1,17 +1,23 @@
-// mxa_crossprod.hip -- integer crossproduct M = X * X^T on the int8 matrix cores (v_mfma_i32_32x32x32_i8).
+// mxa_crossprod.hip -- integer crossproduct M = X * X^T on the matrix cores, exact.
 //
 // Replaces src/cuda/snp_multiply_cuda.cu:38-382 of the reference (CUTLASS u4 TensorOp GEMM with the two-MMA 2-bit trick
 // snp_multiply_cuda.h:121-199, per-tile PCIe re-uploads, host int32->double mirror loop) with a device-resident design:
-// X is staged once (2 bits per value, padded pitch), every upper-triangular 256x256 tile is one workgroup, the packed
-// rows go HBM -> LDS by LDS-DMA, each wave unpacks its 2-bit words to int8 fragments in registers, accumulates exact
-// int32, and the epilogue converts to fp64 and writes the tile and its mirror image.  Exact for any input: int32 holds
-// 9*K for K < 2.3e8.
+// X is staged once (2 bits per value, the 256-row x 32-byte tiled layout of mxa_internal.h), every upper-triangular 256x256 tile
+// is one workgroup, the packed rows go HBM -> LDS by lane-linear LDS-DMA, each wave unpacks its 2-bit words in registers and the
+// epilogue converts to fp64 and writes the tile and its mirror image.  Two exact engines:
+//   k_crossprod_f4  (default)  v_mfma_scale_f32_32x32x64_f8f6f4 with FP4 (e2m1) operands: a 2-bit value z in {0..3} in the low bits
+//                   of a nibble IS the e2m1 number z/2, so the unpack is 3 VALU per 16 values (two masks and a shift) and the
+//                   instruction runs at twice the int8 rate (tools/mfma_f4_probe.hip: exact, 32.8 cycles, 8.3 Pop/s bare loop).
+//                   Products are multiples of 1/4; the fp32 accumulator is exact while sum z z' < 2^24, i.e. for K < 1 864 135 with
+//                   values up to 3 and K < 4 194 304 when the staged matrix holds no 3 (checked while staging).
+//   k_crossprod2    (longer K)  v_mfma_i32_32x32x32_i8, 7 VALU per 16 values, exact int32 for K < 2.3e8.
 #include "../../include/miraculix_amd.h"
 #include "mxa_internal.h"
 #include <atomic>
 #include <thread>
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 namespace mxa {
@@ -39,10 +45,11 @@ __global__ void __launch_bounds__(256) k_plink_lut(uint32_t *__restrict__ d, siz
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ndwords; i += (size_t)gridDim.x * blockDim.x) d[i] = plink_lut4(d[i]);
 }
 
-// copy rows (src pitch arbitrary) into the padded layout (pitch multiple of 32 B), optionally applying the table;
-// padding bytes/rows stay zero (the buffer is memset first)
+// copy rows (src pitch arbitrary) into the tiled layout (mxa_internal.h: byte b of row r -> ((r/256)*nslabs + b/32)*8192 + (r%256)*32
+// + b%32), optionally applying the table; padding bytes/rows stay zero (the buffer is memset first).  *has3 |= 1 when a staged field
+// holds the value 3 (raw 2-bit input, or a byte with a missing pair under the reference's table).
 __global__ void __launch_bounds__(256) k_xstage(const uint8_t *__restrict__ src, size_t src_pitch, long row_bytes, long nrows,
-                                                uint8_t *__restrict__ dst, size_t dst_pitch, long dst_row0, int apply_lut) {
+                                                uint8_t *__restrict__ dst, long nslabs, long dst_row0, int apply_lut, int *__restrict__ has3) {
   const long dpr = (row_bytes + 3) / 4;
   const long total = nrows * dpr;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -52,7 +59,9 @@ __global__ void __launch_bounds__(256) k_xstage(const uint8_t *__restrict__ src,
     for (int u = 0; u < 4; u++)
       if (b + u < row_bytes) { w |= (uint32_t)p[u] << (8 * u); keep |= 0xFFu << (8 * u); }
     if (apply_lut) w = plink_lut4(w) & keep;
-    *reinterpret_cast<uint32_t *>(dst + (size_t)(dst_row0 + r) * dst_pitch + b) = w;
+    if (w & (w >> 1) & 0x55555555u) atomicOr(has3, 1);
+    const long R = dst_row0 + r;
+    *reinterpret_cast<uint32_t *>(dst + ((size_t)(R / kTileRows) * nslabs + (size_t)(b / kSlabBytes)) * kTileBytes + (size_t)(R % kTileRows) * kSlabBytes + b % kSlabBytes) = w;
   }
 }
 
@@ -73,6 +82,43 @@ __device__ __forceinline__ v4i unpack16(uint32_t w) {
   return r;
 }
 
+// Epilogue shared by both engines.  32x32 C/D map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); element (gi, gj) = M[gi][gj].
+// The output holds columns [c0, ..) of M with leading dimension ld (whole matrix: c0 = 0, ld = n).
+// Direct image: M[gj, gi] at ans[gj + (gi-c0)*ld], lanes run along gj (256-byte segments).  Mirror image M[gi, gj] at
+// ans[gi + (gj-c0)*ld]: the tile is transposed through a per-wave LDS scratch (row stride 33 doubles: conflict-free both ways)
+// so its lanes run along gi as well.  AccT = v16i: exact int32 sums; v16f: sums of z z' / 4 (FP4 engine), exact, times 4.
+typedef float v16f __attribute__((ext_vector_type(16)));
+template <typename AccT>
+__device__ __forceinline__ void xprod_store(const AccT (&acc)[4][4], char *smem, int wave, int lane, int wi, int wj, long i0, long j0, int images, long n,
+                                            double *__restrict__ ans, long ld, long c0) {
+  double *scratch = reinterpret_cast<double *>(smem) + wave * (32 * 33);   // the DMA ring is dead after the last barrier
+  const int col = lane & 31, hh = lane >> 5, rq = 4 * hh;
+  constexpr double scale = __is_same(AccT, v16f) ? 4.0 : 1.0;
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const long gi_base = i0 + wi * 128 + a * 32, gj_base = j0 + wj * 128 + b * 32;
+      const long gj = gj_base + col;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + rq;
+        const double v = (double)acc[a][b][r] * scale;
+        if ((images & 1) && gi_base + row < n && gj < n) ans[(size_t)gj + (size_t)(gi_base + row - c0) * ld] = v;
+        scratch[row * 33 + col] = v;
+      }
+      if (images & 2) {
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+          const int cc = 2 * it + hh;                       // column of the tile = gj offset; lanes (lane&31) run along gi
+          const double v = scratch[col * 33 + cc];
+          const long gi = gi_base + col, gjj = gj_base + cc;
+          if (gi < n && gjj < n) ans[(size_t)gi + (size_t)(gjj - c0) * ld] = v;
+        }
+      }
+    }
+}
+
 // 4 waves, one per SIMD, wave tile 128 x 128 (16 accumulator tiles = 256 registers), 3-deep LDS-DMA ring with a counted vmcnt.
 // Per K-step of 32 genotypes a wave unpacks 8 fragments (56 VALU) for 16 MFMAs (512 MFMA cycles).  (The first version used 8
 // waves with 128 x 64 wave tiles -- 6 fragments per 8 MFMAs -- and stalled at 43-54 % of the int8 peak on that VALU density.)
@@ -85,7 +131,7 @@ __device__ __forceinline__ void xdma16_s(const void *sbase, uint32_t voff, uint3
 
 template <bool DIAG>
 __global__ void __launch_bounds__(256, 1)
-k_crossprod2(const uint8_t *__restrict__ X, size_t pitch, int stages, const int4 *__restrict__ tiles, long n, double *__restrict__ ans,
+k_crossprod2(const uint8_t *__restrict__ X, long nslabs, int stages, const int4 *__restrict__ tiles, long n, double *__restrict__ ans,
              long ld, long c0, unsigned long long *__restrict__ diag) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -95,8 +141,10 @@ k_crossprod2(const uint8_t *__restrict__ X, size_t pitch, int stages, const int4
   if (t.z == 0) return;                         // padding entry of the XCD-aware tile order (whole workgroup, before any barrier)
   const long i0 = (long)t.x * kXT, j0 = (long)t.y * kXT;
   const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
-  const uint32_t v_lane = (uint32_t)(lane >> 1) * (uint32_t)pitch + (lane & 1) * 16;
-  const char *Xb = reinterpret_cast<const char *>(X);
+  const uint32_t v_lane = (uint32_t)lane * 16;
+  // tiled layout: the 256 rows of operand block t at stage s are the contiguous 8 KiB tile (t, s): lane-linear 1 KiB DMA units
+  const char *XI = reinterpret_cast<const char *>(X) + (size_t)t.x * nslabs * kTileBytes;
+  const char *XJ = reinterpret_cast<const char *>(X) + (size_t)t.y * nslabs * kTileBytes;
 
   // 16 units of 1 KiB per stage (8 per operand), 4 per wave: unit u = wave + 4*i
   auto issue = [&](int stage, int buf) {
@@ -104,8 +152,7 @@ k_crossprod2(const uint8_t *__restrict__ X, size_t pitch, int stages, const int4
     for (int i = 0; i < 4; i++) {
       const int u = wave + 4 * i;
       const int op = u >> 3, uu = u & 7;
-      const long row = (op ? j0 : i0) + uu * 32;
-      xdma16_s(Xb + (size_t)row * pitch + (size_t)stage * kXStageBytes, v_lane, lds0 + buf * kXBufBytes + op * kXOpBytes + uu * 1024);
+      xdma16_s((op ? XJ : XI) + (size_t)stage * kTileBytes + uu * 1024, v_lane, lds0 + buf * kXBufBytes + op * kXOpBytes + uu * 1024);
     }
   };
 
@@ -192,36 +239,150 @@ k_crossprod2(const uint8_t *__restrict__ X, size_t pitch, int stages, const int4
     if (threadIdx.x == 0 && diag) { diag[2 * (size_t)blockIdx.x] = t1 - t0; diag[2 * (size_t)blockIdx.x + 1] = r1 - r0; }
   }
 
-  // epilogue.  32x32 C/D map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); element (gi, gj) = M[gi][gj].
-  // The output holds columns [c0, ..) of M with leading dimension ld (whole matrix: c0 = 0, ld = n).
-  // Direct image: M[gj, gi] at ans[gj + (gi-c0)*ld], lanes run along gj (256-byte segments).  Mirror image M[gi, gj] at
-  // ans[gi + (gj-c0)*ld]: the tile is transposed through a per-wave LDS scratch (row stride 33 doubles: conflict-free both ways)
-  // so its lanes run along gi as well.
-  double *scratch = reinterpret_cast<double *>(smem) + wave * (32 * 33);   // the DMA ring is dead after the last barrier
-  const int col = lane & 31, hh = lane >> 5, rq = 4 * hh;
+  xprod_store<v16i>(acc, smem, wave, lane, wi, wj, i0, j0, t.z, n, ans, ld, c0);
+}
+
+// ---- FP4 engine ----------------------------------------------------------------------------------------------------------------
+// Same tiling, ring and pipeline as k_crossprod2; per stage of 128 genotypes TWO K-steps of 64 (v_mfma_scale_f32_32x32x64_f8f6f4, FP4
+// operands, unit scales).  Lane (row r = lane&31, K half h = lane>>5) reads 16 bytes = 64 genotypes of its row per stage; K-step ks uses
+// dwords 2ks, 2ks+1 of them.  A dword of 16 two-bit values z becomes two dwords of 8 nibbles 00zz -- the e2m1 numbers z/2 -- by
+// (w & 0x33333333) and ((w >> 2) & 0x33333333): 6 VALU per fragment of 32 values, 48 per K-step of 16 MFMAs (the int8 engine: 56 VALU per
+// 16 MFMAs of HALF the K).  The K order inside a fragment is permuted identically for both operands, so the dot product is unchanged.
+typedef int v8i __attribute__((ext_vector_type(8)));
+constexpr int kF4Bufs = 8;                        // ring depth of the FP4 kernel
+constexpr int kF4Lds = kF4Bufs * kXBufBytes;      // 128 KiB (one workgroup per CU: 256 accumulator registers per lane)
+__device__ __forceinline__ v4i unpack_f4(uint32_t w0, uint32_t w1) {
+  v4i r;
+  r[0] = (int)(w0 & 0x33333333u);
+  r[1] = (int)((w0 >> 2) & 0x33333333u);
+  r[2] = (int)(w1 & 0x33333333u);
+  r[3] = (int)((w1 >> 2) & 0x33333333u);
+  return r;
+}
+__device__ __forceinline__ v16f mfma_f4(const v4i &a, const v4i &b, const v16f &c) {
+  const v8i a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, b8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};   // FP4 operands occupy 4 of the 8 registers
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);   // cbsz = blgp = 4: e2m1; scales 2^0
+}
+
+// EXP (diagnostic instantiations only, results are wrong): 1 = no unpack VALU; 2 = no DMA / barrier / LDS reads inside the loop;
+// 3 = barrier only; 4 = DMA + LDS reads without the barrier; 5 = barrier + DMA, no LDS reads; 6 = barrier + LDS reads, no DMA
+template <bool DIAG, int EXP = 0>
+__global__ void __launch_bounds__(256, 1)
+k_crossprod_f4(const uint8_t *__restrict__ X, long nslabs, int stages, const int4 *__restrict__ tiles, long n, double *__restrict__ ans,
+               long ld, long c0, unsigned long long *__restrict__ diag) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wi = wave >> 1, wj = wave & 1;
+  const int4 t = tiles[blockIdx.x];
+  if (t.z == 0) return;                         // padding entry of the XCD-aware tile order (whole workgroup, before any barrier)
+  const long i0 = (long)t.x * kXT, j0 = (long)t.y * kXT;
+  const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
+  const uint32_t v_lane = (uint32_t)lane * 16;
+  const char *XI = reinterpret_cast<const char *>(X) + (size_t)t.x * nslabs * kTileBytes;
+  const char *XJ = reinterpret_cast<const char *>(X) + (size_t)t.y * nslabs * kTileBytes;
+  auto issue = [&](int stage, int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int u = wave + 4 * i;
+      const int op = u >> 3, uu = u & 7;
+      xdma16_s((op ? XJ : XI) + (size_t)stage * kTileBytes + uu * 1024, v_lane, lds0 + buf * kXBufBytes + op * kXOpBytes + uu * 1024);
+    }
+  };
+
+  v16f acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; a++)
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-      const long gi_base = i0 + wi * 128 + a * 32, gj_base = j0 + wj * 128 + b * 32;
-      const long gj = gj_base + col;
+    for (int b = 0; b < 4; b++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int row = (r & 3) + 8 * (r >> 2) + rq;
-        const double v = (double)acc[a][b][r];
-        if ((t.z & 1) && gi_base + row < n && gj < n) ans[(size_t)gj + (size_t)(gi_base + row - c0) * ld] = v;
-        scratch[row * 33 + col] = v;
-      }
-      if (t.z & 2) {
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  const int a_off = (wi * 128 + (lane & 31)) * kXStageBytes + (lane >> 5) * 16;
+  const int b_off = kXOpBytes + (wj * 128 + (lane & 31)) * kXStageBytes + (lane >> 5) * 16;
+
+  // Ring of NB buffers (a stage lasts only ~0.5 us at the FP4 rate).  Stages 0 .. NB-1 are in flight at the start; at the start of stage s
+  // the words of stage s are already in registers, so its buffer takes stage s + NB, and stage s + 1 is waited for (stages s+2 .. s+NB-1 stay
+  // in flight).
+  constexpr int NB = kF4Bufs;
 #pragma unroll
-        for (int it = 0; it < 16; it++) {
-          const int cc = 2 * it + hh;                       // column of the tile = gj offset; lanes (lane&31) run along gi
-          const double v = scratch[col * 33 + cc];
-          const long gi = gi_base + col, gjj = gj_base + cc;
-          if (gi < n && gjj < n) ans[(size_t)gi + (size_t)(gjj - c0) * ld] = v;
-        }
+  for (int i = 0; i < NB; i++) if (i < stages) issue(i, i);
+  if (stages >= NB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NB - 1)) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  unsigned long long t0 = 0, r0 = 0;
+  if (DIAG) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+  // Software pipeline in K-steps t = 2 s + ks (a stage has two K-steps of 64 genotypes):
+  //   during K-step t the wave (1) issues the ds_read_b64 of the packed words of K-step t+2 into word set W[t%2], (2) unpacks the words of
+  //   K-step t+1 (read during t-1, word set W[(t+1)%2]) into fragment set F[(t+1)%2], 3 VALU after every MFMA, and (3) issues the 16 MFMAs
+  //   of K-step t from fragment set F[t%2].  Neither an LDS latency nor a VALU result is ever waited for, and no register set is copied
+  //   (the period of the alternation, two K-steps, is exactly one stage, so the stage loop needs no unrolling).
+  //   Stage start: the words of stage s were all read during stage s-1, so after the barrier buffer s%NB takes stage s+NB; stage s+1
+  //   must have landed (its words are read during this stage); stages s+2 .. s+NB-1 stay in flight.
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 wa0[4], wb0[4], wa1[4], wb1[4];      // W[0] / W[1]: words of an even / odd K-step, 4 A and 4 B sub-blocks of 32 rows
+  v4i fa0[4], fb0[4], fa1[4], fb1[4];        // F[0] / F[1]
+  auto unpack = [](const u32x2 &w) -> v4i {
+    if (EXP == 1) { v4i r = {(int)w.x, (int)w.y, (int)w.x, (int)w.y}; return r; }
+    return unpack_f4(w.x, w.y);
+  };
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    wa0[a] = *reinterpret_cast<const u32x2 *>(smem + a_off + a * 32 * kXStageBytes);
+    wb0[a] = *reinterpret_cast<const u32x2 *>(smem + b_off + a * 32 * kXStageBytes);
+    wa1[a] = *reinterpret_cast<const u32x2 *>(smem + a_off + a * 32 * kXStageBytes + 8);
+    wb1[a] = *reinterpret_cast<const u32x2 *>(smem + b_off + a * 32 * kXStageBytes + 8);
+  }
+#pragma unroll
+  for (int a = 0; a < 4; a++) { fa0[a] = unpack(wa0[a]); fb0[a] = unpack(wb0[a]); fa1[a] = fa0[a]; fb1[a] = fb0[a]; }
+  int buf = 0;
+  // K-step: MFMAs from (FA, FB); unpack (WAU, WBU) -> (FAN, FBN); read the words at LDS address RD (+ sub-block) into (WAR, WBR)
+#define MXA_F4_KSTEP(FA, FB, WAU, WBU, FAN, FBN, WAR, WBR, RD)                                                                      \
+  {                                                                                                                                        \
+    if (EXP != 2 && EXP != 3 && EXP != 5) { /* unconditional (branch-free): after the last stage the reads hit a valid buffer and are unused */ \
+      _Pragma("unroll") for (int a = 0; a < 4; a++) {                                                                                      \
+        WAR[a] = *reinterpret_cast<const u32x2 *>((RD) + a_off + a * 32 * kXStageBytes);                                                   \
+        WBR[a] = *reinterpret_cast<const u32x2 *>((RD) + b_off + a * 32 * kXStageBytes);                                                   \
+      }                                                                                                                                    \
+    }                                                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                                                     \
+    _Pragma("unroll") for (int a = 0; a < 4; a++) {                                                                                        \
+      FAN[a] = unpack(WAU[a]);                                                                                                             \
+      FBN[a] = unpack(WBU[a]);                                                                                                             \
+      _Pragma("unroll") for (int b = 0; b < 4; b++) acc[a][b] = mfma_f4(FA[a], FB[b], acc[a][b]);                                          \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                                                   \
+    }                                                                                                                                      \
+  }
+  for (int s = 0; s < stages; s++) {
+    const bool more = s + 1 < stages;
+    const char *nxt = smem + buf * kXBufBytes;
+    if (EXP != 2 && more) {
+      if (EXP != 3 && EXP != 6) {
+        if (s + NB - 1 < stages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NB - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of buffer s (issued a K-step ago) are complete before the buffer is refilled
+      if (EXP != 4) __syncthreads();
+      if (EXP != 3 && EXP != 6 && s + NB < stages) issue(s + NB, buf);
+      buf = buf == NB - 1 ? 0 : buf + 1;
+      nxt = smem + buf * kXBufBytes;
     }
+    // t = 2s:   MFMAs F[0]; unpack W[1] (K-step 1 of this stage) -> F[1]; read K-step 0 of stage s+1 -> W[0]
+    MXA_F4_KSTEP(fa0, fb0, wa1, wb1, fa1, fb1, wa0, wb0, nxt)
+    // t = 2s+1: MFMAs F[1]; unpack W[0] (K-step 0 of stage s+1) -> F[0]; read K-step 1 of stage s+1 -> W[1]
+    MXA_F4_KSTEP(fa1, fb1, wa0, wb0, fa0, fb0, wa1, wb1, nxt + 8)
+  }
+#undef MXA_F4_KSTEP
+  __syncthreads();   // all waves are done with the ring before it is reused as the epilogue scratch
+  if (DIAG) {
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && diag) { diag[2 * (size_t)blockIdx.x] = t1 - t0; diag[2 * (size_t)blockIdx.x + 1] = r1 - r0; }
+  }
+  xprod_store<v16f>(acc, smem, wave, lane, wi, wj, i0, j0, t.z, n, ans, ld, c0);
 }
 
 int launch_plink_lut(uint8_t *d, size_t nbytes, hipStream_t s) {
@@ -261,15 +422,78 @@ static void xcd_order_tiles(std::vector<int4> &tiles, int nb, int sr) {
   tiles.swap(inter);
 }
 
-// X: device, padded: rows_pad (multiple of 256) x pitch (multiple of 32 B), zero padded
+// ---- host side ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct XEvent {   // RAII: events, streams and device buffers are released on every exit path
+  hipEvent_t e = nullptr;
+  ~XEvent() { if (e) (void)hipEventDestroy(e); }
+  int create(unsigned flags = hipEventDefault) { MXA_HIP(hipEventCreateWithFlags(&e, flags)); return 0; }
+};
+struct XStream {
+  hipStream_t s = nullptr;
+  ~XStream() { if (s) (void)hipStreamDestroy(s); }
+  int create(unsigned flags) { MXA_HIP(hipStreamCreateWithFlags(&s, flags)); return 0; }
+};
+struct XBuf {
+  void *p = nullptr;
+  ~XBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) { MXA_HIP(hipMalloc(&p, bytes ? bytes : 1)); return 0; }
+};
+}  // namespace
+
+// one launch over a tile list with either engine (f4: FP4 MFMA, else int8 MFMA); diag_out: in-kernel clocks of the DIAG instantiation
+static int launch_tiles(bool f4, size_t ntiles, hipStream_t s, const uint8_t *d_X, long nslabs, int stages, const int4 *d_tiles, long rows, double *d_ans, long ld,
+                        long c0, unsigned long long *d_diag) {
+  static unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;   // per-device function attributes
+  if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod2<false>), kX2Lds, &m0) || ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod2<true>), kX2Lds, &m1) ||
+      ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<false>), kF4Lds, &m2) || ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true>), kF4Lds, &m3)) return 1;
+  const dim3 grid((unsigned)ntiles), block(256);
+  if (f4) {
+    static const int exp = [] { const char *e = getenv("MXA_XPROD_EXP"); return e ? atoi(e) : 0; }();
+    if (d_diag && exp == 1) {
+      static unsigned long long mx1 = 0;
+      if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true, 1>), kF4Lds, &mx1)) return 1;
+      hipLaunchKernelGGL((k_crossprod_f4<true, 1>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
+    } else if (d_diag && exp == 2) {
+      static unsigned long long mx2 = 0;
+      if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true, 2>), kF4Lds, &mx2)) return 1;
+      hipLaunchKernelGGL((k_crossprod_f4<true, 2>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
+    } else if (d_diag && exp == 3) {
+      static unsigned long long mx3 = 0;
+      if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true, 3>), kF4Lds, &mx3)) return 1;
+      hipLaunchKernelGGL((k_crossprod_f4<true, 3>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
+    } else if (d_diag && exp == 4) {
+      static unsigned long long mx4 = 0;
+      if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true, 4>), kF4Lds, &mx4)) return 1;
+      hipLaunchKernelGGL((k_crossprod_f4<true, 4>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
+    } else if (d_diag && exp == 5) {
+      static unsigned long long mx5 = 0;
+      if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true, 5>), kF4Lds, &mx5)) return 1;
+      hipLaunchKernelGGL((k_crossprod_f4<true, 5>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
+    } else if (d_diag && exp == 6) {
+      static unsigned long long mx6 = 0;
+      if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true, 6>), kF4Lds, &mx6)) return 1;
+      hipLaunchKernelGGL((k_crossprod_f4<true, 6>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
+    } else if (d_diag) hipLaunchKernelGGL(k_crossprod_f4<true>, grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
+    else hipLaunchKernelGGL(k_crossprod_f4<false>, grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
+  } else {
+    if (d_diag) hipLaunchKernelGGL(k_crossprod2<true>, grid, block, kX2Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
+    else hipLaunchKernelGGL(k_crossprod2<false>, grid, block, kX2Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
+  }
+  MXA_HIP(hipGetLastError());
+  return 0;
+}
+
+// X: device, tiled layout (rows padded to 256, K padded to 128 genotypes = nslabs slabs), zero padded.
 // Columns [c_begin, c_end) of M = X X^T into d_ans (leading dimension ld; c_begin a multiple of the 256-row tile, c_end a multiple
 // or the matrix end).  upper_only: only rows [0, c_end) are written -- everything above the panel's diagonal block and the block
 // itself; rows >= c_end are left untouched.  The whole matrix is c_begin = 0, c_end = rows, ld = rows.
 int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double *d_ans, hipStream_t s, long c_begin, long c_end, bool upper_only,
-                     long ld) {
+                     long ld, bool f4) {
   const int nb = (int)((rows + kXT - 1) / kXT);
   const int stages = (int)((k + kXStageK - 1) / kXStageK);
-  if ((size_t)stages * kXStageBytes > pitch) { set_error(4, "internal: crossproduct pitch too small"); return 1; }
+  const long nslabs = (long)(pitch / kXStageBytes);
+  if (stages > nslabs) { set_error(4, "internal: crossproduct pitch too small"); return 1; }
   if (c_begin % kXT != 0 || c_begin < 0 || c_end > rows || c_begin >= c_end || ld < (upper_only ? c_end : rows)) { set_error(4, "crossproduct: bad column panel"); return 1; }
   const int t0 = (int)(c_begin / kXT), t1 = (int)((c_end + kXT - 1) / kXT);
   const bool whole = c_begin == 0 && c_end == rows;
@@ -286,44 +510,29 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
     }
   if (tiles.empty()) return 0;
   xcd_order_tiles(tiles, nb, 8);
-  int4 *d_tiles = nullptr;
-  MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_tiles), tiles.size() * sizeof(int4)));
-  MXA_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, s));
-  hipEvent_t e0, e1;
-  MXA_HIP(hipEventCreate(&e0)); MXA_HIP(hipEventCreate(&e1));
-  MXA_HIP(hipEventRecord(e0, s));
-  const long c0 = c_begin;
-  {
-    static bool attr2 = false;
-    if (!attr2) {
-      MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_crossprod2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kX2Lds));
-      MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_crossprod2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kX2Lds));
-      attr2 = true;
-    }
-    if (getenv("MXA_DIAG")) {   // diagnostic instantiation: in-kernel clock and cycles per stage
-      unsigned long long *d_diag = nullptr;
-      MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_diag), 16 * tiles.size()));
-      hipLaunchKernelGGL(k_crossprod2<true>, dim3((unsigned)tiles.size()), dim3(256), kX2Lds, s, d_X, pitch, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
-      MXA_HIP(hipStreamSynchronize(s));
-      std::vector<unsigned long long> hd(2 * tiles.size());
-      MXA_HIP(hipMemcpy(hd.data(), d_diag, 16 * tiles.size(), hipMemcpyDeviceToHost));
-      std::vector<double> ghz, cyc;
-      for (size_t i = 0; i < tiles.size(); i++) if (hd[2 * i + 1]) { ghz.push_back((double)hd[2 * i] / (double)hd[2 * i + 1] * 0.1); cyc.push_back((double)hd[2 * i] / stages); }
-      std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end());
-      if (!ghz.empty()) printf("MXA_DIAG k_crossprod2: %zu tiles, in-kernel clock median %.3f GHz (min %.3f max %.3f); shader cycles per stage median %.0f (ideal 2048)\n",
-                               tiles.size(), ghz[ghz.size() / 2], ghz.front(), ghz.back(), cyc[cyc.size() / 2]);
-      (void)hipFree(d_diag);
-    } else
-    hipLaunchKernelGGL(k_crossprod2<false>, dim3((unsigned)tiles.size()), dim3(256), kX2Lds, s, d_X, pitch, stages, d_tiles, rows, d_ans, ld, c0, (unsigned long long *)nullptr);
-  }
-  MXA_HIP(hipGetLastError());
-  MXA_HIP(hipEventRecord(e1, s));
+  XBuf d_tiles, d_diag;
+  if (d_tiles.alloc(tiles.size() * sizeof(int4))) return 1;
+  MXA_HIP(hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, s));
+  XEvent e0, e1;
+  if (e0.create() || e1.create()) return 1;
+  const bool diag_on = getenv("MXA_DIAG") != nullptr;
+  if (diag_on && d_diag.alloc(16 * tiles.size())) return 1;
+  MXA_HIP(hipEventRecord(e0.e, s));
+  if (launch_tiles(f4, tiles.size(), s, d_X, nslabs, stages, (const int4 *)d_tiles.p, rows, d_ans, ld, c_begin, (unsigned long long *)d_diag.p)) return 1;
+  MXA_HIP(hipEventRecord(e1.e, s));
   MXA_HIP(hipStreamSynchronize(s));   // tiles vector / d_tiles lifetime
+  if (diag_on) {   // diagnostic instantiation: in-kernel clock and cycles per stage
+    std::vector<unsigned long long> hd(2 * tiles.size());
+    MXA_HIP(hipMemcpy(hd.data(), d_diag.p, 16 * tiles.size(), hipMemcpyDeviceToHost));
+    std::vector<double> ghz, cyc;
+    for (size_t i = 0; i < tiles.size(); i++) if (tiles[i].z && hd[2 * i + 1]) { ghz.push_back((double)hd[2 * i] / (double)hd[2 * i + 1] * 0.1); cyc.push_back((double)hd[2 * i] / stages); }
+    std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end());
+    if (!ghz.empty()) printf("MXA_DIAG %s: %zu tiles, in-kernel clock median %.3f GHz (min %.3f max %.3f); shader cycles per stage median %.0f (ideal %d)\n",
+                             f4 ? "k_crossprod_f4" : "k_crossprod2", tiles.size(), ghz[ghz.size() / 2], ghz.front(), ghz.back(), cyc[cyc.size() / 2], f4 ? 1024 : 2048);
+  }
   float ms = 0.f;
-  MXA_HIP(hipEventElapsedTime(&ms, e0, e1));
+  MXA_HIP(hipEventElapsedTime(&ms, e0.e, e1.e));
   profile().launches += 1; profile().total_ms += ms;
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  (void)hipFree(d_tiles);
   return 0;
 }
 
@@ -331,10 +540,11 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
 // (all j >= i).  Tile (i, j) stores M[J rows, I cols] and M[I rows, J cols], so once every chunk up to tile row i1 has run, columns
 // [0, 256*i1) of M are final: a helper thread copies each finished column slab to the host on its own non-blocking stream while
 // the next chunk computes (at config 3 the 80 GB device-to-host copy is as long as the compute).
-static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch, double *d_ans, double *h_ans, hipStream_t s) {
+static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch, double *d_ans, double *h_ans, hipStream_t s, bool f4) {
   const int nb = (int)((rows + kXT - 1) / kXT);
   const int stages = (int)((k + kXStageK - 1) / kXStageK);
-  if ((size_t)stages * kXStageBytes > pitch) { set_error(4, "internal: crossproduct pitch too small"); return 1; }
+  const long nslabs = (long)(pitch / kXStageBytes);
+  if (stages > nslabs) { set_error(4, "internal: crossproduct pitch too small"); return 1; }
   const char *slab_env = getenv("MXA_XPROD_SLAB_MB");                                        // tests use small slabs
   const long slab_bytes = (slab_env && atol(slab_env) > 0 ? atol(slab_env) : 1024L) << 20;
   const int rows_per_chunk = (int)std::max<long>(1, slab_bytes / (rows * 8 * kXT));         // ~1 GiB column slabs
@@ -351,58 +561,51 @@ static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch
     tiles.insert(tiles.end(), part.begin(), part.end());
   }
   first[(size_t)nchunks] = tiles.size();
-  int4 *d_tiles = nullptr;
-  MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_tiles), tiles.size() * sizeof(int4)));
-  MXA_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, s));
-  static bool attr2 = false;
-  if (!attr2) { MXA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_crossprod2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kX2Lds)); attr2 = true; }
-  std::vector<hipEvent_t> ev((size_t)nchunks, nullptr);
+  XBuf d_tiles;
+  if (d_tiles.alloc(tiles.size() * sizeof(int4))) return 1;
+  MXA_HIP(hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, s));
+  std::vector<XEvent> ev((size_t)nchunks);
   int dev = 0;
   MXA_HIP(hipGetDevice(&dev));
-  for (auto &e : ev) MXA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  hipEvent_t e0, e1;
-  MXA_HIP(hipEventCreate(&e0)); MXA_HIP(hipEventCreate(&e1));
+  for (auto &e : ev) if (e.create(hipEventDisableTiming)) return 1;
+  XEvent e0, e1;
+  if (e0.create() || e1.create()) return 1;
   std::atomic<int> launched{0}, copy_err{0};
   std::atomic<bool> abort_copy{false};
   // a copy into pageable memory is staged by the runtime and bound by one host thread's memcpy (~17 GB/s measured): several
   // copier threads, each with its own stream and its own share of every slab, run those memcpys side by side
   constexpr int kCopiers = 4;
-  hipStream_t cs[kCopiers] = {};
-  for (auto &c : cs) MXA_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+  XStream cs[kCopiers];
+  for (auto &c : cs) if (c.create(hipStreamNonBlocking)) return 1;
   auto copy_loop = [&](int t) {
     if (hipSetDevice(dev) != hipSuccess) { copy_err = 1; return; }
     for (int c = 0; c < nchunks; c++) {
       while (launched.load() <= c) { if (abort_copy.load()) return; std::this_thread::yield(); }
-      if (hipEventSynchronize(ev[c]) != hipSuccess) { copy_err = 1; return; }
+      if (hipEventSynchronize(ev[c].e) != hipSuccess) { copy_err = 1; return; }
       const long col0 = (long)c * rows_per_chunk * kXT, col1 = std::min<long>(rows, (long)(c + 1) * rows_per_chunk * kXT);
       const long w = col1 - col0, a = col0 + w * t / kCopiers, b = col0 + w * (t + 1) / kCopiers;
       if (b <= a) continue;
       const size_t off = (size_t)a * rows, cnt = (size_t)(b - a) * rows;
-      if (hipMemcpyAsync(h_ans + off, d_ans + off, cnt * sizeof(double), hipMemcpyDeviceToHost, cs[t]) != hipSuccess || hipStreamSynchronize(cs[t]) != hipSuccess) { copy_err = 1; return; }
+      if (hipMemcpyAsync(h_ans + off, d_ans + off, cnt * sizeof(double), hipMemcpyDeviceToHost, cs[t].s) != hipSuccess || hipStreamSynchronize(cs[t].s) != hipSuccess) { copy_err = 1; return; }
     }
   };
   std::vector<std::thread> copiers;
   for (int t = 0; t < kCopiers; t++) copiers.emplace_back(copy_loop, t);
   int rc = 0;
-  if (hipEventRecord(e0, s) != hipSuccess) rc = 1;
+  if (hipEventRecord(e0.e, s) != hipSuccess) rc = 1;
   for (int c = 0; c < nchunks && !rc; c++) {
     const size_t cnt = first[(size_t)c + 1] - first[(size_t)c];
-    hipLaunchKernelGGL(k_crossprod2<false>, dim3((unsigned)cnt), dim3(256), kX2Lds, s, d_X, pitch, stages, d_tiles + first[(size_t)c], rows, d_ans, rows, 0L, (unsigned long long *)nullptr);
-    if (hipGetLastError() != hipSuccess || hipEventRecord(ev[c], s) != hipSuccess) { rc = 1; break; }
+    if (launch_tiles(f4, cnt, s, d_X, nslabs, stages, (const int4 *)d_tiles.p + first[(size_t)c], rows, d_ans, rows, 0L, nullptr) || hipEventRecord(ev[c].e, s) != hipSuccess) { rc = 1; break; }
     launched.store(c + 1);
   }
   if (rc) abort_copy = true;
-  if (!rc && hipEventRecord(e1, s) != hipSuccess) rc = 1;
+  if (!rc && hipEventRecord(e1.e, s) != hipSuccess) rc = 1;
   for (auto &t : copiers) t.join();
   if (hipStreamSynchronize(s) != hipSuccess) rc = 1;
   if (!rc && !copy_err.load()) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { profile().launches += 1; profile().total_ms += ms; }
+    if (hipEventElapsedTime(&ms, e0.e, e1.e) == hipSuccess) { profile().launches += 1; profile().total_ms += ms; }
   }
-  for (auto &e : ev) if (e) (void)hipEventDestroy(e);
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  for (auto &c : cs) (void)hipStreamDestroy(c);
-  (void)hipFree(d_tiles);
   if (rc || copy_err.load()) { set_error(13, "snp_multiply_gpu: pipelined device-to-host copy of the result failed"); return 1; }
   return 0;
 }
@@ -464,8 +667,9 @@ __global__ void __launch_bounds__(256) k_ld_scale(double *__restrict__ M, long n
 // post: 0 none, 1 GRM (do_scale as given, f = allele frequencies of length k), 2 LD (f of length rows, k = number of individuals)
 static int postprocess_device(double *d_M, long rows, long k, int post, int do_scale, const double *d_f, hipStream_t s) {
   if (post == 0) return 0;
-  double *tmp = nullptr;
-  MXA_HIP(hipMalloc(reinterpret_cast<void **>(&tmp), sizeof(double) * (size_t)(rows + 4)));
+  XBuf tmp_buf;
+  if (tmp_buf.alloc(sizeof(double) * (size_t)(rows + 4))) return 1;
+  double *tmp = (double *)tmp_buf.p;
   dim3 g2((unsigned)rows, (unsigned)((rows + 255) / 256));   // x = column (unbounded), y = row chunk (<= 65535)
   if (post == 1) {
     hipLaunchKernelGGL(k_sym_colsum, dim3((unsigned)rows), dim3(256), 0, s, d_M, rows, tmp);
@@ -479,14 +683,7 @@ static int postprocess_device(double *d_M, long rows, long k, int post, int do_s
   }
   MXA_HIP(hipGetLastError());
   MXA_HIP(hipStreamSynchronize(s));
-  (void)hipFree(tmp);
   return 0;
-}
-
-static bool xp_is_device_ptr(const void *p) {
-  hipPointerAttribute_t attr;
-  if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
 }
 
 static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, double *ans, bool is_plink, int post = 0, int do_scale = 0,
@@ -494,15 +691,12 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
   if (c_end < 0) c_end = rows;
   if (ld < 0) ld = rows;
   if (!snp_matrix || !ans || k <= 0 || rows <= 0) { set_error(1, "snp_multiply_gpu: bad arguments"); return 1; }
-  int count = 0;
-  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); set_error(10, "snp_multiply_gpu: no HIP device available; this engine is GPU-only"); return 1; }
-  const char *dv = getenv("HIP_DEVICE");
-  if (!dv) dv = getenv("CUDA_DEVICE");
-  if (dv) MXA_HIP(hipSetDevice(atoi(dv)));
+  if (select_device() < 0) return 1;   // HIP_DEVICE / CUDA_DEVICE with the range check; GPU-only
   const long row_bytes = (k + 3) / 4;
   const long rows_pad = (rows + kXT - 1) / kXT * kXT;
-  const size_t pitch = (size_t)((k + kXStageK - 1) / kXStageK) * kXStageBytes;
-  const bool in_dev = xp_is_device_ptr(snp_matrix), out_dev = xp_is_device_ptr(ans);
+  const long nslabs = (k + kXStageK - 1) / kXStageK;
+  const size_t pitch = (size_t)nslabs * kXStageBytes;
+  const bool in_dev = ptr_location(snp_matrix, nullptr) == 1, out_dev = ptr_location(ans, nullptr) == 1;
   if (c_begin < 0 || c_begin >= c_end || c_end > rows || c_begin % kXT != 0 || (c_end % kXT != 0 && c_end != rows) || ld < (upper_only ? c_end : rows)) {
     set_error(1, "crossproduct panel: need 0 <= col_begin < col_end <= n, col_begin %% %d == 0, col_end %% %d == 0 or col_end == n, ld >= rows written", kXT, kXT);
     return 1;
@@ -512,56 +706,60 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
   MXA_HIP(hipMemGetInfo(&free_b, &total_b));
   const size_t need = xbytes + (out_dev ? 0 : abytes) + (in_dev ? 0 : std::min<size_t>((size_t)rows * row_bytes, (size_t)256 << 20));
   if (need > free_b) { set_error(12, "snp_multiply_gpu: not enough device memory: required %zu GB, free %zu GB", need >> 30, free_b >> 30); return 1; }
-  hipStream_t s = nullptr;
-  MXA_HIP(hipStreamCreateWithFlags(&s, hipStreamDefault));   // blocking: ordered against the caller's default-stream work
-  uint8_t *d_X = nullptr, *bounce = nullptr;
-  double *d_ans = out_dev ? ans : nullptr;
-  int rc = 0;
-  auto fail = [&](hipError_t e, int line) { if (e != hipSuccess) { check_hip(e, "snp_multiply_gpu", line); rc = 1; } return rc; };
-  if (fail(hipMalloc(reinterpret_cast<void **>(&d_X), xbytes), __LINE__)) goto done;
-  if (fail(hipMemsetAsync(d_X, 0, xbytes, s), __LINE__)) goto done;
+  XStream st;
+  if (st.create(hipStreamDefault)) return 1;   // blocking: ordered against the caller's default-stream work
+  hipStream_t s = st.s;
+  XBuf d_X, bounce, d_out, d_flag, f_tmp;
+  if (d_X.alloc(xbytes) || d_flag.alloc(sizeof(int))) return 1;
+  MXA_HIP(hipMemsetAsync(d_X.p, 0, xbytes, s));
+  MXA_HIP(hipMemsetAsync(d_flag.p, 0, sizeof(int), s));
   if (in_dev) {
     const long total = rows * ((row_bytes + 3) / 4);
-    hipLaunchKernelGGL(k_xstage, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, snp_matrix, (size_t)row_bytes, row_bytes, rows, d_X, pitch, 0L, is_plink ? 1 : 0);
-    if (fail(hipGetLastError(), __LINE__)) goto done;
+    hipLaunchKernelGGL(k_xstage, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, snp_matrix, (size_t)row_bytes, row_bytes, rows, (uint8_t *)d_X.p, nslabs, 0L,
+                       is_plink ? 1 : 0, (int *)d_flag.p);
+    MXA_HIP(hipGetLastError());
   } else {
     long chunk_rows = std::max<long>(1, (long)(((size_t)256 << 20) / (size_t)row_bytes));
     chunk_rows = std::min(chunk_rows, rows);
-    if (fail(hipMalloc(reinterpret_cast<void **>(&bounce), (size_t)chunk_rows * row_bytes), __LINE__)) goto done;
+    if (bounce.alloc((size_t)chunk_rows * row_bytes)) return 1;
     for (long r0 = 0; r0 < rows; r0 += chunk_rows) {
       const long nr = std::min(chunk_rows, rows - r0);
-      if (fail(hipMemcpyAsync(bounce, snp_matrix + (size_t)r0 * row_bytes, (size_t)nr * row_bytes, hipMemcpyHostToDevice, s), __LINE__)) goto done;
+      MXA_HIP(hipMemcpyAsync(bounce.p, snp_matrix + (size_t)r0 * row_bytes, (size_t)nr * row_bytes, hipMemcpyHostToDevice, s));
       const long total = nr * ((row_bytes + 3) / 4);
-      hipLaunchKernelGGL(k_xstage, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, bounce, (size_t)row_bytes, row_bytes, nr, d_X, pitch, r0, is_plink ? 1 : 0);
-      if (fail(hipGetLastError(), __LINE__)) goto done;
-      if (fail(hipStreamSynchronize(s), __LINE__)) goto done;
+      hipLaunchKernelGGL(k_xstage, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, (const uint8_t *)bounce.p, (size_t)row_bytes, row_bytes, nr, (uint8_t *)d_X.p,
+                         nslabs, r0, is_plink ? 1 : 0, (int *)d_flag.p);
+      MXA_HIP(hipGetLastError());
+      MXA_HIP(hipStreamSynchronize(s));
     }
   }
-  if (!out_dev && fail(hipMalloc(reinterpret_cast<void **>(&d_ans), abytes), __LINE__)) goto done;
-  if (!out_dev && upper_only && !rc) fail(hipMemsetAsync(d_ans, 0, abytes, s), __LINE__);   // the untouched part travels back as zeros
-  if (!rc && !out_dev && !post && c_begin == 0 && c_end == rows && ld == rows && !getenv("MXA_XPROD_NO_PIPELINE")) {
-    rc = crossprod_to_host(d_X, k, rows, pitch, d_ans, ans, s);
-    goto done;
+  // engine: FP4 while the fp32 accumulator is provably exact (sum z z' < 2^24), int8 beyond (MXA_XPROD_ENGINE=i8 / f4 forces one, for A/B runs)
+  int has3 = 1;
+  MXA_HIP(hipMemcpyAsync(&has3, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  MXA_HIP(hipStreamSynchronize(s));
+  bool f4 = has3 ? 9 * k < (1L << 24) : 4 * k < (1L << 24);
+  if (const char *e = getenv("MXA_XPROD_ENGINE")) { if (!strcmp(e, "i8")) f4 = false; }
+  double *d_ans = ans;
+  if (!out_dev) {
+    if (d_out.alloc(abytes)) return 1;
+    d_ans = (double *)d_out.p;
+    if (upper_only) MXA_HIP(hipMemsetAsync(d_ans, 0, abytes, s));   // the untouched part travels back as zeros
   }
-  if (!rc) rc = crossprod_device(d_X, k, rows, pitch, d_ans, s, c_begin, c_end, upper_only, ld);
-  if (!rc && post) {
+  if (!out_dev && !post && c_begin == 0 && c_end == rows && ld == rows && !getenv("MXA_XPROD_NO_PIPELINE"))
+    return crossprod_to_host((const uint8_t *)d_X.p, k, rows, pitch, d_ans, ans, s, f4);
+  if (crossprod_device((const uint8_t *)d_X.p, k, rows, pitch, d_ans, s, c_begin, c_end, upper_only, ld, f4)) return 1;
+  if (post) {
     const long flen = post == 1 ? k : rows;
     const double *d_f = freq;
-    double *f_tmp = nullptr;
-    if (freq && !xp_is_device_ptr(freq)) {
-      if (!fail(hipMalloc(reinterpret_cast<void **>(&f_tmp), sizeof(double) * flen), __LINE__) && !fail(hipMemcpyAsync(f_tmp, freq, sizeof(double) * flen, hipMemcpyHostToDevice, s), __LINE__)) d_f = f_tmp;
+    if (freq && ptr_location(freq, nullptr) != 1) {
+      if (f_tmp.alloc(sizeof(double) * flen)) return 1;
+      MXA_HIP(hipMemcpyAsync(f_tmp.p, freq, sizeof(double) * flen, hipMemcpyHostToDevice, s));
+      d_f = (const double *)f_tmp.p;
     }
-    if (!rc) rc = postprocess_device(d_ans, rows, k, post, do_scale, d_f, s);
-    if (f_tmp) (void)hipFree(f_tmp);
+    if (postprocess_device(d_ans, rows, k, post, do_scale, d_f, s)) return 1;
   }
-  if (!rc && !out_dev) fail(hipMemcpyAsync(ans, d_ans, abytes, hipMemcpyDeviceToHost, s), __LINE__);
-  if (!rc) fail(hipStreamSynchronize(s), __LINE__);
-done:
-  if (d_X) (void)hipFree(d_X);
-  if (bounce) (void)hipFree(bounce);
-  if (!out_dev && d_ans) (void)hipFree(d_ans);
-  (void)hipStreamDestroy(s);
-  return rc;
+  if (!out_dev) MXA_HIP(hipMemcpyAsync(ans, d_ans, abytes, hipMemcpyDeviceToHost, s));
+  MXA_HIP(hipStreamSynchronize(s));
+  return 0;
 }
 
 }  // namespace mxa

@@ -1,0 +1,73 @@
+"""The two exact engines of the crossproduct (mxa_crossprod.hip): FP4 MFMA (default while sum z z' < 2^24 is guaranteed) and int8 MFMA
+(longer inner dimensions, or forced with MXA_XPROD_ENGINE=i8).  Both must reproduce the exact integer oracle bit for bit, including
+near the FP4 engine's exactness limit where the fp32 accumulator carries 24 significant bits, and the engine switch must follow
+the documented rule (values of 3 present: K < 1 864 135; absent: K < 4 194 304)."""
+import os
+
+import numpy as np
+import pytest
+
+from _util import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _xprod(X, k, rows, plink, env=None):
+    import miraculix_amd as mx
+    mx.load_shared_library()
+    old = os.environ.get("MXA_XPROD_ENGINE")
+    try:
+        if env:
+            os.environ["MXA_XPROD_ENGINE"] = env
+        else:
+            os.environ.pop("MXA_XPROD_ENGINE", None)
+        return mx.crossproduct.snp_crossprod(X, k, rows, is_snpmajor=False, is_plink_format=plink)
+    finally:
+        if old is None:
+            os.environ.pop("MXA_XPROD_ENGINE", None)
+        else:
+            os.environ["MXA_XPROD_ENGINE"] = old
+
+
+@pytest.mark.parametrize("k,rows,plink", [(1000, 300, True), (4099, 515, True), (777, 260, False), (130, 1, False), (20000, 700, True)])
+def test_both_engines_bit_exact(k, rows, plink):
+    o = Oracle()
+    rng = np.random.default_rng(k)
+    X = rng.integers(0, 256, size=(rows, (k + 3) // 4), dtype=np.uint8)      # raw bytes: missing codes / value 3 included
+    if k % 4:
+        X[:, -1] &= (1 << (2 * (k % 4))) - 1
+    ref = o.crossprod_i32(X, k, plink).astype(np.float64)
+    assert np.array_equal(_xprod(X, k, rows, plink), ref)
+    assert np.array_equal(_xprod(X, k, rows, plink, env="i8"), ref)
+
+
+def test_fp4_engine_exact_next_to_its_limit():
+    """K just below 2^24 / 9 with raw values 0..3 (dense in 3s): sums reach ~16.5 M quarter-units with arbitrary low bits; then a longer K
+    takes the int8 engine (same results as the oracle either way)"""
+    import torch
+    import miraculix_amd as mx
+    L = mx.load_shared_library()
+    o = Oracle()
+    rows = 256
+    for k, engine_ms_ratio in ((1_864_000, None), (1_900_000, None)):
+        rng = np.random.default_rng(1)
+        X = rng.integers(0, 256, size=(rows, k // 4), dtype=np.uint8)
+        X[:64] |= 0xC3                                                     # many 3s: rows with large sums
+        X[64:66] = 0xFF                                                    # all 3s: 9 K on the diagonal, next to 2^24 for the first K
+        ref = o.crossprod_i32(X, k, False).astype(np.float64)
+        assert ref.max() == 9.0 * k
+        got = _xprod(X, k, rows, False)
+        assert np.array_equal(got, ref), k
+    # device-resident operands, PLINK data without missings (no 3 after the table): FP4 up to K < 4 194 304
+    dev = torch.device("cuda", 0)
+    k = 4_000_000
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    b = torch.randint(0, 256, (rows, k // 4), dtype=torch.uint8, device=dev, generator=g)
+    miss = (b & 0x55) & ~((b >> 1) & 0x55)
+    Xd = b ^ miss
+    Xd[:2] = 0xFF                                                          # all code 11 = value 2: 4 K = 16 000 000 on the diagonal
+    M = mx.crossproduct.snp_crossprod(Xd, k, rows, is_snpmajor=False, is_plink_format=True)
+    assert float(M[0, 0]) == 4.0 * k and float(M[0, 1]) == 4.0 * k
+    sub = Xd[:40].cpu().numpy()
+    ref = o.crossprod_i32(sub, k, True).astype(np.float64)
+    assert np.array_equal(M[:40, :40].cpu().numpy(), ref)
