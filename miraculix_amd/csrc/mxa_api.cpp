@@ -180,6 +180,8 @@ void destroy_handle(Handle *h) {
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  for (hipEvent_t e : h->pev) if (e) (void)hipEventDestroy(e);
+  for (hipStream_t ps : h->pipe) if (ps) (void)hipStreamDestroy(ps);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   free(h->h_f);
   h->magic = 0;
@@ -332,6 +334,137 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   return rc;
 }
 
+
+// ------------------------------------------------------------------------------------------------ host-operand pipeline
+// The plain reference ABI hands over HOST B and C (utils/benchmark/benchmark.f90:192-209 times exactly that).  At C2 a call moves 269 MB over
+// PCIe (5.4 ms at the ~50 GB/s a pageable copy reaches) around a 44 ms product.  Both transfers are hidden behind the product:
+//   big B (K-chunk mode, 'N'): the K splits of the launch plan are cut into <= 8 groups; group c's rows of B are uploaded (the host
+//     thread blocks in the staged pageable copy while the GPU multiplies group c-1), scaled and packed on their own (per-group column
+//     exponents), and multiplied by a launch over just those splits.  Groups alternate between two streams so that the ramp of one launch
+//     fills the drain of the previous one.  One k_finish adds all partials in the usual ascending order, each scaled back by its group's
+//     exponent first -- power-of-two scaling commutes with rounding, so the result is bit-identical to the one-launch path.
+//   big C (M-chunk mode, 'T'): B is uploaded and packed once; <= 8 row ranges of the packed matrix are multiplied and finished by launches of
+//     their own (same split count as the one-launch plan, so identical sums), alternating between the two streams, and every finished row
+//     range travels to the host while the next one is computed.
+constexpr int kPipeChunks = 8;            // at most; at least ~8 MB of transfer per chunk
+static const size_t kPipeMinBytes = (size_t)32 << 20;
+
+static int pipe_setup(Handle *h) {
+  for (hipStream_t &ps : h->pipe) if (!ps) MXA_HIP(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+  for (hipEvent_t &e : h->pev) if (!e) MXA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return 0;
+}
+
+// returns 0 done, 1 error, 2 not applicable (caller takes the plain path)
+static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, long ldb, bool b_host, bool b_local, double *C, long ldc, bool c_host, bool c_local,
+                               long fill_rows) {
+  static const bool enabled = [] { const char *e = getenv("MXA_HOST_PIPELINE"); return !e || atoi(e) != 0; }();
+  static const int mode = [] { const char *e = getenv("MXA_GEMM_MODE"); return e ? atoi(e) : 2; }();
+  const int engine = g_engine.load();
+  if (!enabled || mode != 2 || (engine != 0 && engine != 3) || n < 3 || getenv("MXA_DIAG")) return 2;
+  const PackedMatrix &G = trans ? h->snp_major : h->ind_major;
+  const long m = G.rows, k = G.k;
+  const size_t b_bytes = b_host ? sizeof(double) * (size_t)k * n : 0, c_bytes = c_host ? sizeof(double) * (size_t)m * n : 0;
+  if (std::max(b_bytes, c_bytes) < kPipeMinBytes) return 2;
+  const bool kmode = b_bytes >= c_bytes;
+  const bool centered = options().centered;
+  if (centered && !h->has_f) { set_error(6, "dgemm_compressed: centring requested but no allele frequencies were supplied to plink2compressed"); return 1; }
+  if (n > h->max_n) h->max_n = n;
+  if (ensure_workspace(h, n) || pipe_setup(h)) return 1;
+  harvest_profile(h);
+  Workspace &w = h->ws;
+  hipStream_t s = h->stream;
+  const GemmPlan p = plan_gemm(m, G.k_pad, n);
+  // scratch: per-group column-maximum partials (64 n doubles each) + column sums; per-group exponents
+  if (grow(&w.d_colpart, &w.cap_colpart, (size_t)n * (64 * (kPipeChunks + 2) + 2) + 16)) return 1;
+  if (w.cap_exp < (size_t)n * kPipeChunks) {
+    MXA_HIP(hipStreamSynchronize(s));
+    if (w.d_exp) { MXA_HIP(hipFree(w.d_exp)); w.d_exp = nullptr; w.cap_exp = 0; }
+    MXA_HIP(hipMalloc(reinterpret_cast<void **>(&w.d_exp), sizeof(int) * (size_t)n * kPipeChunks));
+    w.cap_exp = (size_t)n * kPipeChunks;
+  }
+  double *d_sumB = w.d_colpart + (size_t)n * 64 * (kPipeChunks + 2), *d_sumfB = d_sumB + n;
+  double *d_sumscratch = w.d_colpart + (size_t)n * 64 * kPipeChunks;   // 128 n doubles for launch_colsums
+  // operands on this device
+  const double *dB = B; long dldb = ldb;
+  if (!b_local) { if (grow(&w.d_Bstage, &w.cap_Bstage, (size_t)k * n)) return 1; dB = w.d_Bstage; dldb = k; }
+  double *dC = C; long dldc = ldc;
+  if (!c_local) { if (grow(&w.d_Cstage, &w.cap_Cstage, (size_t)fill_rows * n)) return 1; dC = w.d_Cstage; dldc = fill_rows; }
+  { std::lock_guard<std::mutex> lk(g_prof_mutex); Geometry &geo = last_geometry(); geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c; geo.path = 0; }
+  MXA_HIP(hipEventRecord(h->pev[0], s));
+  for (hipStream_t ps : h->pipe) MXA_HIP(hipStreamWaitEvent(ps, h->pev[0], 0));   // earlier calls are done with Bp / P
+  const int want_chunks = (int)std::max<size_t>(2, std::min<size_t>(kPipeChunks, std::max(b_bytes, c_bytes) >> 23));
+  if (kmode) {
+    const int spc = (p.splits + want_chunks - 1) / want_chunks, nch = (p.splits + spc - 1) / spc;
+    for (int c = 0; c < nch; c++) {
+      const int sb = c * spc, se = std::min(p.splits, sb + spc);
+      const long slab0 = (long)sb * p.slabs_per_split, slab1 = std::min<long>(p.slabs_total, (long)se * p.slabs_per_split);
+      const long k0 = std::min(k, slab0 * kSlabK), k1 = std::min(k, slab1 * kSlabK);
+      if (!b_local && k1 > k0)
+        MXA_HIP(hipMemcpy2DAsync(w.d_Bstage + k0, sizeof(double) * k, B + k0, sizeof(double) * ldb, sizeof(double) * (k1 - k0), n, hipMemcpyDefault, s));
+      MXA_HIP(hipEventRecord(h->pev[2 + c], s));
+      hipStream_t cs = h->pipe[c & 1];
+      MXA_HIP(hipStreamWaitEvent(cs, h->pev[2 + c], 0));
+      int *d_Ec = w.d_exp + (size_t)c * n;
+      if (launch_colexp(dB + k0, dldb, k1 - k0, n, w.d_colpart + (size_t)c * 64 * n, d_Ec, 0, cs)) return 1;
+      if (launch_pack_B(dB, dldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, cs, d_Ec, slab0 * kSlabSteps, (slab1 - slab0) * kSlabSteps)) return 1;
+      if (launch_gemm(G, w.d_Bp, w.d_P, p, 2, cs, sb, se)) return 1;
+      MXA_HIP(hipEventRecord(h->pev[10 + c], cs));
+    }
+    for (int c = 0; c < nch; c++) MXA_HIP(hipStreamWaitEvent(s, h->pev[10 + c], 0));
+    if (centered && launch_colsums(dB, dldb, k, n, trans ? nullptr : h->d_f, d_sumscratch, d_sumB, d_sumfB, s)) return 1;
+    if (launch_finish(w.d_P, p, m, n, dC, dldc, fill_rows, trans ? 1 : 0, centered, d_sumB, d_sumfB, h->d_f, s, w.d_exp, spc, n)) return 1;
+    if (!c_local) {
+      if (ldc == fill_rows) MXA_HIP(hipMemcpyAsync(C, dC, sizeof(double) * (size_t)fill_rows * n, hipMemcpyDefault, s));
+      else MXA_HIP(hipMemcpy2DAsync(C, sizeof(double) * ldc, dC, sizeof(double) * fill_rows, sizeof(double) * fill_rows, n, hipMemcpyDefault, s));
+    }
+  } else {
+    if (!b_local) {
+      if (ldb == k) MXA_HIP(hipMemcpyAsync(w.d_Bstage, B, sizeof(double) * (size_t)k * n, hipMemcpyDefault, s));
+      else MXA_HIP(hipMemcpy2DAsync(w.d_Bstage, sizeof(double) * k, B, sizeof(double) * ldb, sizeof(double) * k, n, hipMemcpyDefault, s));
+    }
+    if (launch_colexp(dB, dldb, k, n, w.d_colpart, w.d_exp, 0, s)) return 1;
+    if (launch_pack_B(dB, dldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, w.d_exp)) return 1;
+    if (centered && launch_colsums(dB, dldb, k, n, trans ? nullptr : h->d_f, d_sumscratch, d_sumB, d_sumfB, s)) return 1;
+    MXA_HIP(hipEventRecord(h->pev[1], s));
+    const long rows_chunk = ((m + want_chunks - 1) / want_chunks + kRowAlign - 1) / kRowAlign * kRowAlign;
+    {   // the row ranges pad to whole row blocks each: a few blocks more than the one-launch plan
+      size_t total = 0;
+      for (long r0 = 0; r0 < m; r0 += rows_chunk) { const GemmPlan pc = plan_gemm(std::min(m, r0 + rows_chunk) - r0, G.k_pad, n, p.splits); total += (size_t)pc.splits * pc.n_pad * pc.m_pad; }
+      if (total > w.cap_P) { MXA_HIP(hipStreamSynchronize(s)); if (grow(&w.d_P, &w.cap_P, total)) return 1; }
+    }
+    size_t p_off = 0;
+    int nch = 0;
+    for (long r0 = 0; r0 < m; r0 += rows_chunk, nch++) {
+      const int c = nch;
+      const long r1 = std::min(m, r0 + rows_chunk), rows_c = r1 - r0;
+      const bool last = r1 == m;
+      PackedMatrix V = G;   // rows [r0, r1): whole 256-row tiles, so the view starts at a tile boundary of the tiled layout
+      V.d = G.d + (size_t)(r0 / kTileRows) * G.nslabs * kTileBytes;
+      V.rows = rows_c; V.rows_pad = last ? G.rows_pad - r0 : rows_chunk;
+      const GemmPlan pc = plan_gemm(rows_c, G.k_pad, n, p.splits);   // the one-launch plan's K splits: identical sums
+      if (pc.slabs_per_split != p.slabs_per_split) { set_error(4, "internal: chunk plan differs from the launch plan"); return 1; }
+      const size_t p_need = (size_t)pc.splits * pc.n_pad * pc.m_pad;
+      if (p_off + p_need > w.cap_P) { set_error(4, "internal: partial-result workspace too small for the row-range pipeline"); return 1; }
+      hipStream_t cs = h->pipe[c & 1];
+      MXA_HIP(hipStreamWaitEvent(cs, h->pev[1], 0));
+      if (launch_gemm(V, w.d_Bp, w.d_P + p_off, pc, 2, cs)) return 1;
+      const long fill_c = last ? fill_rows - r0 : rows_c;
+      if (launch_finish(w.d_P + p_off, pc, rows_c, n, dC + r0, dldc, fill_c, trans ? 1 : 0, centered, d_sumB, d_sumfB, (h->d_f && trans) ? h->d_f + r0 : h->d_f, cs, w.d_exp)) return 1;
+      MXA_HIP(hipEventRecord(h->pev[10 + c], cs));
+      p_off += p_need;
+    }
+    for (int c = 0; c < nch; c++) {
+      const long r0 = (long)c * rows_chunk, r1 = std::min(m, r0 + rows_chunk);
+      const long cnt = (r1 == m) ? fill_rows - r0 : r1 - r0;
+      MXA_HIP(hipStreamWaitEvent(s, h->pev[10 + c], 0));
+      if (!c_local) MXA_HIP(hipMemcpy2DAsync(C + r0, sizeof(double) * ldc, dC + r0, sizeof(double) * fill_rows, sizeof(double) * cnt, n, hipMemcpyDefault, s));
+    }
+  }
+  MXA_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
 int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, double *C, long ldc, long fill_rows, bool sync, bool timing) {
   MXA_HIP(hipSetDevice(h->device));
   const PackedMatrix &G = trans ? h->snp_major : h->ind_major;
@@ -343,6 +476,10 @@ int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, double *C,
   int b_devno = -1, c_devno = -1;
   const bool b_local = ptr_location(B, &b_devno) == 1 && b_devno == h->device;
   const bool c_local = ptr_location(C, &c_devno) == 1 && c_devno == h->device;
+  if (sync && (b_devno < 0 || c_devno < 0)) {   // a host operand on a synchronous call: transfers hidden behind the product when they are large
+    const int rcp = gemm_host_pipelined(h, trans, n, B, ldb, b_devno < 0, b_local, C, ldc, c_devno < 0, c_local, fill_rows);
+    if (rcp != 2) return rcp;
+  }
   const double *dB = B; long dldb = ldb;
   double *dC = C; long dldc = ldc;
   Workspace &w = h->ws;

@@ -68,6 +68,9 @@ struct Handle {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // timing of the dominant kernel (created once, not per call)
   bool prof_pending = false;                 // ev0/ev1 were recorded by the last call and have not been read yet
+  // host-operand pipeline (mxa_api.cpp: gemm_host_pipelined): two compute streams for alternating chunks, events per chunk
+  hipStream_t pipe[2] = {nullptr, nullptr};
+  hipEvent_t pev[18] = {};                   // [0] start, [1] operands ready, [2..9] upload of chunk c, [10..17] chunk c computed
 };
 
 struct Profile {
@@ -130,19 +133,23 @@ constexpr int kDenUp = 900;
 int launch_colexp(const double *dB, long ldb, long k, int n, double *d_part, int *d_E, int bias, hipStream_t s, int *d_flag = nullptr, int max_span = 0,
                   int min_emax = 0);
 // d_E (nullable): per-column exponents for the denormal-operand mode
-int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k_pad, int n_pad, int c, hipStream_t s, const int *d_E = nullptr);
+// K-steps (16 genotypes) [S0, S0 + S_cnt) only; S_cnt < 0: to the end
+int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k_pad, int n_pad, int c, hipStream_t s, const int *d_E = nullptr, long S0 = 0,
+                  long S_cnt = -1);
 int launch_colsums(const double *dB, long ldb, long k, int n, const double *d_f /*nullable*/, double *d_part,
                    double *d_sumB, double *d_sumfB, hipStream_t s);
 // p_rows: rows per tile of the partial-result array P[split][m_pad / p_rows][n_pad][p_rows] (k_gemm: the workgroup's row block, so a
 // workgroup writes one contiguous chunk; lookup kernel: m_pad, i.e. plain [split][n_pad][m_pad])
 struct GemmPlan { int a, c, nchunks, n_pad, splits, slabs_per_split, slabs_total, rowblocks; long m_pad; long p_rows; };
-GemmPlan plan_gemm(long m, long k_pad, int n);
-int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, int mode, hipStream_t s);
+GemmPlan plan_gemm(long m, long k_pad, int n, int force_splits = 0);
+// K splits [split_begin, split_end) only (split_end < 0: all)
+int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, int mode, hipStream_t s, int split_begin = 0, int split_end = -1);
 GemmPlan plan_lut(long m, long k_pad, int n);
 int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double *dP, const GemmPlan &p, hipStream_t s);
 // fill_rows: rows [m, fill_rows) of every column are zero-filled (fill_rows <= ldc)
 int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC, long ldc, long fill_rows, int mode_trans,
-                  bool centered, const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s, const int *d_E = nullptr);
+                  bool centered, const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s, const int *d_E = nullptr, int e_splits = 0,
+                  int e_stride = 0);
 // per-device one-time hipFuncSetAttribute(MaxDynamicSharedMemorySize): function attributes are per device, `mask` has one bit per device
 int ensure_dyn_lds(const void *func, int bytes, unsigned long long *mask);
 int launch_transpose_2bit(const uint8_t *d_in, long rows, long cols, uint8_t *d_out, hipStream_t s);

@@ -88,15 +88,16 @@ int launch_recode(const uint8_t *d_src, size_t src_pitch, long row0, long nrows,
 // its B operand, lane l <- Bp[..][S][h][l] (lane map measured on gfx950: B lane = j + 4*blk + 16*k, we assign genotype row
 // 16S + (blk + 4*k) = 16S + (l>>2) to it; tools/mfma_f64_probe2.hip).  A slab of 8 K-steps of one chunk is one contiguous
 // run of C*4 KiB, so it streams HBM -> LDS as C*4 lane-linear LDS-DMA units for any C.
+// K-steps [S0, S0 + S_cnt) only (the host-operand pipeline packs B in K ranges as they arrive); the whole array: S0 = 0, S_cnt = S_total.
 __global__ void __launch_bounds__(256) k_pack_B(const double *__restrict__ B, long ldb, long k, int n,
-                                                double *__restrict__ Bp, long total, int C, long S_total, const int *__restrict__ E, int up) {
+                                                double *__restrict__ Bp, long total, int C, long S_total, const int *__restrict__ E, int up, long S0, long S_cnt) {
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int l = (int)(idx & 63);
     const long sh = idx >> 6;
     const int h = (int)(sh % C);
     const long cs = sh / C;
-    const long S = cs % S_total;
-    const int chunk = (int)(cs / S_total);
+    const long S = S0 + cs % S_cnt;
+    const int chunk = (int)(cs / S_cnt);
     const long row = S * 16 + (l >> 2);
     const int col = chunk * 4 * C + 4 * h + (l & 3);
     double v = 0.0;
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(256) k_pack_B(const double *__restrict__ B, lo
       v = B[row + (long)col * ldb];
       if (E) v = ldexp(v, up - E[col]);      // denormal-operand mode: column scaled to just below 2^up (exact)
     }
-    Bp[idx] = v;
+    Bp[(((size_t)chunk * S_total + S) * C + h) * 64 + l] = v;
   }
 }
 
@@ -161,11 +162,13 @@ int launch_colexp(const double *dB, long ldb, long k, int n, double *d_part, int
   return 0;
 }
 
-int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k_pad, int n_pad, int c, hipStream_t s, const int *d_E) {
+int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k_pad, int n_pad, int c, hipStream_t s, const int *d_E, long S0, long S_cnt) {
   const long S_total = k_pad / 16;
-  const long total = S_total * (long)(n_pad / 4) * 64;
+  if (S_cnt < 0) S_cnt = S_total - S0;
+  const long total = S_cnt * (long)(n_pad / 4) * 64;
+  if (total <= 0) return 0;
   const int grid = (int)std::min<long>((total + 255) / 256, 256L * 64);
-  hipLaunchKernelGGL(k_pack_B, dim3(grid), dim3(256), 0, s, dB, ldb, k, n, dBp, total, c, S_total, d_E, kDenUp);
+  hipLaunchKernelGGL(k_pack_B, dim3(grid), dim3(256), 0, s, dB, ldb, k, n, dBp, total, c, S_total, d_E, kDenUp, S0, S_cnt);
   MXA_HIP(hipGetLastError());
   return 0;
 }
@@ -278,7 +281,7 @@ template <int A, int C, int MODE, bool DIAG = false>
 __global__ void __launch_bounds__(256, 2)
 k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ Bp, int H, double *__restrict__ P,
        long m_pad, int n_pad, int rowblocks, int nchunks, int slabs_total, int slabs_per_split, int xcd_order,
-       unsigned long long *__restrict__ diag = nullptr) {
+       unsigned long long *__restrict__ diag = nullptr, int split0 = 0) {
   using Cfg = GemmCfg<A, C>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long rt_begin = 0;
@@ -296,7 +299,7 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
   if (xcd_order && bid < g8 * rowblocks) { const int xcd = bid & 7, slot = bid >> 3; rb = slot % rowblocks; grp = xcd + 8 * (slot / rowblocks); }
   else { const int t = bid - g8 * rowblocks * (xcd_order ? 1 : 0); rb = t % rowblocks; grp = (xcd_order ? g8 : 0) + t / rowblocks; }
   const int nc = grp % nchunks;
-  const int sp = grp / nchunks;
+  const int sp = grp / nchunks + split0;              // split0: first K split of this launch (host-operand pipeline: K ranges as B arrives)
   const int slab0 = sp * slabs_per_split;
   const int slab1 = min(slab0 + slabs_per_split, slabs_total);
   const long row0 = (long)rb * Cfg::kRowsWG;
@@ -459,7 +462,7 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
   if (DIAG && threadIdx.x == 0 && diag) diag[4 * (size_t)gridDim.x + blockIdx.x] = __builtin_amdgcn_s_memrealtime();   // exit
 }
 
-GemmPlan plan_gemm(long m, long k_pad, int n) {
+GemmPlan plan_gemm(long m, long k_pad, int n, int force_splits) {
   GemmPlan p{};
   // tile choice by n: column chunks of at most 32 columns, C = groups of 4 columns per chunk (balanced over the chunks, so at most
   // 3 padded columns per chunk), A = row groups of 4 per wave: A*C <= 64 accumulators (128 VGPRs)
@@ -492,7 +495,7 @@ GemmPlan plan_gemm(long m, long k_pad, int n) {
       if (eff > best_eff + 1e-9) { best_eff = eff; best_splits = cand; }
     }
   }
-  const long splits = best_splits;
+  const long splits = force_splits > 0 ? std::min<long>(force_splits, std::max<long>(1, p.slabs_total)) : best_splits;
   p.slabs_per_split = (int)((p.slabs_total + splits - 1) / splits);
   p.splits = (p.slabs_total + p.slabs_per_split - 1) / p.slabs_per_split;
   if (p.splits < 1) p.splits = 1;
@@ -500,15 +503,16 @@ GemmPlan plan_gemm(long m, long k_pad, int n) {
 }
 
 template <int A, int C, int MODE>
-static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, hipStream_t s) {
+static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, hipStream_t s, int split_begin, int split_end) {
   using Cfg = GemmCfg<A, C>;
   static unsigned long long attr_mask = 0;   // function attributes are per device
   if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm<A, C, MODE>), Cfg::kLds, &attr_mask)) return 1;
-  const long grid = (long)p.rowblocks * p.nchunks * p.splits;
+  const long grid = (long)p.rowblocks * p.nchunks * (split_end - split_begin);
   if (grid > 0x7fffffffL) { set_error(3, "grid too large"); return 1; }
+  if (grid <= 0) return 0;
   static const int xcd_order = [] { const char *e = getenv("MXA_XCD_ORDER"); return e ? atoi(e) : 1; }();   // 0: plain order (A/B measurement)
   static const bool diag_on = getenv("MXA_DIAG") != nullptr;
-  if (diag_on && A == 8 && C == 8) {   // diagnostic instantiation: in-kernel clock + cycles per slab
+  if (diag_on && A == 8 && C == 8 && split_begin == 0 && split_end == p.splits) {   // diagnostic instantiation: in-kernel clock + cycles per slab
     static unsigned long long attr2 = 0;
     if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm<A, C, MODE, true>), Cfg::kLds, &attr2)) return 1;
     unsigned long long *d_diag = nullptr;
@@ -540,12 +544,13 @@ static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, c
     return 0;
   }
   hipLaunchKernelGGL((k_gemm<A, C, MODE>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBp, p.n_pad / 4, dP,
-                     p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, p.slabs_per_split, xcd_order, nullptr);
+                     p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, p.slabs_per_split, xcd_order, nullptr, split_begin);
   MXA_HIP(hipGetLastError());
   return 0;
 }
 
-int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, int mode, hipStream_t s) {
+int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, int mode, hipStream_t s, int split_begin, int split_end) {
+  if (split_end < 0) split_end = p.splits;
   // host-side shape checks: the kernel reads rows [0, m_pad) x [0, slabs_total*32) bytes and Bp[(k_pad/16)][H][64]
   if (p.m_pad > G.rows_pad || (size_t)p.slabs_total * kSlabBytes > G.pitch) {
     set_error(4, "internal: packed matrix smaller than the launch plan (m_pad %ld > %ld or k bytes %ld > pitch %zu)", p.m_pad,
@@ -554,9 +559,9 @@ int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const Gemm
   }
 #define MXA_DISPATCH(AA, CC)                                              \
   if (p.a == AA && p.c == CC) {                                           \
-    if (mode == 1) return launch_gemm_t<AA, CC, 1>(G, dBp, dP, p, s);     \
-    if (mode == 2) return launch_gemm_t<AA, CC, 2>(G, dBp, dP, p, s);     \
-    return launch_gemm_t<AA, CC, 0>(G, dBp, dP, p, s);                    \
+    if (mode == 1) return launch_gemm_t<AA, CC, 1>(G, dBp, dP, p, s, split_begin, split_end);     \
+    if (mode == 2) return launch_gemm_t<AA, CC, 2>(G, dBp, dP, p, s, split_begin, split_end);     \
+    return launch_gemm_t<AA, CC, 0>(G, dBp, dP, p, s, split_begin, split_end);                    \
   }
   MXA_DISPATCH(16, 1)
   MXA_DISPATCH(16, 2)
@@ -757,15 +762,22 @@ int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double 
 __global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, long m_pad, long p_rows, int n_pad, int splits, long m, int n,
                                                 double *__restrict__ Cout, long ldc, long fill_rows, int mode_trans, int centered,
                                                 const double *__restrict__ sumB, const double *__restrict__ sumfB,
-                                                const double *__restrict__ f, const int *__restrict__ E, int back) {
+                                                const double *__restrict__ f, const int *__restrict__ E, int back, int e_splits, int e_stride) {
   const int j = blockIdx.y;
   const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= fill_rows) return;
   double v = 0.0;
   if (r < m) {
     const size_t tile = (size_t)(r / p_rows), within = (size_t)(r % p_rows), ntiles = (size_t)(m_pad / p_rows);
-    for (int s = 0; s < splits; s++) v += P[(((size_t)s * ntiles + tile) * n_pad + j) * p_rows + within];
-    if (E) v = ldexp(v, back + E[j]);          // undo the operand scaling of the denormal-operand mode (exact)
+    if (E && e_splits > 0) {
+      // host-operand pipeline: B was scaled per K chunk (e_splits splits share one exponent row of E).  Every partial is scaled back
+      // BEFORE it is added, in the same ascending order: power-of-two scaling commutes with rounding, so the sum is bit-identical to the
+      // one-exponent path below
+      for (int s = 0; s < splits; s++) v += ldexp(P[(((size_t)s * ntiles + tile) * n_pad + j) * p_rows + within], back + E[(size_t)(s / e_splits) * e_stride + j]);
+    } else {
+      for (int s = 0; s < splits; s++) v += P[(((size_t)s * ntiles + tile) * n_pad + j) * p_rows + within];
+      if (E) v = ldexp(v, back + E[j]);          // undo the operand scaling of the denormal-operand mode (exact)
+    }
     if (centered) {
       if (mode_trans) v = fma(-2.0 * sumB[j], f[r], v);
       else v += -2.0 * sumfB[j];
@@ -775,10 +787,10 @@ __global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, lo
 }
 
 int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC, long ldc, long fill_rows, int mode_trans, bool centered,
-                  const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s, const int *d_E) {
+                  const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s, const int *d_E, int e_splits, int e_stride) {
   dim3 grid((unsigned)((fill_rows + 255) / 256), n);
   hipLaunchKernelGGL(k_finish, grid, dim3(256), 0, s, dP, p.m_pad, p.p_rows, p.n_pad, p.splits, m, n, dC, ldc, fill_rows, mode_trans, centered ? 1 : 0,
-                     d_sumB, d_sumfB, d_f, d_E, 1074 - kDenUp);
+                     d_sumB, d_sumfB, d_f, d_E, 1074 - kDenUp, e_splits, e_stride);
   MXA_HIP(hipGetLastError());
   return 0;
 }
