@@ -281,14 +281,6 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   if (ensure_workspace(h, n)) return 1;
   harvest_profile(h);   // a previous asynchronous call's events are reused below
   Workspace &w = h->ws;
-  static const int lut_max_n = [] { const char *e = getenv("MXA_LUT_MAX_N"); return e ? atoi(e) : 2; }();
-  const bool use_lut = n <= lut_max_n && n <= 4;
-  GemmPlan p = use_lut ? plan_lut(m, G.k_pad, n) : plan_gemm(m, G.k_pad, n);
-  {
-    std::lock_guard<std::mutex> lk(g_prof_mutex);
-    Geometry &geo = last_geometry();
-    geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c; geo.path = use_lut ? 1 : 0;
-  }
   double *d_sumB = w.d_colpart + (size_t)n * 128, *d_sumfB = d_sumB + n;
   static const int mode = [] { const char *e = getenv("MXA_GEMM_MODE"); return e ? atoi(e) : 2; }();
   const int engine = g_engine.load();
@@ -313,6 +305,27 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
       return 0;
     }
     if (rc8 != 2) return 1;   // 2: the guard declined (B not exactly representable): fp64 path below
+  }
+  // Column peel (engine 0, n = 4q + 1 or 4q + 2, q >= 1): the MFMA tile works on groups of 4 columns, so 10 columns cost 12 (the
+  // reference harness's default n = 10: 0.71 of the peak).  The 1-2 odd columns go through the same guarded EXACT int8 route as n <= 2 --
+  // one HBM-bound pass over the packed matrix, 2.4x cheaper than a fourth-full MFMA group -- and the multiple of 4 runs on the fp64
+  // MFMA without padding.  If the guard declines, all n columns take the MFMA path as before.
+  static const bool peel_on = [] { const char *e = getenv("MXA_PEEL"); return !e || atoi(e) != 0; }();
+  const int n_odd = n & 3;
+  if (peel_on && engine == 0 && n > 4 && (n_odd == 1 || n_odd == 2) && k >= 128) {
+    const int n4 = n - n_odd;
+    const int rc8 = gemm_i8_device(G, trans, n_odd, dB + (size_t)n4 * ldb, ldb, dC + (size_t)n4 * ldc, ldc, fill_rows, centered, d_sumB + n4, d_sumfB + n4, h->d_f, w, s,
+                                   nullptr, nullptr, nullptr, true);
+    if (rc8 == 0) n = n4;            // the rest of this function multiplies the first n4 columns
+    else if (rc8 != 2) return 1;
+  }
+  static const int lut_max_n = [] { const char *e = getenv("MXA_LUT_MAX_N"); return e ? atoi(e) : 2; }();
+  const bool use_lut = n <= lut_max_n && n <= 4;
+  GemmPlan p = use_lut ? plan_lut(m, G.k_pad, n) : plan_gemm(m, G.k_pad, n);
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mutex);
+    Geometry &geo = last_geometry();
+    geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c; geo.path = use_lut ? 1 : 0;
   }
   // MODE 2 (default): genotype operand as the denormal z * 2^-1074 (one VALU per fragment instead of two); B scaled per column
   const int *d_E = nullptr;
@@ -374,7 +387,6 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
   harvest_profile(h);
   Workspace &w = h->ws;
   hipStream_t s = h->stream;
-  const GemmPlan p = plan_gemm(m, G.k_pad, n);
   // scratch: per-group column-maximum partials (64 n doubles each) + column sums; per-group exponents
   if (grow(&w.d_colpart, &w.cap_colpart, (size_t)n * (64 * (kPipeChunks + 2) + 2) + 16)) return 1;
   if (w.cap_exp < (size_t)n * kPipeChunks) {
@@ -390,6 +402,28 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
   if (!b_local) { if (grow(&w.d_Bstage, &w.cap_Bstage, (size_t)k * n)) return 1; dB = w.d_Bstage; dldb = k; }
   double *dC = C; long dldc = ldc;
   if (!c_local) { if (grow(&w.d_Cstage, &w.cap_Cstage, (size_t)fill_rows * n)) return 1; dC = w.d_Cstage; dldc = fill_rows; }
+  // column peel as in gemm_device: the 1-2 odd columns go first (their part of B is uploaded ahead of the pipeline) through the guarded
+  // exact int8 route; the K-range / row-range pipeline then multiplies the multiple of 4
+  static const bool peel_on = [] { const char *e = getenv("MXA_PEEL"); return !e || atoi(e) != 0; }();
+  const int n_all = n, n_odd = n & 3;
+  bool b_uploaded = false;
+  if (peel_on && engine == 0 && n > 4 && (n_odd == 1 || n_odd == 2) && k >= 128) {
+    const int n4 = n - n_odd;
+    if (!b_local) {
+      if (kmode) MXA_HIP(hipMemcpy2DAsync(w.d_Bstage + (size_t)n4 * k, sizeof(double) * k, B + (size_t)n4 * ldb, sizeof(double) * ldb, sizeof(double) * k, n_odd, hipMemcpyDefault, s));
+      else {   // row-range mode uploads the whole (small) B anyway
+        if (ldb == k) MXA_HIP(hipMemcpyAsync(w.d_Bstage, B, sizeof(double) * (size_t)k * n, hipMemcpyDefault, s));
+        else MXA_HIP(hipMemcpy2DAsync(w.d_Bstage, sizeof(double) * k, B, sizeof(double) * ldb, sizeof(double) * k, n, hipMemcpyDefault, s));
+        b_uploaded = true;
+      }
+    }
+    if (centered && launch_colsums(dB + (size_t)n4 * dldb, dldb, k, n_odd, trans ? nullptr : h->d_f, d_sumscratch, d_sumB + n4, d_sumfB + n4, s)) return 1;
+    const int rc8 = gemm_i8_device(G, trans, n_odd, dB + (size_t)n4 * dldb, dldb, dC + (size_t)n4 * dldc, dldc, fill_rows, centered, d_sumB + n4, d_sumfB + n4, h->d_f, w, s,
+                                   nullptr, nullptr, nullptr, true);
+    if (rc8 == 0) n = n4;
+    else if (rc8 != 2) return 1;
+  }
+  const GemmPlan p = plan_gemm(m, G.k_pad, n);
   { std::lock_guard<std::mutex> lk(g_prof_mutex); Geometry &geo = last_geometry(); geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c; geo.path = 0; }
   MXA_HIP(hipEventRecord(h->pev[0], s));
   for (hipStream_t ps : h->pipe) MXA_HIP(hipStreamWaitEvent(ps, h->pev[0], 0));   // earlier calls are done with Bp / P
@@ -415,11 +449,11 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
     if (centered && launch_colsums(dB, dldb, k, n, trans ? nullptr : h->d_f, d_sumscratch, d_sumB, d_sumfB, s)) return 1;
     if (launch_finish(w.d_P, p, m, n, dC, dldc, fill_rows, trans ? 1 : 0, centered, d_sumB, d_sumfB, h->d_f, s, w.d_exp, spc, n)) return 1;
     if (!c_local) {
-      if (ldc == fill_rows) MXA_HIP(hipMemcpyAsync(C, dC, sizeof(double) * (size_t)fill_rows * n, hipMemcpyDefault, s));
-      else MXA_HIP(hipMemcpy2DAsync(C, sizeof(double) * ldc, dC, sizeof(double) * fill_rows, sizeof(double) * fill_rows, n, hipMemcpyDefault, s));
+      if (ldc == fill_rows) MXA_HIP(hipMemcpyAsync(C, dC, sizeof(double) * (size_t)fill_rows * n_all, hipMemcpyDefault, s));
+      else MXA_HIP(hipMemcpy2DAsync(C, sizeof(double) * ldc, dC, sizeof(double) * fill_rows, sizeof(double) * fill_rows, n_all, hipMemcpyDefault, s));
     }
   } else {
-    if (!b_local) {
+    if (!b_local && !b_uploaded) {
       if (ldb == k) MXA_HIP(hipMemcpyAsync(w.d_Bstage, B, sizeof(double) * (size_t)k * n, hipMemcpyDefault, s));
       else MXA_HIP(hipMemcpy2DAsync(w.d_Bstage, sizeof(double) * k, B, sizeof(double) * ldb, sizeof(double) * k, n, hipMemcpyDefault, s));
     }
@@ -458,7 +492,7 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
       const long r0 = (long)c * rows_chunk, r1 = std::min(m, r0 + rows_chunk);
       const long cnt = (r1 == m) ? fill_rows - r0 : r1 - r0;
       MXA_HIP(hipStreamWaitEvent(s, h->pev[10 + c], 0));
-      if (!c_local) MXA_HIP(hipMemcpy2DAsync(C + r0, sizeof(double) * ldc, dC + r0, sizeof(double) * fill_rows, sizeof(double) * cnt, n, hipMemcpyDefault, s));
+      if (!c_local) MXA_HIP(hipMemcpy2DAsync(C + r0, sizeof(double) * ldc, dC + r0, sizeof(double) * fill_rows, sizeof(double) * cnt, n_all, hipMemcpyDefault, s));
     }
   }
   MXA_HIP(hipStreamSynchronize(s));

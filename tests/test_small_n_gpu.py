@@ -166,3 +166,43 @@ def test_zero_vector_short_k_and_mixed_columns(mx):
         assert np.abs(C - ref).max() <= 1e-11 * np.abs(ref).max()
     finally:
         dg.free_compressed(obj)
+
+
+def _last_n(mx):
+    import ctypes
+    L = mx.check_library_handle()
+    gm, gk, gn, gs, ga, gc = ctypes.c_long(), ctypes.c_long(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    L.mxa_last_geometry(ctypes.byref(gm), ctypes.byref(gk), ctypes.byref(gn), ctypes.byref(gs), ctypes.byref(ga), ctypes.byref(gc))
+    return gn.value, ga.value, gc.value
+
+
+@pytest.mark.parametrize("n", [5, 6, 10, 33])
+def test_column_peel_exact_route_and_fallback(mx, n):
+    """n = 4q + 1 / 4q + 2: the odd columns take the guarded exact int8 route, the MFMA tile multiplies 4q columns without padding (the
+    reference harness's n = 10 becomes 8 + 2); a peeled column whose entries span too many binades sends all n columns to the MFMA"""
+    o = Oracle()
+    snps, indiv = 2050, 777
+    prob = _adversarial_problem(snps, indiv, seed=5)
+    dg = mx.dgemm_compressed
+    obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], n)
+    try:
+        for centered in (0, 1):
+            dg.set_options(use_gpu=True, not_center=not centered, verbose=0)
+            for trans in (0, 1):
+                k = indiv if trans else snps
+                m = snps if trans else indiv
+                B = np.random.default_rng(n + trans).standard_normal((n, k))
+                C = _run(mx, obj, prob, trans, B)
+                assert _last_n(mx)[0] == n - n % 4                       # the MFMA launch saw the multiple of 4 only
+                ref = o.dgemm_dense(trans, prob, B, centered)[:, :m]
+                assert np.abs(C - ref).max() <= 1e-11 * np.abs(ref).max()
+                B[n - 1] = _wide_B(k, 1, 70, seed=2, big_every=5)[0]     # 230 binades in the last column: guard declines
+                C = _run(mx, obj, prob, trans, B)
+                assert _last_n(mx)[0] == n
+                ref = o.dgemm_dense(trans, prob, B, centered)[:, :m]
+                err = np.abs(C - ref)
+                abssum = o.dgemm_dense(trans, prob, np.abs(B), 0)[:, :m]
+                tol = k * U * abssum + (8 * U * np.abs(ref - o.dgemm_dense(trans, prob, B, 0)[:, :m]) if centered else 0.0)
+                assert np.all(err <= tol + 1e-300)
+    finally:
+        dg.free_compressed(obj)
