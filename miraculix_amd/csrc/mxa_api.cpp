@@ -312,7 +312,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   // MFMA without padding.  If the guard declines, all n columns take the MFMA path as before.
   static const bool peel_on = [] { const char *e = getenv("MXA_PEEL"); return !e || atoi(e) != 0; }();
   const int n_odd = n & 3;
-  if (peel_on && engine == 0 && n > 4 && (n_odd == 1 || n_odd == 2) && k >= 128) {
+  if (peel_on && (engine == 0 || engine == 2) && n > 4 && (n_odd == 1 || n_odd == 2) && k >= 128) {   // engine 2 = engine 0 for n > 4
     const int n4 = n - n_odd;
     const int rc8 = gemm_i8_device(G, trans, n_odd, dB + (size_t)n4 * ldb, ldb, dC + (size_t)n4 * ldc, ldc, fill_rows, centered, d_sumB + n4, d_sumfB + n4, h->d_f, w, s,
                                    nullptr, nullptr, nullptr, true);
