@@ -4,7 +4,7 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as
  * the checker / the CPU baseline.  The product (miraculix_amd/csrc) never links or calls it.
  *
- * Parity status: PINNED.  This restatement is checked (tests/test_oracle_vs_ref.py, run in the
+ * Parity status: PINNED.  This restatement is checked (tests/test_oracle.py::test_port_vs_live_reference_library, run in the
  * build container where /root/reference exists) against the reference's own CPU library compiled
  * from its sources by oracle/Makefile.ref, and against the committed fixtures tests/golden/ that
  * were emitted by that library (script: tests/golden/make_golden.py).
