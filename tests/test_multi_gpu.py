@@ -208,3 +208,31 @@ def test_bed_ranges_reproduce_the_unsharded_object(mx, tmp_path):
         dg.free_compressed(multi)
         for obj, _ in parts:
             dg.free_compressed(obj)
+
+
+def test_multi_object_with_pipelined_host_transfers(mx):
+    """two shards whose 'T' result blocks (150k x 32 doubles = 38 MB each) are large enough for the row-range pipeline of
+    gemm_host_pipelined: it then runs inside both worker threads at the same time; integer-valued operands make every sum exact, so the
+    sharded object must equal the single-device object bit for bit"""
+    import torch
+    from bench import synth_genotypes_device
+    dev = torch.device("cuda", 0)
+    snps, indiv, n = 300_000, 2_001, 32
+    plink = synth_genotypes_device(torch, snps, indiv, 9, dev)
+    plink_t = mx.compressed_operations.transpose_genotype_matrix(plink, snps, indiv)
+    f = mx.read_plink.calc_freq(plink, snps, indiv)
+    dg = mx.dgemm_compressed
+    dg.set_options(use_gpu=True, not_center=True, verbose=0)
+    single = dg.init_compressed(plink, plink_t, snps, indiv, f, n)
+    with _env(MIRACULIX_NUM_GPUS=2):
+        multi = dg.init_compressed(plink, plink_t, snps, indiv, f, n)
+    try:
+        assert dg.num_shards(multi) == 2
+        rng = np.random.default_rng(4)
+        BT = np.asfortranarray(rng.integers(-20, 20, size=(indiv, n)).astype(np.float64))
+        BN = np.asfortranarray(rng.integers(-20, 20, size=(snps, n)).astype(np.float64))
+        assert np.array_equal(dg.dgemm_compressed_main(True, multi, BT, snps, indiv), dg.dgemm_compressed_main(True, single, BT, snps, indiv))
+        assert np.array_equal(dg.dgemm_compressed_main(False, multi, BN, snps, indiv), dg.dgemm_compressed_main(False, single, BN, snps, indiv))
+    finally:
+        dg.free_compressed(multi)
+        dg.free_compressed(single)
