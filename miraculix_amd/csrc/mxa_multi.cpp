@@ -110,6 +110,14 @@ Rccl &rccl() {
   return r;
 }
 
+// the calling thread's current device is put back when a multi-device entry returns (the entries switch devices while they work;
+// a caller such as PyTorch keeps its own notion of the current device)
+struct DeviceRestore {
+  int prev = -1;
+  DeviceRestore() { if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; } }
+  ~DeviceRestore() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 struct Multi {
   uint32_t magic = kMagicMulti;
   long snps = 0, indiv = 0;
@@ -211,6 +219,7 @@ int multi_requested() {
 void multi_destroy(void *obj) {
   Multi *m = as_multi(obj);
   if (!m) return;
+  DeviceRestore restore;
   m->worker.clear();   // joins the threads
   if (m->use_rccl) for (void *c : m->comm) if (c) (void)rccl().CommDestroy(c);
   for (size_t g = 0; g < m->shard.size(); g++) {
@@ -233,6 +242,7 @@ static int multi_build(long snps, long indiv, int shards, void **out, const std:
   if (out) *out = nullptr;
   if (!out) { set_error(1, "plink2compressed: compressed is NULL"); return 1; }
   if (snps <= 0 || indiv <= 0) { set_error(1, "plink2compressed: snps and indiv must be positive"); return 1; }
+  DeviceRestore restore;
   Multi *m = new Multi();
   m->snps = snps; m->indiv = indiv;
   shard_blocks(snps, shards, m->begin, m->end);
@@ -357,6 +367,7 @@ int multi_gemm(void *obj, bool trans, int n, const double *B, long ldb, double *
   Multi *m = as_multi(obj);
   if (!m) { set_error(2, "dgemm_compressed: invalid or uninitialised compressed object"); return 1; }
   if (n <= 0) return 0;
+  DeviceRestore restore;
   if (!B || !C) { set_error(1, "dgemm_compressed: B and C must not be NULL"); return 1; }
   const long snps = m->snps, indiv = m->indiv;
   const int G = (int)m->shard.size();
@@ -387,6 +398,7 @@ int multi_gram(void *obj, int n, const double *V, long ldv, double *out, long ld
   Multi *m = as_multi(obj);
   if (!m) { set_error(2, "mxa_gram_matvec: invalid or uninitialised compressed object"); return 1; }
   if (n <= 0) return 0;
+  DeviceRestore restore;
   if (!V || !out) { set_error(1, "mxa_gram_matvec: V and out must not be NULL"); return 1; }
   const long indiv = m->indiv;
   if (ldv < indiv || ldo < indiv) { set_error(7, "mxa_gram_matvec: leading dimension too small (ldv %ld, ldo %ld < %ld)", ldv, ldo, indiv); return 1; }
