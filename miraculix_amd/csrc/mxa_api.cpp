@@ -295,16 +295,24 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   const bool auto_i8 = engine == 0 && n <= 2 && k >= 128;
   if (engine == 1 || (engine == 2 && n <= 4) || auto_i8) {   // exact int8 slicing of B on the int8 matrix cores (mxa_gemm_i8.hip)
     int splits8 = 1;
+    const int *d_flag = nullptr;
+    // auto_i8: the verdict of the exactness check stays on the device (guard = 2) -- the int8 chain and the fp64 fallback are both enqueued and
+    // test the flag themselves, so the product has no host round trip in its middle (44 us of a 1.2 ms product in the kernel timeline)
     const int rc8 = gemm_i8_device(G, trans, n, dB, ldb, dC, ldc, fill_rows, centered, d_sumB, d_sumfB, h->d_f, w, s, prof ? h->ev0 : nullptr, prof ? h->ev1 : nullptr,
-                                   &splits8, auto_i8);
-    if (rc8 == 0) {
+                                   &splits8, auto_i8 ? 2 : 0, &d_flag);
+    if (rc8 == 0 || rc8 == 3) {
+      if (rc8 == 3) {   // fp64 pair tables, run only if the flag is set
+        const GemmPlan pl = plan_lut(m, G.k_pad, n);
+        if (launch_lut(G, dB, ldb, n, w.d_P, pl, s, d_flag)) return 1;
+        if (launch_finish(w.d_P, pl, m, n, dC, ldc, fill_rows, trans ? 1 : 0, centered, d_sumB, d_sumfB, h->d_f, s, nullptr, 0, 0, d_flag)) return 1;
+      }
       std::lock_guard<std::mutex> lk(g_prof_mutex);
       Geometry &geo = last_geometry();
-      geo.splits = splits8; geo.a = 0; geo.c = 0; geo.path = 2;
+      geo.m = m; geo.k = k; geo.n = n; geo.splits = splits8; geo.a = 0; geo.c = 0; geo.path = rc8 == 3 ? 4 : 2; geo.d_flag = d_flag; geo.flag_dev = h->device;
       h->prof_pending = prof;
       return 0;
     }
-    if (rc8 != 2) return 1;   // 2: the guard declined (B not exactly representable): fp64 path below
+    if (rc8 != 2) return 1;   // 2: the host-checked guard declined (B not exactly representable): fp64 path below
   }
   // Column peel (engine 0, n = 4q + 1 or 4q + 2, q >= 1): the MFMA tile works on groups of 4 columns, so 10 columns cost 12 (the
   // reference harness's default n = 10: 0.71 of the peak).  The 1-2 odd columns go through the same guarded EXACT int8 route as n <= 2 --
@@ -795,7 +803,16 @@ void mxa_profile_get(int *launches, double *total_ms) {
   if (launches) *launches = profile().launches;
   if (total_ms) *total_ms = profile().total_ms;
 }
-int mxa_last_path(void) { return last_geometry().path; }
+int mxa_last_path(void) {
+  const Geometry g = last_geometry();
+  if (g.path != 4) return g.path;
+  // n <= 2 under the default engine: the route was chosen on the device; read the verdict now (the entries that use it are synchronous)
+  int flag = 0, prev = 0;
+  (void)hipGetDevice(&prev);
+  if (hipSetDevice(g.flag_dev) != hipSuccess || hipMemcpy(&flag, g.d_flag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); flag = 0; }
+  (void)hipSetDevice(prev);
+  return flag ? 1 : 2;
+}
 void mxa_last_geometry(long *m, long *k, int *n, int *splits, int *a_tile, int *c_tile) {
   const Geometry &g = last_geometry();
   if (m) *m = g.m; if (k) *k = g.k; if (n) *n = g.n; if (splits) *splits = g.splits; if (a_tile) *a_tile = g.a; if (c_tile) *c_tile = g.c;

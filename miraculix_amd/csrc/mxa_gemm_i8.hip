@@ -78,7 +78,8 @@ __device__ __forceinline__ unsigned int digit_of(const Digits9 &d, int S, int s)
 }
 
 __global__ void __launch_bounds__(256) k_slice_B(const double *__restrict__ B, long ldb, long k, int n, const int *__restrict__ E, int S, int nc, int NT,
-                                                 long T_total, int ncols, uint32_t *__restrict__ Bs, long total) {
+                                                 long T_total, int ncols, uint32_t *__restrict__ Bs, long total, const int *__restrict__ skip_if_set) {
+  if (skip_if_set && *skip_if_set) return;   // guarded route: B is not exactly representable, the fp64 fallback does this product
   // one thread per (q, column cj = chunk*nc + jj, h, T): reads the 4 values k = 128(T/4) + 64h + 16(T%4) + 4i + q (i = 0..3), writes dword q of
   // lane (h, col) for each slice.  q runs fastest, then the column: 16-byte lane records and 128-byte runs of doubles.
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -141,8 +142,9 @@ struct SchedIter {
 template <int NT, int MT, int WC, bool DIAG>
 __global__ void __launch_bounds__(256, 1)
 k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict__ Bs, long T_total, int *__restrict__ P, long m_pad, int e_pad,
-          int rowblocks, int nchunks, int stages_total, int stages_per_split, unsigned long long *__restrict__ diag) {
+          int rowblocks, int nchunks, int stages_total, int stages_per_split, unsigned long long *__restrict__ diag, const int *__restrict__ skip_if_set) {
   using Cfg = I8Cfg<NT>;
+  if (skip_if_set && *skip_if_set) return;
   constexpr int NTW = NT / WC;
   static_assert(NT % WC == 0 && MT * (4 / WC) == 8 && MT * NTW <= 16, "wave tiling");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -279,8 +281,9 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
 __global__ void __launch_bounds__(256) k_finish_i8(const int *__restrict__ P, long m_pad, int e_pad, int splits, long m, int n, int S, int nc, int NT,
                                                    const int *__restrict__ E, const double *__restrict__ colmax_part, double *__restrict__ Cout, long ldc,
                                                    long fill_rows, int mode_trans, int centered, const double *__restrict__ sumB, const double *__restrict__ sumfB,
-                                                   const double *__restrict__ f) {
+                                                   const double *__restrict__ f, const int *__restrict__ skip_if_set) {
   __shared__ double sh[32][33];
+  if (skip_if_set && *skip_if_set) return;
   __shared__ double contrib[8][8 * 32 + 1];        // scaled terms of 8 rows x all expanded columns of the chunk
   __shared__ int bad[32];                           // column holds an inf or a NaN: the result column is NaN, like 0 * inf in fp64
   const int chunk = blockIdx.y;
@@ -363,6 +366,54 @@ __global__ void __launch_bounds__(256) k_finish_i8(const int *__restrict__ P, lo
   }
 }
 
+
+// n <= 2 (one tile of 32 expanded columns, e = s * nc + jj, nc * S <= 32): 64 rows per workgroup, 32 lanes per row, 8 rows per half-wave
+// with all loads of the 8 rows issued before the first use (the kernel is pure HBM streaming: splits x 128 bytes per row).  Lane e adds its
+// digit's int32 partials of all K splits exactly (int64), scales (exact), and the lanes of a column are added in a fixed butterfly order
+// (log2(S) levels: at most 5 roundings per result, fewer than the S - 1 of a sequential sum).
+constexpr int kFinSmallRows = 8;   // rows per half-wave
+__global__ void __launch_bounds__(256) k_finish_i8_small(const int *__restrict__ P, long m_pad, int splits, long m, int n, int S, int nc, const int *__restrict__ E,
+                                                         const double *__restrict__ colmax_part, double *__restrict__ Cout, long ldc, long fill_rows, int mode_trans,
+                                                         int centered, const double *__restrict__ sumB, const double *__restrict__ sumfB, const double *__restrict__ f,
+                                                         const int *__restrict__ skip_if_set) {
+  if (skip_if_set && *skip_if_set) return;
+  const int e = threadIdx.x & 31;
+  const long r0 = ((long)blockIdx.x * 8 + (threadIdx.x >> 5)) * kFinSmallRows;
+  const int s = e / nc, jj = e - s * nc;
+  const bool live = e < nc * S;
+  const int sh = live ? E[jj] - 8 * (s + 1) : 0;
+  long long t[kFinSmallRows];
+#pragma unroll
+  for (int i = 0; i < kFinSmallRows; i++) t[i] = 0;
+  for (int sp = 0; sp < splits; sp++) {
+    const int *Ps = P + ((size_t)sp * m_pad + r0) * 32 + e;
+#pragma unroll
+    for (int i = 0; i < kFinSmallRows; i++) t[i] += (r0 + i < m) ? Ps[(size_t)i * 32] : 0;   // m_pad rows exist; rows >= m hold padding
+  }
+  bool bad = false;
+  double cs = 0.0;
+  if (e < nc && e < n) {
+    double cm = 0.0;
+    for (int c = 0; c < 64; c++) cm = fmax(cm, colmax_part[(size_t)e * 64 + c]);
+    bad = !(cm <= 1.7976931348623157e308);   // a column with inf / NaN: NaN, like 0 * inf in fp64
+    if (centered) cs = -2.0 * (mode_trans ? sumB[e] : sumfB[e]);
+  }
+#pragma unroll
+  for (int i = 0; i < kFinSmallRows; i++) {
+    const long r = r0 + i;
+    double v = live ? ldexp((double)t[i], sh) : 0.0;
+    // lanes of one column: e = jj, jj + nc, jj + 2 nc, ...  (nc = 1: all 32 lanes; nc = 2: lanes of equal parity)
+    for (int off = 16; off >= nc; off >>= 1) v += __shfl_xor(v, off, 32);
+    if (e < nc && e < n && r < fill_rows) {
+      if (r < m) {
+        if (bad) v = __longlong_as_double(0x7ff8000000000000ll);
+        if (centered) v = mode_trans ? fma(cs, f[r], v) : v + cs;
+      } else v = 0.0;
+      Cout[r + (long)e * ldc] = v;
+    }
+  }
+}
+
 struct I8Plan { int S, nc, nchunks, NT, e_pad, rowblocks, stages_total, stages_per_split, splits; long m_pad, T_total; };
 
 static I8Plan plan_i8(long m, long k_pad, int n) {
@@ -387,6 +438,20 @@ static I8Plan plan_i8(long m, long k_pad, int n) {
   long want = (2048 + units - 1) / units;                        // 256 resident workgroups -> >= 8 rounds
   long max_splits = std::max<long>(1, p.stages_total / 32);
   long splits = std::max<long>(1, std::min<long>(want, max_splits));
+  {
+    // like plan_gemm: around the target pick the split count whose workgroup total fills whole rounds of the resident slots best (two
+    // workgroups per CU for NT <= 4, else one): 391 row blocks x 6 splits = 4.58 rounds of 512 wastes 8 % of the last round's HBM time
+    static const long search = [] { const char *e = getenv("MXA_I8_SPLIT_SEARCH"); return e ? atol(e) : 1L; }();
+    const long resident = p.NT <= 4 ? 512 : 256;
+    double best_eff = -1.0;
+    const long lo = splits, hi = std::min<long>(max_splits, splits + splits / 2 + 2);
+    for (long cand = lo; search && cand <= hi; cand++) {
+      const long per = (p.stages_total + cand - 1) / cand, actual = (p.stages_total + per - 1) / per;
+      const long wgs = units * actual;
+      const double eff = (double)wgs / (double)(resident * ((wgs + resident - 1) / resident));
+      if (eff > best_eff + 0.02) { best_eff = eff; splits = cand; }   // prefer fewer splits unless the fill improves by 2 %
+    }
+  }
   splits = std::max<long>(splits, (p.stages_total + 32767) / 32768);   // int32 accumulators: 2 * 128 * (K per split) < 2^31
   p.stages_per_split = (int)((p.stages_total + splits - 1) / splits);
   p.splits = (p.stages_total + p.stages_per_split - 1) / p.stages_per_split;
@@ -394,7 +459,7 @@ static I8Plan plan_i8(long m, long k_pad, int n) {
 }
 
 template <int NT, int MT, int WC>
-static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const I8Plan &p, hipStream_t s) {
+static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const I8Plan &p, hipStream_t s, const int *skip_if_set) {
   using Cfg = I8Cfg<NT>;
   static unsigned long long attr_a = 0, attr_b = 0;   // function attributes are per device
   if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8<NT, MT, WC, false>), Cfg::kLds, &attr_a) ||
@@ -405,7 +470,7 @@ static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const 
     unsigned long long *d_diag = nullptr;
     MXA_HIP(hipMalloc((void **)&d_diag, sizeof(unsigned long long) * 2 * grid));
     hipLaunchKernelGGL((k_gemm_i8<NT, MT, WC, true>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBs, p.T_total, dP, p.m_pad, p.e_pad,
-                       p.rowblocks, p.nchunks, p.stages_total, p.stages_per_split, d_diag);
+                       p.rowblocks, p.nchunks, p.stages_total, p.stages_per_split, d_diag, skip_if_set);
     std::vector<unsigned long long> h(2 * grid);
     MXA_HIP(hipStreamSynchronize(s));
     MXA_HIP(hipMemcpy(h.data(), d_diag, sizeof(unsigned long long) * 2 * grid, hipMemcpyDeviceToHost));
@@ -418,7 +483,7 @@ static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const 
     return 0;
   }
   hipLaunchKernelGGL((k_gemm_i8<NT, MT, WC, false>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBs, p.T_total, dP, p.m_pad, p.e_pad,
-                     p.rowblocks, p.nchunks, p.stages_total, p.stages_per_split, (unsigned long long *)nullptr);
+                     p.rowblocks, p.nchunks, p.stages_total, p.stages_per_split, (unsigned long long *)nullptr, skip_if_set);
   MXA_HIP(hipGetLastError());
   return 0;
 }
@@ -426,7 +491,8 @@ static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const 
 // Whole product on the device; B, C device pointers; asynchronous on s.  The workspace (exponents, slices, partials) lives with the
 // handle and only grows.
 int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool centered, const double *d_sumB,
-                   const double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out, bool guard) {
+                   const double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out, int guard,
+                   const int **flag_out) {
   const long m = G.rows, k = G.k;
   const I8Plan p = plan_i8(m, G.k_pad, n);
   if (p.m_pad > G.rows_pad) { set_error(4, "internal: packed matrix smaller than the i8 plan"); return 1; }
@@ -449,6 +515,7 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   int *d_P = reinterpret_cast<int *>(base + part_bytes + e_bytes + bs_bytes);
 
   // E_j = e + 2: |b| * 2^-E_j < 1/4, inside the remainder range of the balanced digits
+  const int *skip = nullptr;   // guard = 2: the kernels below test this device flag themselves
   if (!guard) {
     if (launch_colexp(dB, ldb, k, n, d_part, d_E, 2, s)) return 1;
   } else {
@@ -457,39 +524,47 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
     // i.e. the exponent span e_max - e_min <= 8S - 55; the recombination ldexp(t, E_j - 8(s+1)) stays normal iff e_max + 2 - 8S >= -1021.
     int *d_flag = d_E + n, h_flag = 1;
     if (launch_colexp(dB, ldb, k, n, d_part, d_E, 2, s, d_flag, 8 * p.S - 55, 8 * p.S - 1023)) return 1;
-    MXA_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
-    MXA_HIP(hipStreamSynchronize(s));
-    if (h_flag) return 2;
+    if (guard == 1) {
+      MXA_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+      MXA_HIP(hipStreamSynchronize(s));
+      if (h_flag) return 2;
+    } else {
+      skip = d_flag;
+      if (flag_out) *flag_out = d_flag;
+    }
   }
   if (p.NT * 32 != p.nc * p.S) MXA_HIP(hipMemsetAsync(d_Bs, 0, bs_bytes, s));   // expanded columns beyond nc*S are never written
   {
     const int ncols = p.nchunks * p.nc;
     const long total = (long)p.T_total * 2 * ncols * 4;
     hipLaunchKernelGGL(k_slice_B, dim3((unsigned)std::min<long>((total + 255) / 256, 256L * 64)), dim3(256), 0, s, dB, ldb, k, n, d_E, p.S, p.nc, p.NT,
-                       p.T_total, ncols, reinterpret_cast<uint32_t *>(d_Bs), total);
+                       p.T_total, ncols, reinterpret_cast<uint32_t *>(d_Bs), total, skip);
   }
   MXA_HIP(hipGetLastError());
   if (ev0) MXA_HIP(hipEventRecord(ev0, s));
   int rc = 0;
   switch (p.NT) {
-    case 1: rc = launch_i8_t<1, 2, 1>(G, d_Bs, d_P, p, s); break;
-    case 2: rc = launch_i8_t<2, 2, 1>(G, d_Bs, d_P, p, s); break;
-    case 3: rc = launch_i8_t<3, 2, 1>(G, d_Bs, d_P, p, s); break;
-    case 4: rc = launch_i8_t<4, 2, 1>(G, d_Bs, d_P, p, s); break;
-    case 5: rc = launch_i8_t<5, 2, 1>(G, d_Bs, d_P, p, s); break;
-    case 6: rc = launch_i8_t<6, 2, 1>(G, d_Bs, d_P, p, s); break;
-    case 7: rc = launch_i8_t<7, 2, 1>(G, d_Bs, d_P, p, s); break;
-    default: rc = launch_i8_t<8, 4, 2>(G, d_Bs, d_P, p, s); break;
+    case 1: rc = launch_i8_t<1, 2, 1>(G, d_Bs, d_P, p, s, skip); break;
+    case 2: rc = launch_i8_t<2, 2, 1>(G, d_Bs, d_P, p, s, skip); break;
+    case 3: rc = launch_i8_t<3, 2, 1>(G, d_Bs, d_P, p, s, skip); break;
+    case 4: rc = launch_i8_t<4, 2, 1>(G, d_Bs, d_P, p, s, skip); break;
+    case 5: rc = launch_i8_t<5, 2, 1>(G, d_Bs, d_P, p, s, skip); break;
+    case 6: rc = launch_i8_t<6, 2, 1>(G, d_Bs, d_P, p, s, skip); break;
+    case 7: rc = launch_i8_t<7, 2, 1>(G, d_Bs, d_P, p, s, skip); break;
+    default: rc = launch_i8_t<8, 4, 2>(G, d_Bs, d_P, p, s, skip); break;
   }
   if (rc) return rc;
   if (ev1) MXA_HIP(hipEventRecord(ev1, s));
-  {
+  if (p.nchunks == 1 && p.NT == 1 && p.nc * p.S <= 32 && (p.nc == 1 || p.nc == 2)) {   // n <= 2: one tile, the fast finish
+    hipLaunchKernelGGL(k_finish_i8_small, dim3((unsigned)((fill_rows + 8 * kFinSmallRows - 1) / (8 * kFinSmallRows))), dim3(256), 0, s, d_P, p.m_pad, p.splits, m, n, p.S, p.nc, d_E, d_part, dC, ldc, fill_rows,
+                       trans ? 1 : 0, centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip);
+  } else {
     dim3 grid((unsigned)((fill_rows + 31) / 32), p.nchunks);
     hipLaunchKernelGGL(k_finish_i8, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, d_part, dC, ldc, fill_rows, trans ? 1 : 0,
-                       centered ? 1 : 0, d_sumB, d_sumfB, d_f);
+                       centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip);
   }
   MXA_HIP(hipGetLastError());
-  return 0;
+  return guard == 2 ? 3 : 0;
 }
 
 }  // namespace mxa

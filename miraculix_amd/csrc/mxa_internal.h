@@ -79,7 +79,8 @@ struct Profile {
 };
 Profile &profile();
 
-struct Geometry { long m = 0, k = 0; int n = 0, splits = 0, a = 0, c = 0, path = 0; };   // path: 0 k_gemm, 1 k_lut, 2 k_gemm_i8
+// path: 0 k_gemm, 1 k_lut, 2 k_gemm_i8, 4 decided on the device (flag != 0: k_lut, else k_gemm_i8; resolved by mxa_last_path())
+struct Geometry { long m = 0, k = 0; int n = 0, splits = 0, a = 0, c = 0, path = 0; const int *d_flag = nullptr; int flag_dev = 0; };
 Geometry &last_geometry();
 
 // ---- host-side engine entry points shared by mxa_api.cpp (single device) and mxa_multi.cpp (SNP shards over several devices)
@@ -145,11 +146,12 @@ GemmPlan plan_gemm(long m, long k_pad, int n, int force_splits = 0);
 // K splits [split_begin, split_end) only (split_end < 0: all)
 int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, int mode, hipStream_t s, int split_begin = 0, int split_end = -1);
 GemmPlan plan_lut(long m, long k_pad, int n);
-int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double *dP, const GemmPlan &p, hipStream_t s);
+// run_if_set (nullable, device int): the kernel does nothing unless *run_if_set != 0 (fallback of the guarded small-n route)
+int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double *dP, const GemmPlan &p, hipStream_t s, const int *run_if_set = nullptr);
 // fill_rows: rows [m, fill_rows) of every column are zero-filled (fill_rows <= ldc)
 int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC, long ldc, long fill_rows, int mode_trans,
                   bool centered, const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s, const int *d_E = nullptr, int e_splits = 0,
-                  int e_stride = 0);
+                  int e_stride = 0, const int *run_if_set = nullptr);
 // per-device one-time hipFuncSetAttribute(MaxDynamicSharedMemorySize): function attributes are per device, `mask` has one bit per device
 int ensure_dyn_lds(const void *func, int bytes, unsigned long long *mask);
 int launch_transpose_2bit(const uint8_t *d_in, long rows, long cols, uint8_t *d_out, hipStream_t s);
@@ -162,9 +164,13 @@ int launch_sparse_times_plink(const uint8_t *dP, size_t pitch, long entries, int
                               double *dC_slab, long ldc, long e_base, long e_count, hipStream_t s);
 // opt-in engine (mxa_set_engine(1) / MXA_ENGINE=i8, mxa_gemm_i8.hip): whole product by exact int8 slicing of B.
 // Asynchronous on s; ev0/ev1 (optional) are recorded around the dominant kernel.
-// guard: first check on the device that every column of B is represented EXACTLY by the slicing (finite, dynamic range inside the
-// digits, no underflow in the recombination); if not, nothing is computed and 2 is returned (the caller takes the fp64 path).
+// guard: check on the device that every column of B is represented EXACTLY by the slicing (finite, dynamic range inside the digits, no
+// underflow in the recombination).  guard = 1: the host reads the verdict (one 4-byte copy + sync); if it is negative nothing is computed
+// and 2 is returned (the caller takes the fp64 path).  guard = 2: no host round trip -- the three kernels of the chain test the device
+// flag themselves and do nothing when it is set; 3 is returned with *flag_out = the device flag, and the caller enqueues the fp64
+// fallback with run_if_set = that flag.
 int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool centered, const double *d_sumB,
-                   const double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out, bool guard = false);
+                   const double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out, int guard = 0,
+                   const int **flag_out = nullptr);
 
 }  // namespace mxa

@@ -601,9 +601,10 @@ struct LutCfg {
 template <int NV, int KS, int WV>
 __global__ void __launch_bounds__(64 * WV)
 k_lut(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B, long ldb, long k, int n, double *__restrict__ P,
-      long m_pad, int rowblocks, int slabs_total, int slabs_per_split) {
+      long m_pad, int rowblocks, int slabs_total, int slabs_per_split, const int *__restrict__ run_if_set) {
   using Cfg = LutCfg<NV, KS, WV>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (run_if_set && *run_if_set == 0) return;   // fallback launch of the guarded small-n route: the exact int8 chain is doing this product
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rb = blockIdx.x % rowblocks, sp = blockIdx.x / rowblocks;
@@ -714,13 +715,13 @@ k_lut(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B,
 constexpr int kLutWaves = 8;   // 512 lanes = 512 rows per workgroup share one set of tables
 
 template <int NV, int KS>
-static int launch_lut_t(const PackedMatrix &G, const double *dB, long ldb, int n, double *dP, const GemmPlan &p, hipStream_t s) {
+static int launch_lut_t(const PackedMatrix &G, const double *dB, long ldb, int n, double *dP, const GemmPlan &p, hipStream_t s, const int *run_if_set) {
   using Cfg = LutCfg<NV, KS, kLutWaves>;
   static unsigned long long attr_mask = 0;
   if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_lut<NV, KS, kLutWaves>), Cfg::kLds, &attr_mask)) return 1;
   const long grid = (long)p.rowblocks * p.splits;
   hipLaunchKernelGGL((k_lut<NV, KS, kLutWaves>), dim3((unsigned)grid), dim3(Cfg::kThreads), Cfg::kLds, s, G.d, G.pitch, dB, ldb, G.k, n, dP, p.m_pad,
-                     p.rowblocks, p.slabs_total, p.slabs_per_split);
+                     p.rowblocks, p.slabs_total, p.slabs_per_split, run_if_set);
   MXA_HIP(hipGetLastError());
   return 0;
 }
@@ -746,11 +747,11 @@ GemmPlan plan_lut(long m, long k_pad, int n) {
   return p;
 }
 
-int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double *dP, const GemmPlan &p, hipStream_t s) {
+int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double *dP, const GemmPlan &p, hipStream_t s, const int *run_if_set) {
   if (p.m_pad > G.rows_pad || (size_t)p.slabs_total * (kLutKS / 4) > G.pitch) { set_error(4, "internal: packed matrix smaller than the lookup plan"); return 1; }
-  if (p.n_pad == 1) return launch_lut_t<1, kLutKS>(G, dB, ldb, n, dP, p, s);
-  if (p.n_pad == 2) return launch_lut_t<2, kLutKS>(G, dB, ldb, n, dP, p, s);
-  return launch_lut_t<4, kLutKS>(G, dB, ldb, n, dP, p, s);
+  if (p.n_pad == 1) return launch_lut_t<1, kLutKS>(G, dB, ldb, n, dP, p, s, run_if_set);
+  if (p.n_pad == 2) return launch_lut_t<2, kLutKS>(G, dB, ldb, n, dP, p, s, run_if_set);
+  return launch_lut_t<4, kLutKS>(G, dB, ldb, n, dP, p, s, run_if_set);
 }
 
 // =====================================================================================================
@@ -762,9 +763,11 @@ int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double 
 __global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, long m_pad, long p_rows, int n_pad, int splits, long m, int n,
                                                 double *__restrict__ Cout, long ldc, long fill_rows, int mode_trans, int centered,
                                                 const double *__restrict__ sumB, const double *__restrict__ sumfB,
-                                                const double *__restrict__ f, const int *__restrict__ E, int back, int e_splits, int e_stride) {
+                                                const double *__restrict__ f, const int *__restrict__ E, int back, int e_splits, int e_stride,
+                                                const int *__restrict__ run_if_set) {
   const int j = blockIdx.y;
   const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (run_if_set && *run_if_set == 0) return;
   if (r >= fill_rows) return;
   double v = 0.0;
   if (r < m) {
@@ -787,10 +790,10 @@ __global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, lo
 }
 
 int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC, long ldc, long fill_rows, int mode_trans, bool centered,
-                  const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s, const int *d_E, int e_splits, int e_stride) {
+                  const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s, const int *d_E, int e_splits, int e_stride, const int *run_if_set) {
   dim3 grid((unsigned)((fill_rows + 255) / 256), n);
   hipLaunchKernelGGL(k_finish, grid, dim3(256), 0, s, dP, p.m_pad, p.p_rows, p.n_pad, p.splits, m, n, dC, ldc, fill_rows, mode_trans, centered ? 1 : 0,
-                     d_sumB, d_sumfB, d_f, d_E, 1074 - kDenUp, e_splits, e_stride);
+                     d_sumB, d_sumfB, d_f, d_E, 1074 - kDenUp, e_splits, e_stride, run_if_set);
   MXA_HIP(hipGetLastError());
   return 0;
 }

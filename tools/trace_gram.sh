@@ -1,0 +1,23 @@
+#!/bin/bash
+# kernel timeline of the CG step (mxa_gram_matvec, n = 1) on the config-5 shard: where the time between the two big kernels goes
+R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/r02"; mkdir -p "$O"
+cd /tmp && export TMPDIR=/tmp
+rm -rf "$O/tmp_g"
+timeout -k 10 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d "$O/tmp_g" -- python3 "$R/tools/perf_gram.py" 250000 100000 1 > "$O/gram_trace_run.log" 2>&1
+kt=$(find "$O/tmp_g" -name "*kernel_trace.csv" | head -1)
+python3 - "$kt" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows = [r for r in rows if "mxa::" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# last 2 gram calls: find the last 40 kernels
+tail = rows[-44:]
+t0 = int(tail[0]["Start_Timestamp"])
+prev_end = None
+for r in tail:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    gap = (s - prev_end) / 1e3 if prev_end else 0.0
+    print(f"{(s - t0) / 1e3:9.1f} us  +{gap:6.1f} gap  {(e - s) / 1e3:8.1f} us  {r['Kernel_Name'].split('(')[0][:60]}")
+    prev_end = e
+PY
+rm -rf "$O/tmp_g"
