@@ -385,10 +385,17 @@ __global__ void __launch_bounds__(256) k_finish_i8_small(const int *__restrict__
   long long t[kFinSmallRows];
 #pragma unroll
   for (int i = 0; i < kFinSmallRows; i++) t[i] = 0;
-  for (int sp = 0; sp < splits; sp++) {
-    const int *Ps = P + ((size_t)sp * m_pad + r0) * 32 + e;
+  // unconditional loads (P has m_pad rows; row indices are clamped, rows >= m are masked below): all 8 x splits loads of a lane are in flight together
+  long rl[kFinSmallRows];
 #pragma unroll
-    for (int i = 0; i < kFinSmallRows; i++) t[i] += (r0 + i < m) ? Ps[(size_t)i * 32] : 0;   // m_pad rows exist; rows >= m hold padding
+  for (int i = 0; i < kFinSmallRows; i++) rl[i] = r0 + i < m_pad ? r0 + i : m_pad - 1;
+  for (int sp = 0; sp < splits; sp++) {
+    const int *Ps = P + (size_t)sp * m_pad * 32 + e;
+    int x[kFinSmallRows];
+#pragma unroll
+    for (int i = 0; i < kFinSmallRows; i++) x[i] = Ps[(size_t)rl[i] * 32];
+#pragma unroll
+    for (int i = 0; i < kFinSmallRows; i++) t[i] += x[i];
   }
   bool bad = false;
   double cs = 0.0;
@@ -401,7 +408,7 @@ __global__ void __launch_bounds__(256) k_finish_i8_small(const int *__restrict__
 #pragma unroll
   for (int i = 0; i < kFinSmallRows; i++) {
     const long r = r0 + i;
-    double v = live ? ldexp((double)t[i], sh) : 0.0;
+    double v = (live && r < m) ? ldexp((double)t[i], sh) : 0.0;
     // lanes of one column: e = jj, jj + nc, jj + 2 nc, ...  (nc = 1: all 32 lanes; nc = 2: lanes of equal parity)
     for (int off = 16; off >= nc; off >>= 1) v += __shfl_xor(v, off, 32);
     if (e < nc && e < n && r < fill_rows) {
