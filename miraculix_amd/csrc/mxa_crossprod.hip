@@ -306,9 +306,8 @@ k_crossprod_f4(const uint8_t *__restrict__ X, long nslabs, int stages, const int
   // in flight).
   constexpr int NB = kF4Bufs;
 #pragma unroll
-  for (int i = 0; i < NB; i++) if (i < stages) issue(i, i);
-  if (stages >= NB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NB - 1)) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int i = 0; i < NB; i++) issue(min(i, stages - 1), i);   // always NB stages in flight (clamped: short K re-loads the last stage)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NB - 1)) : "memory");
   __syncthreads();
   unsigned long long t0 = 0, r0 = 0;
   if (DIAG) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -336,46 +335,49 @@ k_crossprod_f4(const uint8_t *__restrict__ X, long nslabs, int stages, const int
 #pragma unroll
   for (int a = 0; a < 4; a++) { fa0[a] = unpack(wa0[a]); fb0[a] = unpack(wb0[a]); fa1[a] = fa0[a]; fb1[a] = fb0[a]; }
   int buf = 0;
-  // K-step: MFMAs from (FA, FB); unpack (WAU, WBU) -> (FAN, FBN); read the words at LDS address RD (+ sub-block) into (WAR, WBR)
-#define MXA_F4_KSTEP(FA, FB, WAU, WBU, FAN, FBN, WAR, WBR, RD)                                                                      \
+  // K-step: MFMAs from (FA, FB); unpack (WAU, WBU) -> (FAN, FBN); read the words at LDS address RD (+ sub-block) into (WAR, WBR).
+  // Everything that is not an MFMA is spread over the four groups of 4 MFMAs (one DMA unit when DO_DMA, two ds_read_b64, 12 unpack VALU per
+  // group) and the whole stage is ONE basic block (no branches: the DMA of the last NB stages re-loads the final stage into buffers nobody
+  // reads, the reads after the last stage hit a valid buffer), so that the instruction scheduler keeps the interleave it is given:
+  // clustered at the stage start the 4 DMA issues and 16 LDS reads cost ~165 + ~140 cycles of a 1024-cycle stage (profiles/r02_mfma_f4_probe.txt).
+#define MXA_F4_KSTEP(FA, FB, WAU, WBU, FAN, FBN, WAR, WBR, RD, DO_DMA)                                                                      \
   {                                                                                                                                        \
-    if (EXP != 2 && EXP != 3 && EXP != 5) { /* unconditional (branch-free): after the last stage the reads hit a valid buffer and are unused */ \
-      _Pragma("unroll") for (int a = 0; a < 4; a++) {                                                                                      \
+    _Pragma("unroll") for (int a = 0; a < 4; a++) {                                                                                        \
+      if (DO_DMA && EXP != 2 && EXP != 3 && EXP != 6) {                                                                                    \
+        const int u = wave + 4 * a, op = u >> 3, uu = u & 7;                                                                               \
+        xdma16_s((op ? XJ : XI) + (size_t)dma_stage * kTileBytes + uu * 1024, v_lane, lds0 + dma_buf * kXBufBytes + op * kXOpBytes + uu * 1024); \
+      }                                                                                                                                    \
+      if (EXP != 2 && EXP != 3 && EXP != 5) {                                                                                              \
         WAR[a] = *reinterpret_cast<const u32x2 *>((RD) + a_off + a * 32 * kXStageBytes);                                                   \
         WBR[a] = *reinterpret_cast<const u32x2 *>((RD) + b_off + a * 32 * kXStageBytes);                                                   \
       }                                                                                                                                    \
-    }                                                                                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                                                                     \
-    _Pragma("unroll") for (int a = 0; a < 4; a++) {                                                                                        \
       FAN[a] = unpack(WAU[a]);                                                                                                             \
       FBN[a] = unpack(WBU[a]);                                                                                                             \
       _Pragma("unroll") for (int b = 0; b < 4; b++) acc[a][b] = mfma_f4(FA[a], FB[b], acc[a][b]);                                          \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                \
       __builtin_amdgcn_sched_barrier(0);                                                                                                   \
     }                                                                                                                                      \
   }
   for (int s = 0; s < stages; s++) {
-    const bool more = s + 1 < stages;
-    const char *nxt = smem + buf * kXBufBytes;
-    if (EXP != 2 && more) {
-      if (EXP != 3 && EXP != 6) {
-        if (s + NB - 1 < stages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NB - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of buffer s (issued a K-step ago) are complete before the buffer is refilled
+    // stage start: stage s+1 must have landed -- exactly (NB-2) stages' DMAs may stay in flight (one stage's 4 units are issued per stage,
+    // always); this wave's reads of buffer s%NB were issued a K-step ago and are complete; after the barrier that buffer is refilled
+    if (EXP != 2) {
+      if (EXP != 3 && EXP != 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NB - 2)) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (EXP != 4) __syncthreads();
-      if (EXP != 3 && EXP != 6 && s + NB < stages) issue(s + NB, buf);
-      buf = buf == NB - 1 ? 0 : buf + 1;
-      nxt = smem + buf * kXBufBytes;
     }
-    // t = 2s:   MFMAs F[0]; unpack W[1] (K-step 1 of this stage) -> F[1]; read K-step 0 of stage s+1 -> W[0]
-    MXA_F4_KSTEP(fa0, fb0, wa1, wb1, fa1, fb1, wa0, wb0, nxt)
+    const int dma_stage = min(s + NB, stages - 1), dma_buf = buf;
+    buf = buf == NB - 1 ? 0 : buf + 1;
+    const char *nxt = smem + buf * kXBufBytes;
+    // t = 2s:   MFMAs F[0]; unpack W[1] (K-step 1 of this stage) -> F[1]; read K-step 0 of stage s+1 -> W[0]; refill buffer s%NB
+    MXA_F4_KSTEP(fa0, fb0, wa1, wb1, fa1, fb1, wa0, wb0, nxt, true)
     // t = 2s+1: MFMAs F[1]; unpack W[0] (K-step 0 of stage s+1) -> F[0]; read K-step 1 of stage s+1 -> W[1]
-    MXA_F4_KSTEP(fa1, fb1, wa0, wb0, fa0, fb0, wa1, wb1, nxt + 8)
+    MXA_F4_KSTEP(fa1, fb1, wa0, wb0, fa0, fb0, wa1, wb1, nxt + 8, false)
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant refills of the last stages have landed before the ring becomes scratch
 #undef MXA_F4_KSTEP
   __syncthreads();   // all waves are done with the ring before it is reused as the epilogue scratch
   if (DIAG) {
