@@ -384,7 +384,8 @@ int multi_gemm(void *obj, bool trans, int n, const double *B, long ldb, double *
     if (ldb < snps || ldc < indiv) { set_error(7, "dgemm_compressed: leading dimension too small (ldb %ld < %ld or ldc %ld < %ld)", ldb, snps, ldc, indiv); return 1; }
     if (prepare_partials(m, indiv, n)) return 1;
     rc = run_all(m, [&](int g) {
-      if (gemm_any(m->shard[g], false, n, B + m->begin[g], ldb, m->d_part[g], indiv, indiv, false, true)) return 1;
+      // synchronous inside the shard's own worker thread: a big host B is then uploaded in K ranges behind the product (gemm_host_pipelined)
+      if (gemm_any(m->shard[g], false, n, B + m->begin[g], ldb, m->d_part[g], indiv, indiv, true, true)) return 1;
       return publish_partial(m, g, indiv, n);
     });
     if (!rc) rc = multi_reduce(m, indiv, n, C, ldc);
