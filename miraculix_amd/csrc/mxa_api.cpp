@@ -255,6 +255,30 @@ int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink
   return 0;
 }
 
+
+// Column-major block copy (height columns of `width` bytes, pitches in bytes) between host / device memory: one hipMemcpy2DAsync (a strided
+// 100 MB download takes 1.8 ms this way and 7.7 ms as one 1-D copy per column).  Exception: strided DOWNLOADS issued by the shard worker
+// threads of a multi-device object go column by column.  hipMemcpy2DAsync to pageable host memory issued from several threads at the same
+// time leaves device memory behind on ROCm 7.2 (0.2-0.6 MiB per shard and object life cycle; not with HIP_LAUNCH_BLOCKING=1, not from a
+// single thread, not with 1-D copies: tools/leak_probe*.py, tools/soak_lifecycle.py), and a long-lived session must not creep.
+// MXA_COPY_COLUMNS=1 forces the per-column form everywhere, =2 a synchronous hipMemcpy2D (diagnosis).
+static thread_local bool tl_concurrent = false;
+void mark_thread_concurrent() { tl_concurrent = true; }
+static hipError_t copy_columns(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipStream_t s) {
+  if (width == 0 || height == 0) return hipSuccess;
+  if (dpitch == width && spitch == width) return hipMemcpyAsync(dst, src, width * height, hipMemcpyDefault, s);
+  if (height == 1) return hipMemcpyAsync(dst, src, width, hipMemcpyDefault, s);
+  static const int mode = [] { const char *e = getenv("MXA_COPY_COLUMNS"); return e ? atoi(e) : 0; }();
+  if (mode == 2) { hipError_t e = hipStreamSynchronize(s); return e != hipSuccess ? e : hipMemcpy2D(dst, dpitch, src, spitch, width, height, hipMemcpyDefault); }
+  const bool per_column = mode == 1 || (tl_concurrent && ptr_location(dst, nullptr) == 0);
+  if (!per_column) return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDefault, s);
+  for (size_t j = 0; j < height; j++) {
+    const hipError_t e = hipMemcpyAsync(static_cast<char *>(dst) + j * dpitch, static_cast<const char *>(src) + j * spitch, width, hipMemcpyDefault, s);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 // ------------------------------------------------------------------------------------------------ multiply
 static std::mutex g_prof_mutex;   // profile() / last_geometry() are written by the worker threads of multi-device objects too
 
@@ -418,10 +442,10 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
   if (peel_on && engine == 0 && n > 4 && (n_odd == 1 || n_odd == 2) && k >= 128) {
     const int n4 = n - n_odd;
     if (!b_local) {
-      if (kmode) MXA_HIP(hipMemcpy2DAsync(w.d_Bstage + (size_t)n4 * k, sizeof(double) * k, B + (size_t)n4 * ldb, sizeof(double) * ldb, sizeof(double) * k, n_odd, hipMemcpyDefault, s));
+      if (kmode) MXA_HIP(copy_columns(w.d_Bstage + (size_t)n4 * k, sizeof(double) * k, B + (size_t)n4 * ldb, sizeof(double) * ldb, sizeof(double) * k, n_odd, s));
       else {   // row-range mode uploads the whole (small) B anyway
         if (ldb == k) MXA_HIP(hipMemcpyAsync(w.d_Bstage, B, sizeof(double) * (size_t)k * n, hipMemcpyDefault, s));
-        else MXA_HIP(hipMemcpy2DAsync(w.d_Bstage, sizeof(double) * k, B, sizeof(double) * ldb, sizeof(double) * k, n, hipMemcpyDefault, s));
+        else MXA_HIP(copy_columns(w.d_Bstage, sizeof(double) * k, B, sizeof(double) * ldb, sizeof(double) * k, n, s));
         b_uploaded = true;
       }
     }
@@ -443,7 +467,7 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
       const long slab0 = (long)sb * p.slabs_per_split, slab1 = std::min<long>(p.slabs_total, (long)se * p.slabs_per_split);
       const long k0 = std::min(k, slab0 * kSlabK), k1 = std::min(k, slab1 * kSlabK);
       if (!b_local && k1 > k0)
-        MXA_HIP(hipMemcpy2DAsync(w.d_Bstage + k0, sizeof(double) * k, B + k0, sizeof(double) * ldb, sizeof(double) * (k1 - k0), n, hipMemcpyDefault, s));
+        MXA_HIP(copy_columns(w.d_Bstage + k0, sizeof(double) * k, B + k0, sizeof(double) * ldb, sizeof(double) * (k1 - k0), n, s));
       MXA_HIP(hipEventRecord(h->pev[2 + c], s));
       hipStream_t cs = h->pipe[c & 1];
       MXA_HIP(hipStreamWaitEvent(cs, h->pev[2 + c], 0));
@@ -458,12 +482,12 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
     if (launch_finish(w.d_P, p, m, n, dC, dldc, fill_rows, trans ? 1 : 0, centered, d_sumB, d_sumfB, h->d_f, s, w.d_exp, spc, n)) return 1;
     if (!c_local) {
       if (ldc == fill_rows) MXA_HIP(hipMemcpyAsync(C, dC, sizeof(double) * (size_t)fill_rows * n_all, hipMemcpyDefault, s));
-      else MXA_HIP(hipMemcpy2DAsync(C, sizeof(double) * ldc, dC, sizeof(double) * fill_rows, sizeof(double) * fill_rows, n_all, hipMemcpyDefault, s));
+      else MXA_HIP(copy_columns(C, sizeof(double) * ldc, dC, sizeof(double) * fill_rows, sizeof(double) * fill_rows, n_all, s));
     }
   } else {
     if (!b_local && !b_uploaded) {
       if (ldb == k) MXA_HIP(hipMemcpyAsync(w.d_Bstage, B, sizeof(double) * (size_t)k * n, hipMemcpyDefault, s));
-      else MXA_HIP(hipMemcpy2DAsync(w.d_Bstage, sizeof(double) * k, B, sizeof(double) * ldb, sizeof(double) * k, n, hipMemcpyDefault, s));
+      else MXA_HIP(copy_columns(w.d_Bstage, sizeof(double) * k, B, sizeof(double) * ldb, sizeof(double) * k, n, s));
     }
     if (launch_colexp(dB, dldb, k, n, w.d_colpart, w.d_exp, 0, s)) return 1;
     if (launch_pack_B(dB, dldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, w.d_exp)) return 1;
@@ -500,7 +524,7 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
       const long r0 = (long)c * rows_chunk, r1 = std::min(m, r0 + rows_chunk);
       const long cnt = (r1 == m) ? fill_rows - r0 : r1 - r0;
       MXA_HIP(hipStreamWaitEvent(s, h->pev[10 + c], 0));
-      if (!c_local) MXA_HIP(hipMemcpy2DAsync(C + r0, sizeof(double) * ldc, dC + r0, sizeof(double) * fill_rows, sizeof(double) * cnt, n_all, hipMemcpyDefault, s));
+      if (!c_local) MXA_HIP(copy_columns(C + r0, sizeof(double) * ldc, dC + r0, sizeof(double) * fill_rows, sizeof(double) * cnt, n_all, s));
     }
   }
   MXA_HIP(hipStreamSynchronize(s));
@@ -528,7 +552,7 @@ int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, double *C,
   if (!b_local) {   // host memory, or memory of another device (peer copy over xGMI): dense k x n copy into this device's staging buffer
     if (grow(&w.d_Bstage, &w.cap_Bstage, (size_t)k * n)) return 1;
     if (ldb == k) MXA_HIP(hipMemcpyAsync(w.d_Bstage, B, sizeof(double) * (size_t)k * n, hipMemcpyDefault, s));
-    else MXA_HIP(hipMemcpy2DAsync(w.d_Bstage, sizeof(double) * k, B, sizeof(double) * ldb, sizeof(double) * k, n, hipMemcpyDefault, s));
+    else MXA_HIP(copy_columns(w.d_Bstage, sizeof(double) * k, B, sizeof(double) * ldb, sizeof(double) * k, n, s));
     dB = w.d_Bstage; dldb = k;
   }
   if (!c_local) {
@@ -538,7 +562,7 @@ int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, double *C,
   if (gemm_device(h, trans, n, dB, dldb, dC, dldc, fill_rows, s, timing)) return 1;
   if (!c_local) {
     if (ldc == fill_rows) MXA_HIP(hipMemcpyAsync(C, dC, sizeof(double) * (size_t)fill_rows * n, hipMemcpyDefault, s));
-    else MXA_HIP(hipMemcpy2DAsync(C, sizeof(double) * ldc, dC, sizeof(double) * fill_rows, sizeof(double) * fill_rows, n, hipMemcpyDefault, s));
+    else MXA_HIP(copy_columns(C, sizeof(double) * ldc, dC, sizeof(double) * fill_rows, sizeof(double) * fill_rows, n, s));
   }
   if (sync) { MXA_HIP(hipStreamSynchronize(s)); harvest_profile(h); }
   return 0;
@@ -561,7 +585,7 @@ int gram_any(Handle *h, int n, const double *V, long ldv, double *out, long ldo,
   if (!v_local) {
     if (grow(&w.d_Bstage, &w.cap_Bstage, (size_t)std::max(snps, indiv) * n)) return 1;
     if (ldv == indiv) MXA_HIP(hipMemcpyAsync(w.d_Bstage, V, sizeof(double) * (size_t)indiv * n, hipMemcpyDefault, s));
-    else MXA_HIP(hipMemcpy2DAsync(w.d_Bstage, sizeof(double) * indiv, V, sizeof(double) * ldv, sizeof(double) * indiv, n, hipMemcpyDefault, s));
+    else MXA_HIP(copy_columns(w.d_Bstage, sizeof(double) * indiv, V, sizeof(double) * ldv, sizeof(double) * indiv, n, s));
     dV = w.d_Bstage; dldv = indiv;
   }
   if (!o_local) {

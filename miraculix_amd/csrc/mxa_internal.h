@@ -98,6 +98,8 @@ int ptr_location(const void *p, int *dev);
 int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, double *C, long ldc, long fill_rows, bool sync, bool timing);
 int gram_any(Handle *h, int n, const double *V, long ldv, double *out, long ldo, bool sync);
 void harvest_profile(Handle *h);
+// called once by every shard worker thread: this thread issues transfers at the same time as other threads
+void mark_thread_concurrent();
 int select_device();                       // honours HIP_DEVICE / CUDA_DEVICE; -1 + error when no device
 // SNP-sharded objects (mxa_multi.cpp)
 int multi_requested();                     // MIRACULIX_NUM_GPUS (>= 1)

@@ -56,6 +56,7 @@ class Worker {
 
  private:
   void loop() {
+    mark_thread_concurrent();   // strided downloads issued from here take the per-column path (see copy_columns in mxa_api.cpp)
     for (;;) {
       std::function<int()> job;
       {
@@ -76,6 +77,24 @@ class Worker {
   int rc_ = 0;
   std::thread th_;
 };
+
+// Worker threads are kept for the life of the process and lent to multi-device objects (a thread per shard): objects that are created and
+// destroyed repeatedly reuse the same threads, and neither creation nor destruction pays for thread start-up / joins.
+class WorkerPool {
+ public:
+  Worker *borrow() {
+    std::lock_guard<std::mutex> lk(m_);
+    if (!free_.empty()) { Worker *w = free_.back(); free_.pop_back(); return w; }
+    all_.emplace_back(new Worker());
+    return all_.back().get();
+  }
+  void give_back(Worker *w) { std::lock_guard<std::mutex> lk(m_); free_.push_back(w); }
+ private:
+  std::mutex m_;
+  std::vector<std::unique_ptr<Worker>> all_;
+  std::vector<Worker *> free_;
+};
+WorkerPool &worker_pool() { static WorkerPool *p = new WorkerPool(); return *p; }   // never destroyed: no thread joins at process exit
 
 // ---- RCCL, bound at run time (the library does not link it; the default reduction does not need it)
 struct Rccl {
@@ -124,7 +143,7 @@ struct Multi {
   int root = 0;                              // device that holds the reduced result
   std::vector<Handle *> shard;
   std::vector<long> begin, end;              // SNP block of every shard
-  std::vector<std::unique_ptr<Worker>> worker;
+  std::vector<Worker *> worker;              // borrowed from worker_pool()
   // per shard: dense indiv x n partial on the shard's device; on the root: one landing buffer per remote shard + the reduced result
   std::vector<double *> d_part, d_land;
   std::vector<size_t> cap_part, cap_land;
@@ -220,16 +239,21 @@ void multi_destroy(void *obj) {
   Multi *m = as_multi(obj);
   if (!m) return;
   DeviceRestore restore;
-  m->worker.clear();   // joins the threads
   if (m->use_rccl) for (void *c : m->comm) if (c) (void)rccl().CommDestroy(c);
+  // every shard is released by the thread that worked on it
   for (size_t g = 0; g < m->shard.size(); g++) {
-    if (m->shard[g]) {
+    if (!m->shard[g] || g >= m->worker.size()) continue;
+    m->worker[g]->submit([m, g] {
       (void)hipSetDevice(m->shard[g]->device);
       if (g < m->d_part.size() && m->d_part[g]) (void)hipFree(m->d_part[g]);
       if (g < m->ev_done.size() && m->ev_done[g]) (void)hipEventDestroy(m->ev_done[g]);
       destroy_handle(m->shard[g]);
-    }
+      return 0;
+    });
   }
+  for (size_t g = 0; g < m->shard.size(); g++) if (m->shard[g] && g < m->worker.size()) (void)m->worker[g]->wait();
+  for (Worker *w : m->worker) worker_pool().give_back(w);   // idle: every job has been waited for
+  m->worker.clear();
   (void)hipSetDevice(m->root);
   for (double *p : m->d_land) if (p) (void)hipFree(p);
   if (m->d_red) (void)hipFree(m->d_red);
@@ -250,7 +274,7 @@ static int multi_build(long snps, long indiv, int shards, void **out, const std:
   std::vector<int> dev;
   if (pick_devices(G, dev)) { delete m; return 1; }
   m->shard.assign(G, nullptr);
-  for (int g = 0; g < G; g++) m->worker.emplace_back(new Worker());
+  for (int g = 0; g < G; g++) m->worker.push_back(worker_pool().borrow());
   // stage all shards side by side: every worker uploads over its own GPU's PCIe link
   for (int g = 0; g < G; g++) {
     m->worker[g]->submit([&, g] {
