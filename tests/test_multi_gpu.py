@@ -236,3 +236,31 @@ def test_multi_object_with_pipelined_host_transfers(mx):
     finally:
         dg.free_compressed(multi)
         dg.free_compressed(single)
+
+
+def test_multi_object_life_cycle_does_not_leak_device_memory(mx):
+    """create / multiply / free 40 three-shard objects with host operands (strided downloads from three worker threads at once): device memory
+    must return to where it was -- concurrent hipMemcpy2DAsync downloads left 0.2-0.6 MiB per shard behind before they went per column"""
+    import torch
+    snps, indiv, n = 6001, 1201, 10
+    prob = make_problem(snps, indiv, n, seed=3)
+    dg = mx.dgemm_compressed
+    dg.set_options(use_gpu=True, not_center=True, verbose=0)
+    rng = np.random.default_rng(0)
+    BT = np.asfortranarray(rng.standard_normal((indiv, n)))
+    BN = np.asfortranarray(rng.standard_normal((snps, n)))
+
+    def free_bytes():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    base = None
+    for it in range(48):
+        obj = _make(mx, prob, n, 3)
+        dg.dgemm_compressed_main(True, obj, BT, snps, indiv)
+        dg.dgemm_compressed_main(False, obj, BN, snps, indiv)
+        dg.dgemm_compressed_main(True, obj, np.asfortranarray(BT[:, :1]), snps, indiv)
+        dg.free_compressed(obj)
+        if it == 7:
+            base = free_bytes()
+    assert base - free_bytes() <= 8 << 20
