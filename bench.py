@@ -195,6 +195,8 @@ def measure_traffic(args):
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return None, {"skipped": "rocprofv3 not found"}
+    if any("rocprof" in (os.environ.get(k) or "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")) or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD"):
+        return None, {"skipped": "this run is itself under a profiler (the PMC passes cannot be nested); run bench.py plainly for roofline.traffic"}
     factor, calib = 2.0, "guide default x2 (uncalibrated for this access pattern)"
     try:
         cj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_calibration.json")))
