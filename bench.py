@@ -157,7 +157,7 @@ def cpu_baseline_and_check(torch, mx, plink_dev, freq_dev, snps, indiv, n, B_T, 
     base = {"value": round(gflops, 2), "unit": "GFLOP/s", "cores": cores, "cores_counted_as": how, "kind": kind,
             "sample": f"first {sample} SNPs of the bench matrix x {indiv} indiv, n={n}, one 'N' + one 'T' multiply, uncentred, AVX2 variant 256, "
                       f"best of 2 (N {times[0]:.3f}s, T {times[1]:.3f}s)"}
-    check = {"gpu_T_rows_vs_cpu_library_max_rel_err": err_t, "gpu_N_64_sampled_rows_vs_dense_oracle_max_rel_err": err_n, "tolerance": 1e-11}
+    check = {"gpu_T_rows_vs_cpu_library_max_rel_err": err_t, "gpu_N_64_sampled_rows_vs_dense_oracle_max_rel_err": err_n, "checker_tolerance": 1e-11}
     return base, check
 
 
@@ -449,7 +449,7 @@ def main():
                                    + (" inside one process behind the C ABI (MIRACULIX_NUM_GPUS)" if inprocess else ""),
                        "snps": snps, "indiv": indiv, "ncol": n, "parallelism": f"snp-shard{args.gpus if inprocess else world}",
                        "genotypes": "p_s ~ U(0.1, 0.6), g ~ Binomial(2, p_s), no missings; B ~ N(0, 1)"},
-            "check": {"adjoint_identity_max_rel_err": adj_err, "tolerance": 1e-10},
+            "check": {"adjoint_identity_max_rel_err": adj_err, "adjoint_tolerance": 1e-10},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "GB per launch, measured by this run (two rocprofv3 --pmc child passes of the same workload)", "traffic_detail": traffic_detail,
