@@ -177,6 +177,9 @@ int mxa_bed2compressed_range(const char *bed_path, int snps, int indiv, int snp_
  * by default with peer-to-peer pushes over xGMI and ONE addition kernel in ascending block order (bitwise reproducible),
  * with MXA_REDUCE=rccl by ncclReduce (RCCL is dlopen()ed; needs distinct devices); 'T' writes disjoint row blocks, no exchange.
  * B / C may be host memory or memory of any of the devices.  mxa_dgemm_compressed_device is not available on such a handle.
+ * snp_multiply_gpu with host operands follows the same variable: device g computes the column panel [c_g, c_g+1) of the symmetric result (equal
+ * numbers of 256-column tiles = equal work), staging the packed matrix itself, and downloads it over its own PCIe link into its slab of the host
+ * matrix -- independent units, no exchange; bit-identical to the single-device result.
  * mxa_num_shards: number of per-device objects behind a handle (1 for an ordinary one).  mxa_shard_bounds: block g of the
  * partition of `snps` into `shards` blocks; returns the number of non-empty blocks. */
 int mxa_num_shards(void *compressed);

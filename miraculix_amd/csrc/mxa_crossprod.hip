@@ -18,6 +18,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <vector>
 
 namespace mxa {
@@ -425,6 +427,7 @@ static void xcd_order_tiles(std::vector<int4> &tiles, int nb, int sr) {
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
+static std::mutex g_xprof_mutex;   // panels of one call run in several threads (MIRACULIX_NUM_GPUS): the profile counters are shared
 namespace {
 struct XEvent {   // RAII: events, streams and device buffers are released on every exit path
   hipEvent_t e = nullptr;
@@ -534,7 +537,7 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
   }
   float ms = 0.f;
   MXA_HIP(hipEventElapsedTime(&ms, e0.e, e1.e));
-  profile().launches += 1; profile().total_ms += ms;
+  { std::lock_guard<std::mutex> lk(g_xprof_mutex); profile().launches += 1; profile().total_ms += ms; }
   return 0;
 }
 
@@ -689,11 +692,12 @@ static int postprocess_device(double *d_M, long rows, long k, int post, int do_s
 }
 
 static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, double *ans, bool is_plink, int post = 0, int do_scale = 0,
-                         const double *freq = nullptr, long c_begin = 0, long c_end = -1, bool upper_only = false, long ld = -1) {
+                         const double *freq = nullptr, long c_begin = 0, long c_end = -1, bool upper_only = false, long ld = -1, int device = -1) {
   if (c_end < 0) c_end = rows;
   if (ld < 0) ld = rows;
   if (!snp_matrix || !ans || k <= 0 || rows <= 0) { set_error(1, "snp_multiply_gpu: bad arguments"); return 1; }
-  if (select_device() < 0) return 1;   // HIP_DEVICE / CUDA_DEVICE with the range check; GPU-only
+  if (device >= 0) MXA_HIP(hipSetDevice(device));
+  else if (select_device() < 0) return 1;   // HIP_DEVICE / CUDA_DEVICE with the range check; GPU-only
   const long row_bytes = (k + 3) / 4;
   const long rows_pad = (rows + kXT - 1) / kXT * kXT;
   const long nslabs = (k + kXStageK - 1) / kXStageK;
@@ -769,6 +773,22 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
 extern "C" int snp_multiply_gpu(unsigned char *snp_matrix, int snps, int indiv, double *ans, bool is_plink_format) {
   // positional meaning as in the reference: arg 2 = packed (inner) dimension, arg 3 = output dimension
   mxa::clear_error();
+  // MIRACULIX_NUM_GPUS = G > 1 with host operands: output-tile sharding inside this process (packed matrix replicated,
+  // independent units, no collective).  Device g stages X itself, computes the column panel [c_g, c_g+1) of the symmetric result -- equal
+  // numbers of 256-column tiles, which is equal work: a panel of t tile columns touches t * (rows / 256) tiles -- and downloads it over
+  // its own PCIe link into the contiguous slab ans + c_g * indiv of the column-major host matrix.  Every tile is computed by the same
+  // kernel as on one device, so the result is bit-identical.  Total work is the full matrix (2x the triangular single-device launch):
+  // at config 3 the 80 GB download, not the arithmetic, bounds a host result, and that is what the G links divide.
+  const int G = mxa::multi_requested();
+  if (G > 1 && snp_matrix && ans && snps > 0 && indiv > 0 && mxa::ptr_location(snp_matrix, nullptr) == 0 && mxa::ptr_location(ans, nullptr) == 0) {
+    const long nb = ((long)indiv + mxa::kXT - 1) / mxa::kXT;
+    const int parts = (int)std::min<long>(G, nb);
+    return mxa::run_on_devices(parts, [&](int g, int dev) {
+      const long c0 = std::min<long>(indiv, nb * g / parts * mxa::kXT), c1 = std::min<long>(indiv, nb * (g + 1) / parts * mxa::kXT);
+      if (c1 <= c0) return 0;
+      return mxa::crossprod_any(snp_matrix, snps, indiv, ans + (size_t)c0 * indiv, is_plink_format, 0, 0, nullptr, c0, c1, false, indiv, dev);
+    });
+  }
   return mxa::crossprod_any(snp_matrix, snps, indiv, ans, is_plink_format);
 }
 

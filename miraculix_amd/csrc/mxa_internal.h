@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 
 namespace mxa {
 
@@ -110,6 +111,9 @@ int multi_gram(void *obj, int n, const double *V, long ldv, double *out, long ld
 void multi_freq(void *obj, double *f);
 void multi_destroy(void *obj);
 bool is_multi(const void *obj);
+// run job(g, device) for g = 0 .. parts-1 at the same time, each in a pooled worker thread bound to device (first device + g) modulo the
+// visible device count; returns the OR of the jobs' return codes.  The caller's current device is restored.
+int run_on_devices(int parts, const std::function<int(int, int)> &job);
 // one SNP range of a .bed file -> object on `device` (rows [snp_begin, snp_end) are read, transposed and counted on the device)
 int bed_range_to_handle(const char *base, long snps_total, long indiv, long snp_begin, long snp_end, int max_n, int device, void **out,
                         double *f_out_local);

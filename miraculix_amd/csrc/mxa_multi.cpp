@@ -229,6 +229,19 @@ int finish_setup(Multi *m) {
 
 bool is_multi(const void *obj) { return obj && reinterpret_cast<const Multi *>(obj)->magic == kMagicMulti; }
 
+int run_on_devices(int parts, const std::function<int(int, int)> &job) {
+  if (parts <= 0) return 0;
+  std::vector<int> dev;
+  if (pick_devices(parts, dev)) return 1;
+  DeviceRestore restore;
+  std::vector<Worker *> ws;
+  for (int g = 0; g < parts; g++) ws.push_back(worker_pool().borrow());
+  for (int g = 0; g < parts; g++) ws[g]->submit([&job, &dev, g] { return job(g, dev[g]); });
+  int rc = 0;
+  for (int g = 0; g < parts; g++) { rc |= ws[g]->wait(); worker_pool().give_back(ws[g]); }
+  return rc;
+}
+
 int multi_requested() {
   const char *e = getenv("MIRACULIX_NUM_GPUS");
   const int g = e ? atoi(e) : 1;

@@ -264,3 +264,19 @@ def test_multi_object_life_cycle_does_not_leak_device_memory(mx):
         if it == 7:
             base = free_bytes()
     assert base - free_bytes() <= 8 << 20
+
+
+@pytest.mark.parametrize("rows,parts", [(1000, 3), (300, 4), (2100, 2)])
+def test_crossproduct_column_panels_inside_one_process(mx, rows, parts):
+    """snp_multiply_gpu with MIRACULIX_NUM_GPUS > 1 and host operands: every 'device' computes a column panel of the symmetric result and
+    downloads it into its slab of the host matrix (virtual devices on a one-GPU box); bit-identical to the single-device call and to the oracle"""
+    o = Oracle()
+    k = 4099
+    rng = np.random.default_rng(rows)
+    X = rng.integers(0, 256, size=(rows, (k + 3) // 4), dtype=np.uint8)
+    X[:, -1] &= (1 << (2 * (k % 4))) - 1
+    single = mx.crossproduct.snp_crossprod(X, k, rows, is_snpmajor=False, is_plink_format=True)
+    with _env(MIRACULIX_NUM_GPUS=parts):
+        multi = mx.crossproduct.snp_crossprod(X, k, rows, is_snpmajor=False, is_plink_format=True)
+    assert np.array_equal(multi, single)
+    assert np.array_equal(multi, o.crossprod_i32(X, k, True).astype(np.float64))
