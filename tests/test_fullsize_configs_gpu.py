@@ -208,3 +208,32 @@ def test_c3_sampled_tiles_vs_oracle(c3):
         assert np.array_equal(got, ref), (ti, tj)
         got_m = M[rj[0]:rj[-1] + 1, ri[0]:ri[-1] + 1].cpu().numpy()
         assert np.array_equal(got_m, ref.T), (ti, tj)
+
+
+def test_c3_host_result_through_the_plain_abi():
+    """the reference's own calling convention (host snp_matrix, host ans; crossproduct.jl:54-58) at K = 500 000 with a 12.8 GB result: the
+    staged upload, the tile-row chunks and the four copier threads of the pipelined copy-out (mxa_crossprod.hip: crossprod_to_host) against the
+    device-resident result of the same rows (bitwise) and the oracle on a sampled tile"""
+    import torch
+    import miraculix_amd as mx
+    from bench import synth_genotypes_device
+    mx.load_shared_library()
+    torch.cuda.empty_cache()
+    dev = torch.device("cuda", 0)
+    snps, rows = 500_000, 40_000
+    Xd = synth_genotypes_device(torch, rows, snps, 47, dev, p_along="cols")
+    X = Xd.cpu().numpy()                                                     # 5 GB host copy
+    M = mx.crossproduct.snp_crossprod(X, snps, rows, is_snpmajor=False, is_plink_format=True)      # host in, host out
+    assert M.shape == (rows, rows)
+    Md = mx.crossproduct.snp_crossprod(Xd, snps, rows, is_snpmajor=False, is_plink_format=True)    # device in, device out
+    step = 4000
+    for a in range(0, rows, step):
+        assert np.array_equal(M[a:a + step], Md[a:a + step].cpu().numpy()), a
+    del Md
+    o = Oracle()
+    ri, rj = np.arange(256, 512), np.arange(rows - 160, rows)
+    sub = np.ascontiguousarray(X[np.concatenate([ri, rj])])
+    ref = o.crossprod_i32(sub, snps, True).astype(np.float64)[:256, 256:]
+    assert np.array_equal(M[256:512, rows - 160:], ref)
+    del Xd
+    torch.cuda.empty_cache()
