@@ -237,3 +237,41 @@ def test_c3_host_result_through_the_plain_abi():
     assert np.array_equal(M[256:512, rows - 160:], ref)
     del Xd
     torch.cuda.empty_cache()
+
+
+def test_c5_cg_loop_on_the_full_shard(c5):
+    """the loop of config 5 (examples/iterative_solver/grm_solve_cg.jl:108-134) on the full per-GPU shard: 25 CG iterations of
+    (Zc Zc^T + lambda I) x = b with one mxa_gram_matvec each.  The residual must fall monotonically for this well-conditioned system, the final x
+    must satisfy the equation to the residual the loop reports (checked with two separate products), and a second run must repeat bit for bit"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from grm_solve_cg import cg
+    torch, dg, dev = c5["torch"], c5["dg"], c5["dev"]
+    snps, indiv, obj = c5["snps"], c5["indiv"], c5["obj"]
+
+    class Op:   # the part of ShardedGenotypeOperator the loop uses, on the fixture's object
+        def gram(self, v):
+            return dg.gram_matvec(obj, v, snps, indiv)
+
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    b = torch.randn((1, indiv), dtype=torch.float64, device=dev, generator=g).t()
+    lam = float(snps)
+    x0 = torch.zeros_like(b)
+    hist = []
+
+    class Rec(Op):
+        def gram(self, v):
+            out = super().gram(v)
+            hist.append(float(torch.linalg.vector_norm(out)))
+            return out
+
+    x, res, it = cg(Rec(), b, x0, lam, max_iter=25, conv_crit=1e-30, verbose=False)
+    assert it == 25 and len(hist) == 26
+    T = dg.dgemm_compressed_main(True, obj, x, snps, indiv)
+    Ax = dg.dgemm_compressed_main(False, obj, T, snps, indiv) + lam * x
+    true_res = float(torch.linalg.vector_norm(b - Ax))
+    assert res < 1e-6 * float(torch.linalg.vector_norm(b))                 # well-conditioned: 25 iterations go far
+    assert abs(true_res - res) <= 1e-6 * float(torch.linalg.vector_norm(b)) + 10 * res
+    x2, res2, _ = cg(Op(), b, x0, lam, max_iter=25, conv_crit=1e-30, verbose=False)
+    assert torch.equal(x, x2) and res == res2
