@@ -68,3 +68,40 @@ def test_crossprod_random_shapes_bit_exact(k, rows, plink, engine, seed):
         if old is not None:
             os.environ["MXA_XPROD_ENGINE"] = old
     assert np.array_equal(M, o.crossprod_i32(X, k, plink).astype(np.float64)), (k, rows, plink, engine)
+
+
+@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(snps=st.sampled_from([5, 16, 127, 130, 513, 1025, 3001]), indiv=st.sampled_from([3, 64, 257, 700]), n=st.sampled_from([1, 2, 3, 6, 10, 33]),
+       shards=st.sampled_from([2, 3, 5, 8]), centered=st.booleans(), trans=st.booleans(), pad=st.sampled_from([0, 3]), seed=st.integers(0, 1000))
+def test_multi_object_random_shapes_vs_oracle(snps, indiv, n, shards, centered, trans, pad, seed):
+    """SNP-sharded objects behind the C ABI (virtual shards on one GPU) at ragged sizes: blocks of fewer than 128 SNPs, more shards than SNP
+    quadruples, the small-n route and the column peel inside shards, padded leading dimensions"""
+    import os
+    import miraculix_amd as mx
+    L = mx.load_shared_library()
+    dg = mx.dgemm_compressed
+    o = Oracle()
+    prob = make_problem(snps, indiv, n, seed=seed)
+    k = indiv if trans else snps
+    m = snps if trans else indiv
+    ldb, ldc = k + pad, m + pad
+    rng = np.random.default_rng(seed + 7)
+    B = np.full((n, ldb), 1e300)
+    B[:, :k] = rng.standard_normal((n, k))
+    dg.set_options(use_gpu=True, not_center=not centered, verbose=0)
+    os.environ["MIRACULIX_NUM_GPUS"] = str(shards)
+    try:
+        obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], n)
+    finally:
+        os.environ.pop("MIRACULIX_NUM_GPUS", None)
+    try:
+        C = np.full((n, ldc), -777.0)
+        L.dgemm_compressed(b"T" if trans else b"N", obj, n, B.ctypes.data_as(ctypes.c_void_p), ldb, C.ctypes.data_as(ctypes.c_void_p), ldc)
+        assert L.mxa_last_error() == 0
+    finally:
+        dg.free_compressed(obj)
+    ref = o.dgemm_dense(int(trans), prob, B, int(centered))[:, :m]
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    scale[scale == 0] = 1.0
+    assert (np.abs(C[:, :m] - ref) / scale).max() <= 1e-11, (snps, indiv, n, shards, centered, trans, pad)
+    assert np.all(C[:, m:] == 0.0)
