@@ -17,3 +17,7 @@ def test_c_driver(tmp_path):
     r = subprocess.run([exe, "1000", "500"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "c_driver ok" in r.stdout
+    # the same binary, unchanged, with the SNPs sharded over three (virtual) devices behind the same symbols, and with the crossproduct in panels
+    r = subprocess.run([exe, "1000", "500"], capture_output=True, text=True, timeout=300, env=dict(os.environ, MIRACULIX_NUM_GPUS="3"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "c_driver ok" in r.stdout
