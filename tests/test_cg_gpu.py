@@ -71,3 +71,27 @@ def test_gblup_dense_route_equals_iterative_route():
     from gblup_small import run
     diff, it = run(snps=6000, indiv=700, lam=0.5, verbose=False)
     assert diff <= 1e-9 and it < 1000
+
+
+def test_randomized_snp_pca_finds_the_population_structure():
+    """examples/pca_randomized.py (the PCA half of the reference's examples/gblup/calculate_gblup.jl:54-97): n = 2 + 20 columns per
+    multiply, two power iterations.  Three sub-populations give two dominant components; the randomised subspace must coincide with the
+    one from a dense SVD of the centred matrix, and the eigenvalues with its squared singular values"""
+    import torch
+    import miraculix_amd as mx
+    from pca_randomized import randomized_snp_pca, structured_population
+    mx.load_shared_library()
+    dev = torch.device("cuda", 0)
+    snps, indiv, n = 3000, 400, 2
+    plink, Z, lab = structured_population(torch, snps, indiv, 5, dev)
+    plink_t = mx.compressed_operations.transpose_genotype_matrix(plink, snps, indiv)
+    f = mx.read_plink.calc_freq(plink, snps, indiv)
+    PC, U, ev = randomized_snp_pca(plink, plink_t, snps, indiv, f, n, p=20, q=2)
+    Zc = Z.astype(np.float64) - 2.0 * f.cpu().numpy()[None, :]
+    Ud, sd, Vt = np.linalg.svd(Zc, full_matrices=False)
+    assert np.allclose(np.sort(ev.cpu().numpy())[::-1], sd[:n] ** 2, rtol=1e-8)
+    # principal angles between the spans of the computed and the exact leading components
+    Qa = np.linalg.qr(PC.cpu().numpy())[0]
+    cosines = np.linalg.svd(Qa.T @ Ud[:, :n], compute_uv=False)
+    assert cosines.min() >= 1.0 - 1e-9
+    assert sd[n - 1] > 1.5 * sd[n]                                         # the structure is real: a gap after the second component
