@@ -223,6 +223,14 @@ int mxa_ld(const unsigned char *plink, int snps, int indiv, double *R, int is_pl
 int mxa_set_engine(int engine);
 int mxa_get_engine(void);
 int mxa_last_path(void);
+/* Range of the fp64 MFMA path.  k_gemm feeds the genotype operand as the denormal double z * 2^-1074 and scales every column of B by a
+ * power of two so that its largest |entry| sits just below 2^900; products of entries up to 847 binades below their column's largest
+ * one are then normal doubles and every result equals the plain fp64 FMA chain of the reference
+ * (src/cuda/dgemm_compressed_cuda.h:259-266) bit for bit.  A per-call check on the device finds columns whose non-zero entries span more
+ * than 800 binades (about 240 decades) or hold inf / NaN; the product is then redone with plain fp64 operands (v_cvt_f64_u32, no
+ * scaling) -- same arithmetic as the reference for every input, at twice the time for such calls.  mxa_last_range_fallback: 1 if the
+ * most recent fp64-MFMA product on this (single-device) object took that fallback, 0 if not, -1 if unknown. */
+int mxa_last_range_fallback(void *compressed);
 
 /* measurement: HIP-event timing of the dominant kernel on the stream it is launched on.
  * mxa_profile_reset() clears the counters; after some dgemm_compressed / snp_multiply_gpu calls

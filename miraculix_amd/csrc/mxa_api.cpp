@@ -43,6 +43,7 @@ int env_print_level() {  // reference: cuda_utils.cu:44-52, env PRINT_LEVEL
 
 // The status is per process, like the reference's (its entries return void and print).  Worker threads of a multi-device object
 // report through the same state: the mutex keeps the message intact, the first error of a call wins.
+static std::mutex g_prof_mutex;   // profile() / last_geometry() are written by the worker threads of multi-device objects too
 static std::mutex g_err_mutex;
 void clear_error() { std::lock_guard<std::mutex> lk(g_err_mutex); g_err = 0; g_errmsg[0] = 0; }
 
@@ -174,9 +175,14 @@ static int stage_matrix(PackedMatrix &M, const uint8_t *src, size_t src_pitch, l
 
 void destroy_handle(Handle *h) {
   if (!h) return;
+  {   // mxa_last_path() must not read a flag of this object once its memory is gone
+    std::lock_guard<std::mutex> lk(g_prof_mutex);
+    Geometry &geo = last_geometry();
+    if (geo.d_flag && h->ws.d_denflag && geo.d_flag >= h->ws.d_denflag && geo.d_flag < h->ws.d_denflag + 4) { geo.d_flag = nullptr; if (geo.path == 4) geo.path = 2; }
+  }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void *ptrs[] = {h->snp_major.d, h->ind_major.d, h->d_f, h->ws.d_Bstage, h->ws.d_Cstage, h->ws.d_Bp, h->ws.d_P, h->ws.d_colpart, h->ws.d_i8, h->ws.d_tmp, h->ws.d_exp};
+  void *ptrs[] = {h->snp_major.d, h->ind_major.d, h->d_f, h->ws.d_Bstage, h->ws.d_Cstage, h->ws.d_Bp, h->ws.d_P, h->ws.d_colpart, h->ws.d_i8, h->ws.d_tmp, h->ws.d_exp, h->ws.d_denflag};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -200,6 +206,10 @@ static int ensure_workspace(Handle *h, int n) {
   if (grow(&w.d_Bp, &w.cap_Bp, bp)) return 1;
   if (grow(&w.d_P, &w.cap_P, pp)) return 1;
   if (grow(&w.d_colpart, &w.cap_colpart, (size_t)n * (64 * 2 + 2) + 16)) return 1;
+  if (!w.d_denflag) {
+    MXA_HIP(hipMalloc(reinterpret_cast<void **>(&w.d_denflag), 4 * sizeof(int)));
+    MXA_HIP(hipMemset(w.d_denflag, 0, 4 * sizeof(int)));
+  }
   return 0;
 }
 
@@ -280,8 +290,6 @@ static hipError_t copy_columns(void *dst, size_t dpitch, const void *src, size_t
 }
 
 // ------------------------------------------------------------------------------------------------ multiply
-static std::mutex g_prof_mutex;   // profile() / last_geometry() are written by the worker threads of multi-device objects too
-
 void harvest_profile(Handle *h) {
   if (!h || !h->prof_pending) return;
   h->prof_pending = false;
@@ -368,14 +376,20 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
       MXA_HIP(hipMalloc(reinterpret_cast<void **>(&w.d_exp), sizeof(int) * (size_t)n));
       w.cap_exp = n;
     }
-    if (launch_colexp(dB, ldb, k, n, w.d_colpart, w.d_exp, 0, s)) return 1;
+    // per-column exponents + the range guard of the mode: a column whose non-zero entries span more than kDenMaxSpan binades (or that
+    // holds inf / NaN) raises d_denflag, and the plain-operand chain below redoes the product (the verdict stays on the device)
+    if (launch_colexp(dB, ldb, k, n, w.d_colpart, w.d_exp, 0, s, w.d_denflag, kDenMaxSpan, -100000)) return 1;
     d_E = w.d_exp;
   }
   if (!use_lut && launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, d_E)) return 1;
   if (prof) MXA_HIP(hipEventRecord(h->ev0, s));
   int rc = use_lut ? launch_lut(G, dB, ldb, n, w.d_P, p, s) : launch_gemm(G, w.d_Bp, w.d_P, p, mode, s);
   if (prof && !rc) { MXA_HIP(hipEventRecord(h->ev1, s)); h->prof_pending = true; }
-  if (!rc) rc = launch_finish(w.d_P, p, m, n, dC, ldc, fill_rows, trans ? 1 : 0, centered, d_sumB, d_sumfB, h->d_f, s, d_E);
+  if (!rc && d_E) {   // fallback of the denormal-operand mode, run only when the guard raised the flag: unscaled B, two-instruction conversion
+    rc = launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, nullptr, 0, -1, w.d_denflag);
+    if (!rc) rc = launch_gemm(G, w.d_Bp, w.d_P, p, 0, s, 0, -1, w.d_denflag);
+  }
+  if (!rc) rc = launch_finish(w.d_P, p, m, n, dC, ldc, fill_rows, trans ? 1 : 0, centered, d_sumB, d_sumfB, h->d_f, s, d_E, 0, 0, nullptr, d_E ? w.d_denflag : nullptr);
   return rc;
 }
 
@@ -420,15 +434,15 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
   Workspace &w = h->ws;
   hipStream_t s = h->stream;
   // scratch: per-group column-maximum partials (64 n doubles each) + column sums; per-group exponents
-  if (grow(&w.d_colpart, &w.cap_colpart, (size_t)n * (64 * (kPipeChunks + 2) + 2) + 16)) return 1;
+  if (grow(&w.d_colpart, &w.cap_colpart, (size_t)n * (128 * (kPipeChunks + 1) + 2) + 16)) return 1;
   if (w.cap_exp < (size_t)n * kPipeChunks) {
     MXA_HIP(hipStreamSynchronize(s));
     if (w.d_exp) { MXA_HIP(hipFree(w.d_exp)); w.d_exp = nullptr; w.cap_exp = 0; }
     MXA_HIP(hipMalloc(reinterpret_cast<void **>(&w.d_exp), sizeof(int) * (size_t)n * kPipeChunks));
     w.cap_exp = (size_t)n * kPipeChunks;
   }
-  double *d_sumB = w.d_colpart + (size_t)n * 64 * (kPipeChunks + 2), *d_sumfB = d_sumB + n;
-  double *d_sumscratch = w.d_colpart + (size_t)n * 64 * kPipeChunks;   // 128 n doubles for launch_colsums
+  double *d_sumB = w.d_colpart + (size_t)n * 128 * (kPipeChunks + 1), *d_sumfB = d_sumB + n;
+  double *d_sumscratch = w.d_colpart + (size_t)n * 128 * kPipeChunks;   // 128 n doubles for launch_colsums
   // operands on this device
   const double *dB = B; long dldb = ldb;
   if (!b_local) { if (grow(&w.d_Bstage, &w.cap_Bstage, (size_t)k * n)) return 1; dB = w.d_Bstage; dldb = k; }
@@ -457,6 +471,7 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
   }
   const GemmPlan p = plan_gemm(m, G.k_pad, n);
   { std::lock_guard<std::mutex> lk(g_prof_mutex); Geometry &geo = last_geometry(); geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c; geo.path = 0; }
+  MXA_HIP(hipMemsetAsync(w.d_denflag, 0, sizeof(int), s));   // range guard of the denormal-operand mode, raised by any K group's launch_colexp
   MXA_HIP(hipEventRecord(h->pev[0], s));
   for (hipStream_t ps : h->pipe) MXA_HIP(hipStreamWaitEvent(ps, h->pev[0], 0));   // earlier calls are done with Bp / P
   const int want_chunks = (int)std::max<size_t>(2, std::min<size_t>(kPipeChunks, std::max(b_bytes, c_bytes) >> 23));
@@ -472,7 +487,7 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
       hipStream_t cs = h->pipe[c & 1];
       MXA_HIP(hipStreamWaitEvent(cs, h->pev[2 + c], 0));
       int *d_Ec = w.d_exp + (size_t)c * n;
-      if (launch_colexp(dB + k0, dldb, k1 - k0, n, w.d_colpart + (size_t)c * 64 * n, d_Ec, 0, cs)) return 1;
+      if (launch_colexp(dB + k0, dldb, k1 - k0, n, w.d_colpart + (size_t)c * 128 * n, d_Ec, 0, cs, w.d_denflag, kDenMaxSpan, -100000, false)) return 1;
       if (launch_pack_B(dB, dldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, cs, d_Ec, slab0 * kSlabSteps, (slab1 - slab0) * kSlabSteps)) return 1;
       if (launch_gemm(G, w.d_Bp, w.d_P, p, 2, cs, sb, se)) return 1;
       MXA_HIP(hipEventRecord(h->pev[10 + c], cs));
@@ -489,7 +504,7 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
       if (ldb == k) MXA_HIP(hipMemcpyAsync(w.d_Bstage, B, sizeof(double) * (size_t)k * n, hipMemcpyDefault, s));
       else MXA_HIP(copy_columns(w.d_Bstage, sizeof(double) * k, B, sizeof(double) * ldb, sizeof(double) * k, n, s));
     }
-    if (launch_colexp(dB, dldb, k, n, w.d_colpart, w.d_exp, 0, s)) return 1;
+    if (launch_colexp(dB, dldb, k, n, w.d_colpart, w.d_exp, 0, s, w.d_denflag, kDenMaxSpan, -100000, false)) return 1;
     if (launch_pack_B(dB, dldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, w.d_exp)) return 1;
     if (centered && launch_colsums(dB, dldb, k, n, trans ? nullptr : h->d_f, d_sumscratch, d_sumB, d_sumfB, s)) return 1;
     MXA_HIP(hipEventRecord(h->pev[1], s));
@@ -528,7 +543,11 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
     }
   }
   MXA_HIP(hipStreamSynchronize(s));
-  return 0;
+  // a column outside the range of the denormal-operand mode (kDenMaxSpan; absurd inputs): the plain path redoes the product with its
+  // on-device fallback
+  int den = 0;
+  MXA_HIP(hipMemcpy(&den, w.d_denflag, sizeof(int), hipMemcpyDeviceToHost));
+  return den ? 2 : 0;
 }
 
 int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, double *C, long ldc, long fill_rows, bool sync, bool timing) {
@@ -828,14 +847,27 @@ void mxa_profile_get(int *launches, double *total_ms) {
   if (total_ms) *total_ms = profile().total_ms;
 }
 int mxa_last_path(void) {
-  const Geometry g = last_geometry();
+  Geometry g;
+  { std::lock_guard<std::mutex> lk(g_prof_mutex); g = last_geometry(); }
   if (g.path != 4) return g.path;
   // n <= 2 under the default engine: the route was chosen on the device; read the verdict now (the entries that use it are synchronous)
   int flag = 0, prev = 0;
+  if (!g.d_flag) return 2;
   (void)hipGetDevice(&prev);
   if (hipSetDevice(g.flag_dev) != hipSuccess || hipMemcpy(&flag, g.d_flag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); flag = 0; }
   (void)hipSetDevice(prev);
   return flag ? 1 : 2;
+}
+int mxa_last_range_fallback(void *compressed) {
+  if (!compressed || is_multi(compressed)) return -1;
+  Handle *h = as_handle(compressed, "mxa_last_range_fallback");
+  if (!h || !h->ws.d_denflag) return -1;
+  int flag = 0, prev = 0;
+  (void)hipGetDevice(&prev);
+  if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess ||
+      hipMemcpy(&flag, h->ws.d_denflag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); flag = -1; }
+  (void)hipSetDevice(prev);
+  return flag;
 }
 void mxa_last_geometry(long *m, long *k, int *n, int *splits, int *a_tile, int *c_tile) {
   const Geometry &g = last_geometry();

@@ -529,7 +529,9 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
     // Exactness guard of the default small-n route.  With |b| = f 2^e, f in [1/2, 1), an entry is the integer m 2^(e-53);
     // the last digit has weight 2^(E_j - 8S) = 2^(e_max + 2 - 8S).  Every entry is an exact multiple of it iff e_min - 53 >= e_max + 2 - 8S,
     // i.e. the exponent span e_max - e_min <= 8S - 55; the recombination ldexp(t, E_j - 8(s+1)) stays normal iff e_max + 2 - 8S >= -1021.
-    int *d_flag = d_E + n, h_flag = 1;
+    // the flag lives in the handle's small flag block (never reallocated while the handle lives: mxa_last_path() may read it later)
+    if (!w.d_denflag) { set_error(4, "internal: flag block missing"); return 1; }
+    int *d_flag = w.d_denflag + 1, h_flag = 1;
     if (launch_colexp(dB, ldb, k, n, d_part, d_E, 2, s, d_flag, 8 * p.S - 55, 8 * p.S - 1023)) return 1;
     if (guard == 1) {
       MXA_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));

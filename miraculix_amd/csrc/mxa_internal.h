@@ -49,6 +49,7 @@ struct Workspace {
   double *d_colpart = nullptr; size_t cap_colpart = 0; // column-sum partials + sums
   double *d_tmp = nullptr;    size_t cap_tmp = 0;      // snps x n intermediate of mxa_gram_matvec
   int *d_exp = nullptr;       size_t cap_exp = 0;      // per-column exponents of B (denormal-operand mode)
+  int *d_denflag = nullptr;                            // != 0: a column of B spans more binades than the denormal-operand mode carries (kDenMaxSpan)
   void *d_i8 = nullptr;       size_t cap_i8 = 0;       // int8 engine: exponents, slices of B, int32 partials (bytes)
 };
 
@@ -135,14 +136,20 @@ int launch_recode(const uint8_t *d_src, size_t src_pitch, long row0, long nrows,
                   PackedMatrix &dst, hipStream_t s);
 // denormal-operand mode of k_gemm (MODE 2): B columns are scaled to just below 2^kDenUp, the genotype operand is z * 2^-1074
 constexpr int kDenUp = 900;
+// A product z * b' * 2^-1074 (b' = the scaled entry) is a NORMAL double, i.e. exact, while |b'| >= 2^52: entries up to 847 binades below
+// their column's largest one.  Columns whose non-zero entries span more than kDenMaxSpan binades (or hold inf / NaN) are multiplied with
+// the two-instruction conversion (MODE 0, plain fp64 operands, no scaling) instead: launch_colexp raises a device flag, the MODE 0 chain
+// is enqueued behind the MODE 2 one with run_if_set = that flag and overwrites its partial sums; k_finish skips the scale-back.
+constexpr int kDenMaxSpan = 800;
 // E[j] = binary exponent of the largest |entry| of column j (frexp convention) + bias; d_part: 64 * n doubles of scratch
 // d_flag (nullable, device int): range guard of the exact int8 slicing, see k_colexp_final; then d_part needs 128 * n doubles
 int launch_colexp(const double *dB, long ldb, long k, int n, double *d_part, int *d_E, int bias, hipStream_t s, int *d_flag = nullptr, int max_span = 0,
-                  int min_emax = 0);
+                  int min_emax = 0, bool reset_flag = true);
 // d_E (nullable): per-column exponents for the denormal-operand mode
 // K-steps (16 genotypes) [S0, S0 + S_cnt) only; S_cnt < 0: to the end
+// run_if_set (nullable, device int): the kernel does nothing unless *run_if_set != 0
 int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k_pad, int n_pad, int c, hipStream_t s, const int *d_E = nullptr, long S0 = 0,
-                  long S_cnt = -1);
+                  long S_cnt = -1, const int *run_if_set = nullptr);
 int launch_colsums(const double *dB, long ldb, long k, int n, const double *d_f /*nullable*/, double *d_part,
                    double *d_sumB, double *d_sumfB, hipStream_t s);
 // p_rows: rows per tile of the partial-result array P[split][m_pad / p_rows][n_pad][p_rows] (k_gemm: the workgroup's row block, so a
@@ -150,14 +157,17 @@ int launch_colsums(const double *dB, long ldb, long k, int n, const double *d_f 
 struct GemmPlan { int a, c, nchunks, n_pad, splits, slabs_per_split, slabs_total, rowblocks; long m_pad; long p_rows; };
 GemmPlan plan_gemm(long m, long k_pad, int n, int force_splits = 0);
 // K splits [split_begin, split_end) only (split_end < 0: all)
-int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, int mode, hipStream_t s, int split_begin = 0, int split_end = -1);
+// run_if_set (nullable, device int; MODE 0 only): the kernel does nothing unless *run_if_set != 0 (fallback of the denormal-operand mode)
+int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, int mode, hipStream_t s, int split_begin = 0, int split_end = -1,
+                const int *run_if_set = nullptr);
 GemmPlan plan_lut(long m, long k_pad, int n);
 // run_if_set (nullable, device int): the kernel does nothing unless *run_if_set != 0 (fallback of the guarded small-n route)
 int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double *dP, const GemmPlan &p, hipStream_t s, const int *run_if_set = nullptr);
 // fill_rows: rows [m, fill_rows) of every column are zero-filled (fill_rows <= ldc)
 int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC, long ldc, long fill_rows, int mode_trans,
                   bool centered, const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s, const int *d_E = nullptr, int e_splits = 0,
-                  int e_stride = 0, const int *run_if_set = nullptr);
+                  int e_stride = 0, const int *run_if_set = nullptr, const int *unscaled_if_set = nullptr);
+// unscaled_if_set (nullable, device int): when *unscaled_if_set != 0 the partial sums were produced WITHOUT the operand scaling (MODE 0 fallback): d_E is ignored
 // per-device one-time hipFuncSetAttribute(MaxDynamicSharedMemorySize): function attributes are per device, `mask` has one bit per device
 int ensure_dyn_lds(const void *func, int bytes, unsigned long long *mask);
 int launch_transpose_2bit(const uint8_t *d_in, long rows, long cols, uint8_t *d_out, hipStream_t s);

@@ -90,7 +90,9 @@ int launch_recode(const uint8_t *d_src, size_t src_pitch, long row0, long nrows,
 // run of C*4 KiB, so it streams HBM -> LDS as C*4 lane-linear LDS-DMA units for any C.
 // K-steps [S0, S0 + S_cnt) only (the host-operand pipeline packs B in K ranges as they arrive); the whole array: S0 = 0, S_cnt = S_total.
 __global__ void __launch_bounds__(256) k_pack_B(const double *__restrict__ B, long ldb, long k, int n,
-                                                double *__restrict__ Bp, long total, int C, long S_total, const int *__restrict__ E, int up, long S0, long S_cnt) {
+                                                double *__restrict__ Bp, long total, int C, long S_total, const int *__restrict__ E, int up, long S0, long S_cnt,
+                                                const int *__restrict__ run_if_set) {
+  if (run_if_set && *run_if_set == 0) return;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int l = (int)(idx & 63);
     const long sh = idx >> 6;
@@ -154,21 +156,22 @@ __global__ void k_colexp_final(const double *__restrict__ part, int n, int bias,
     if (!ok) atomicOr(flag, 1);
   }
 }
-int launch_colexp(const double *dB, long ldb, long k, int n, double *d_part, int *d_E, int bias, hipStream_t s, int *d_flag, int max_span, int min_emax) {
-  if (d_flag) MXA_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), s));
+int launch_colexp(const double *dB, long ldb, long k, int n, double *d_part, int *d_E, int bias, hipStream_t s, int *d_flag, int max_span, int min_emax, bool reset_flag) {
+  if (d_flag && reset_flag) MXA_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), s));
   hipLaunchKernelGGL(k_colmax_partial, dim3(64, n), dim3(256), 0, s, dB, ldb, k, d_part, n, d_flag ? 1 : 0);
   hipLaunchKernelGGL(k_colexp_final, dim3((n + 63) / 64), dim3(64), 0, s, d_part, n, bias, d_E, d_flag, max_span, min_emax);
   MXA_HIP(hipGetLastError());
   return 0;
 }
 
-int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k_pad, int n_pad, int c, hipStream_t s, const int *d_E, long S0, long S_cnt) {
+int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k_pad, int n_pad, int c, hipStream_t s, const int *d_E, long S0, long S_cnt,
+                  const int *run_if_set) {
   const long S_total = k_pad / 16;
   if (S_cnt < 0) S_cnt = S_total - S0;
   const long total = S_cnt * (long)(n_pad / 4) * 64;
   if (total <= 0) return 0;
   const int grid = (int)std::min<long>((total + 255) / 256, 256L * 64);
-  hipLaunchKernelGGL(k_pack_B, dim3(grid), dim3(256), 0, s, dB, ldb, k, n, dBp, total, c, S_total, d_E, kDenUp, S0, S_cnt);
+  hipLaunchKernelGGL(k_pack_B, dim3(grid), dim3(256), 0, s, dB, ldb, k, n, dBp, total, c, S_total, d_E, kDenUp, S0, S_cnt, run_if_set);
   MXA_HIP(hipGetLastError());
   return 0;
 }
@@ -281,9 +284,11 @@ template <int A, int C, int MODE, bool DIAG = false>
 __global__ void __launch_bounds__(256, 2)
 k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ Bp, int H, double *__restrict__ P,
        long m_pad, int n_pad, int rowblocks, int nchunks, int slabs_total, int slabs_per_split, int xcd_order,
-       unsigned long long *__restrict__ diag = nullptr, int split0 = 0) {
+       unsigned long long *__restrict__ diag = nullptr, int split0 = 0, const int *__restrict__ run_if_set = nullptr) {
   using Cfg = GemmCfg<A, C>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // MODE 0 as the fallback of the denormal-operand mode: runs only when launch_colexp found a column outside its range (kDenMaxSpan)
+  if (MODE == 0) { if (run_if_set && *run_if_set == 0) return; }
   unsigned long long rt_begin = 0;
   if (DIAG) rt_begin = __builtin_amdgcn_s_memrealtime();
 
@@ -503,7 +508,7 @@ GemmPlan plan_gemm(long m, long k_pad, int n, int force_splits) {
 }
 
 template <int A, int C, int MODE>
-static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, hipStream_t s, int split_begin, int split_end) {
+static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, hipStream_t s, int split_begin, int split_end, const int *run_if_set) {
   using Cfg = GemmCfg<A, C>;
   static unsigned long long attr_mask = 0;   // function attributes are per device
   if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm<A, C, MODE>), Cfg::kLds, &attr_mask)) return 1;
@@ -512,7 +517,7 @@ static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, c
   if (grid <= 0) return 0;
   static const int xcd_order = [] { const char *e = getenv("MXA_XCD_ORDER"); return e ? atoi(e) : 1; }();   // 0: plain order (A/B measurement)
   static const bool diag_on = getenv("MXA_DIAG") != nullptr;
-  if (diag_on && A == 8 && C == 8 && split_begin == 0 && split_end == p.splits) {   // diagnostic instantiation: in-kernel clock + cycles per slab
+  if (diag_on && A == 8 && C == 8 && split_begin == 0 && split_end == p.splits && !run_if_set) {   // diagnostic instantiation: in-kernel clock + cycles per slab
     static unsigned long long attr2 = 0;
     if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm<A, C, MODE, true>), Cfg::kLds, &attr2)) return 1;
     unsigned long long *d_diag = nullptr;
@@ -544,12 +549,12 @@ static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, c
     return 0;
   }
   hipLaunchKernelGGL((k_gemm<A, C, MODE>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBp, p.n_pad / 4, dP,
-                     p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, p.slabs_per_split, xcd_order, nullptr, split_begin);
+                     p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, p.slabs_per_split, xcd_order, nullptr, split_begin, run_if_set);
   MXA_HIP(hipGetLastError());
   return 0;
 }
 
-int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, int mode, hipStream_t s, int split_begin, int split_end) {
+int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, int mode, hipStream_t s, int split_begin, int split_end, const int *run_if_set) {
   if (split_end < 0) split_end = p.splits;
   // host-side shape checks: the kernel reads rows [0, m_pad) x [0, slabs_total*32) bytes and Bp[(k_pad/16)][H][64]
   if (p.m_pad > G.rows_pad || (size_t)p.slabs_total * kSlabBytes > G.pitch) {
@@ -559,9 +564,9 @@ int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const Gemm
   }
 #define MXA_DISPATCH(AA, CC)                                              \
   if (p.a == AA && p.c == CC) {                                           \
-    if (mode == 1) return launch_gemm_t<AA, CC, 1>(G, dBp, dP, p, s, split_begin, split_end);     \
-    if (mode == 2) return launch_gemm_t<AA, CC, 2>(G, dBp, dP, p, s, split_begin, split_end);     \
-    return launch_gemm_t<AA, CC, 0>(G, dBp, dP, p, s, split_begin, split_end);                    \
+    if (mode == 1) return launch_gemm_t<AA, CC, 1>(G, dBp, dP, p, s, split_begin, split_end, nullptr);     \
+    if (mode == 2) return launch_gemm_t<AA, CC, 2>(G, dBp, dP, p, s, split_begin, split_end, nullptr);     \
+    return launch_gemm_t<AA, CC, 0>(G, dBp, dP, p, s, split_begin, split_end, run_if_set);                 \
   }
   MXA_DISPATCH(16, 1)
   MXA_DISPATCH(16, 2)
@@ -764,10 +769,11 @@ __global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, lo
                                                 double *__restrict__ Cout, long ldc, long fill_rows, int mode_trans, int centered,
                                                 const double *__restrict__ sumB, const double *__restrict__ sumfB,
                                                 const double *__restrict__ f, const int *__restrict__ E, int back, int e_splits, int e_stride,
-                                                const int *__restrict__ run_if_set) {
+                                                const int *__restrict__ run_if_set, const int *__restrict__ unscaled_if_set) {
   const int j = blockIdx.y;
   const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (run_if_set && *run_if_set == 0) return;
+  if (unscaled_if_set && *unscaled_if_set != 0) E = nullptr;   // the MODE 0 fallback produced these partial sums: nothing to scale back
   if (r >= fill_rows) return;
   double v = 0.0;
   if (r < m) {
@@ -790,10 +796,11 @@ __global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, lo
 }
 
 int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC, long ldc, long fill_rows, int mode_trans, bool centered,
-                  const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s, const int *d_E, int e_splits, int e_stride, const int *run_if_set) {
+                  const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s, const int *d_E, int e_splits, int e_stride, const int *run_if_set,
+                  const int *unscaled_if_set) {
   dim3 grid((unsigned)((fill_rows + 255) / 256), n);
   hipLaunchKernelGGL(k_finish, grid, dim3(256), 0, s, dP, p.m_pad, p.p_rows, p.n_pad, p.splits, m, n, dC, ldc, fill_rows, mode_trans, centered ? 1 : 0,
-                     d_sumB, d_sumfB, d_f, d_E, 1074 - kDenUp, e_splits, e_stride, run_if_set);
+                     d_sumB, d_sumfB, d_f, d_E, 1074 - kDenUp, e_splits, e_stride, run_if_set, unscaled_if_set);
   MXA_HIP(hipGetLastError());
   return 0;
 }

@@ -80,6 +80,9 @@ def load_shared_library():
     L.mxa_set_engine.argtypes = [ctypes.c_int]
     L.mxa_set_engine.restype = ctypes.c_int
     L.mxa_get_engine.restype = ctypes.c_int
+    L.mxa_last_path.restype = ctypes.c_int
+    L.mxa_last_range_fallback.argtypes = [ctypes.c_void_p]
+    L.mxa_last_range_fallback.restype = ctypes.c_int
     L.mxa_profile_reset.restype = None
     L.mxa_profile_get.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]
     L.mxa_profile_get.restype = None

@@ -138,3 +138,55 @@ def test_extreme_magnitudes_of_B(mx):
             assert not np.any(np.isfinite(Cinf[:, 1]))             # inf * z is inf (z > 0) or NaN (z = 0), as in plain fp64
     finally:
         dg.free_compressed(obj)
+
+
+def _problem_from_Z(Z):
+    from _util import pack_plink
+    indiv, snps = Z.shape
+    return dict(snps=snps, indiv=indiv, plink=np.ascontiguousarray(pack_plink(Z.T.copy())), plink_t=np.ascontiguousarray(pack_plink(Z)),
+                f=Z.astype(np.float64).mean(axis=0) / 2.0, Z=Z)
+
+
+@pytest.mark.parametrize("decades,expect_fallback", [(150, 1), (100, 0)])
+def test_column_span_around_the_denormal_window(mx, decades, expect_fallback):
+    """The fp64 MFMA path scales every column of B into a fixed window (genotype operand = the denormal z * 2^-1074); entries more than
+    ~848 binades below their column's largest one would produce sub-normal products.  Adversarial input: a column that is 10^+decades at
+    a few positions and 10^-decades * N(0,1) elsewhere, and output rows whose genotypes are ZERO exactly where the column is huge --
+    their results are sums of the tiny entries only and a plain fp64 FMA chain (the reference's arithmetic,
+    dgemm_compressed_cuda.h:259-266) gets them right.  decades = 150 (span 996 binades > kDenMaxSpan = 800): the per-call guard must send
+    the product to the plain-operand fallback; decades = 100 (664 binades): inside the window, no fallback.  Element-wise against the
+    long-double oracle either way."""
+    from _util import synth_genotypes
+    o = Oracle()
+    snps, indiv, n = 1500, 600, 6
+    Z, _ = synth_genotypes(snps, indiv, seed=5)
+    Z[:12, :48] = 0          # 'N': individuals 0..11 carry no allele at SNPs 0..47
+    Z[:40, :9] = 0           # 'T': SNPs 0..8 are zero in individuals 0..39
+    prob = _problem_from_Z(Z)
+    dg = mx.dgemm_compressed
+    L = mx.check_library_handle()
+    dg.set_options(use_gpu=True, not_center=True, verbose=0)
+    obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], n)
+    try:
+        for trans, nbig, quiet in ((0, 48, slice(0, 12)), (1, 40, slice(0, 9))):
+            k = indiv if trans else snps
+            m = snps if trans else indiv
+            B = make_B(k, n, seed=8)
+            B[2, :nbig] = 10.0 ** decades * (1.0 + np.arange(nbig) / 64.0)
+            B[2, nbig:] *= 10.0 ** -decades
+            ref = o.dgemm_dense(trans, prob, B, 0)[:, :m]
+            C = dg.dgemm_compressed_main(bool(trans), obj, np.asfortranarray(B.T), snps, indiv)
+            assert L.mxa_last_range_fallback(obj) == expect_fallback
+            for j in range(n):
+                assert np.abs(C[:, j] - ref[j]).max() <= RTOL * np.abs(ref[j]).max(), (trans, j)
+            q_ref, q_got = ref[2][quiet], C[quiet, 2]
+            assert np.all(q_ref != 0.0) and np.abs(q_ref).max() < 10.0 ** (3 - decades)       # tiny, but not nothing
+            assert np.abs(q_got - q_ref).max() <= 1e-12 * np.abs(q_ref).max(), (trans, q_got, q_ref)
+            # the next ordinary product on the same object is back on the fast path
+            B2 = make_B(k, n, seed=9)
+            C2 = dg.dgemm_compressed_main(bool(trans), obj, np.asfortranarray(B2.T), snps, indiv)
+            assert L.mxa_last_range_fallback(obj) == 0
+            ref2 = o.dgemm_dense(trans, prob, B2, 0)[:, :m]
+            assert np.abs(C2.T - ref2).max() <= RTOL * np.abs(ref2).max()
+    finally:
+        dg.free_compressed(obj)
