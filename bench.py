@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: effective GFLOP/s of dgemm_compressed (2-bit SNP x fp64) on N MI355X.
 
+Structure: setup_process / stage_headline / make_step_and_sync / run_timed (the timed region and `value`), then legs that never feed
+`value`: per_rank (launcher) or per_shard + rccl_reduction + hub_operands_on_first_device (in-process N > 1), opt_in_engine,
+abi_end_to_end, cpu_baseline + check, and at N = 1 the other BASELINE configs under their own checkers: config5_cg_step,
+config4_shard, config3_crossprod (reference harness shape: utils/benchmark/benchmark.f90:182-254).
+
 Workload (BASELINE.json configs[1]): 1M SNPs x 50k individuals, n=32, dgemm_compressed 'N' and 'T', uncentred,
 synthetic PLINK data generated on the device.  One step = one 'N' multiply (+ the fp64 all-reduce of the indiv x n
 result when N > 1) and one 'T' multiply; flops per step = 2 * (2 * snps * indiv * n).  Inputs (packed genotypes, B, C)
@@ -191,7 +196,7 @@ def measure_traffic(args):
     x `read_factor`: the guide's gfx950 correction is x2 for wide coalesced streams; profiles/r02_pmc_calibration.json holds the factor
     calibrated here on a known-size stream through the same 1-KiB LDS-DMA units (tools/pmc_calibrate.*), used when present.
     Returns (GB per launch or None, detail dict)."""
-    import collections, csv, glob, shutil, subprocess, tempfile
+    import collections, csv, glob, re, shutil, subprocess, tempfile
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return None, {"skipped": "rocprofv3 not found"}
@@ -216,7 +221,8 @@ def measure_traffic(args):
                 return None, {"skipped": f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"}
             agg = collections.OrderedDict()
             for row in csv.DictReader(open(src[0])):
-                if "k_gemm<" in row["Kernel_Name"] and row.get("Counter_Name", ctr) == ctr:
+                # the shipped instantiation only (MODE 2); the MODE 0 launch behind it is the range-guard fallback and returns at once
+                if re.search(r"k_gemm<\d+, ?\d+, ?2,", row["Kernel_Name"]) and row.get("Counter_Name", ctr) == ctr:
                     agg[row["Dispatch_Id"]] = agg.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
             vals[ctr] = list(agg.values())
     except Exception as e:   # a profiler problem must not take the benchmark down
@@ -232,6 +238,353 @@ def measure_traffic(args):
                                         "WRITE_SIZE_GB": [round(w / 1e9, 3) for w in writes], "read_factor": factor, "read_factor_source": calib}
 
 
+# ====================================================================================================== helpers shared by the legs
+def sampled_rows_vs_oracle(torch, S, trans, Bdev, Cdev, cols, centered, nsample=64, seed=1):
+    """nsample rows of a result (individuals for 'N', SNPs for 'T'), columns `cols`, against the long-double dense oracle on the
+    extracted rows of the packed matrix.  S: dict(dev, snps, indiv, plink (SNP-major, device), plink_t (individual-major, device),
+    f (device)).  Returns max|C - ref| / max|ref|.  (Checker use of oracle/: tests and this file's parity legs only.)"""
+    import numpy as np
+    from _util import Oracle
+    dev, snps, indiv = S["dev"], S["snps"], S["indiv"]
+    o = Oracle()
+    rng = np.random.default_rng(seed)
+    f = S["f"].cpu().numpy()
+    Bs = np.ascontiguousarray(Bdev[:, cols].t().cpu().numpy())                        # len(cols) x k, row j = column cols[j]
+    if not trans:
+        ii = np.sort(rng.choice(indiv, nsample, replace=False))
+        rows = S["plink_t"][torch.from_numpy(ii).to(dev)].cpu().numpy()               # nsample x ceil(snps/4)
+        sub_plink = o.transpose_2bit(np.ascontiguousarray(rows), nsample, snps)        # snps x ceil(nsample/4)
+        prob = dict(snps=snps, indiv=nsample, plink=sub_plink, plink_t=rows, f=f)
+        ref = o.dgemm_dense(0, prob, Bs, centered)                                     # len(cols) x nsample
+        got = Cdev[torch.from_numpy(ii).to(dev)][:, cols].t().cpu().numpy()
+    else:
+        ss = np.sort(rng.choice(snps, nsample, replace=False))
+        srows = S["plink"][torch.from_numpy(ss).to(dev)].cpu().numpy()                # nsample x ceil(indiv/4)
+        prob = dict(snps=nsample, indiv=indiv, plink=np.ascontiguousarray(srows), plink_t=None, f=np.ascontiguousarray(f[ss]))
+        ref = o.dgemm_dense(1, prob, Bs, centered)
+        got = Cdev[torch.from_numpy(ss).to(dev)][:, cols].t().cpu().numpy()
+    return float(np.abs(got - ref).max() / np.abs(ref).max())
+
+
+def stage_object(torch, mx, dev, snps, indiv, n, seed, centered):
+    """synthetic genotypes generated on the device, transposed and counted there, staged through plink2compressed"""
+    plink = synth_genotypes_device(torch, snps, indiv, seed, dev)                       # SNP-major
+    plink_t = mx.compressed_operations.transpose_genotype_matrix(plink, snps, indiv)
+    f = mx.read_plink.calc_freq(plink, snps, indiv)
+    dg = mx.dgemm_compressed
+    dg.set_options(use_gpu=True, not_center=not centered, verbose=0)
+    obj = dg.init_compressed(plink, plink_t, snps, indiv, f, n)
+    return dict(torch=torch, mx=mx, dev=dev, plink=plink, plink_t=plink_t, f=f, obj=obj, dg=dg, snps=snps, indiv=indiv, n=n)
+
+
+def kernel_profile(L):
+    la, ms = ctypes.c_int(0), ctypes.c_double(0.0)
+    L.mxa_profile_get(ctypes.byref(la), ctypes.byref(ms))
+    return la.value, ms.value
+
+
+def timed(fn, sync, reps):
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / reps
+
+
+# ====================================================================================================== the other configs (N = 1, rank 0, never `value`)
+def config5_cg_step_leg(torch, mx, L, dev, snps=250_000, indiv=100_000, reps=20):
+    """BASELINE config 5 at its per-GPU shard (2M SNPs x 100k over 8 GPUs): one CG step G v = Zc (Zc^T v), n = 1, centred, vectors
+    resident in HBM (reference loop: examples/iterative_solver/grm_solve_cg.jl:74-84).  HBM-bound: a step reads both packed
+    orientations once."""
+    S = stage_object(torch, mx, dev, snps, indiv, 1, 45, centered=True)
+    dg = S["dg"]
+    try:
+        g = torch.Generator(device=dev); g.manual_seed(7)
+        v = torch.randn((1, indiv), dtype=torch.float64, device=dev, generator=g).t()
+        out = torch.zeros((1, indiv), dtype=torch.float64, device=dev).t()
+        sync = torch.cuda.synchronize
+        dg.gram_matvec(S["obj"], v, snps, indiv, out=out)
+        t_step = timed(lambda: dg.gram_matvec(S["obj"], v, snps, indiv, out=out), sync, reps)
+        L.mxa_profile_reset()
+        T = dg.dgemm_compressed_main(True, S["obj"], v, snps, indiv)
+        la_t, ms_t = kernel_profile(L)
+        path = dg.last_path()
+        L.mxa_profile_reset()
+        N = dg.dgemm_compressed_main(False, S["obj"], T, snps, indiv)
+        la_n, ms_n = kernel_profile(L)
+        err_t = sampled_rows_vs_oracle(torch, S, 1, v, T, [0], 1, nsample=32)
+        err_n = sampled_rows_vs_oracle(torch, S, 0, T, N, [0], 1, nsample=32)
+        same = bool(torch.equal(out, N))
+        bytes_step = 2.0 * snps * ((indiv + 3) // 4)      # both packed orientations, once each
+        tbs = bytes_step / t_step * 1e-12
+        return {"workload": f"{snps} SNPs x {indiv} indiv (per-GPU shard of config 5), n=1, centred, one mxa_gram_matvec = 'T' + 'N'",
+                "ms_per_cg_step": round(t_step * 1e3, 4), "kernel_path": path, "dominant_kernel_ms": {"T": round(ms_t / max(1, la_t), 4), "N": round(ms_n / max(1, la_n), 4)},
+                "algorithmic_TB_per_s": round(tbs, 3), "frac_of_8_TBs_spec": round(tbs / 8.0, 4), "frac_of_6.3_TBs_achievable": round(tbs / 6.3, 4),
+                "check": {"T_32_sampled_rows_vs_dense_oracle_max_rel_err": err_t, "N_32_sampled_rows_vs_dense_oracle_max_rel_err": err_n,
+                          "gram_matvec_bitwise_equals_T_then_N": same, "checker_tolerance": 1e-11}}
+    finally:
+        dg.free_compressed(S["obj"])
+        S.clear()
+        torch.cuda.empty_cache()
+
+
+def config4_shard_leg(torch, mx, L, dev, snps=625_000, indiv=200_000, n=128, reps=3):
+    """BASELINE config 4 at its per-GPU shard (5M SNPs x 200k over 8 GPUs): ncol = 128, allele-frequency centred, 'N' + 'T'"""
+    S = stage_object(torch, mx, dev, snps, indiv, n, 44, centered=True)
+    dg = S["dg"]
+    try:
+        g = torch.Generator(device=dev); g.manual_seed(3)
+        Y = torch.randn((n, snps), dtype=torch.float64, device=dev, generator=g).t()
+        X = torch.randn((n, indiv), dtype=torch.float64, device=dev, generator=g).t()
+        CN = torch.zeros((n, indiv), dtype=torch.float64, device=dev).t()
+        CT = torch.zeros((n, snps), dtype=torch.float64, device=dev).t()
+        sync = torch.cuda.synchronize
+        res = {}
+        for name, trans, B, C in (("N", False, Y, CN), ("T", True, X, CT)):
+            dg.dgemm_compressed_main(trans, S["obj"], B, snps, indiv, out=C)
+            L.mxa_profile_reset()
+            t = timed(lambda: dg.dgemm_compressed_main(trans, S["obj"], B, snps, indiv, out=C), sync, reps)
+            la, ms = kernel_profile(L)
+            flops = 2.0 * snps * indiv * n
+            res[name] = {"ms_per_call": round(t * 1e3, 3), "k_gemm_ms": round(ms / max(1, la), 3), "TFLOPs_call": round(flops / t * 1e-12, 2),
+                         "TFLOPs_kernel": round(flops / (ms / max(1, la) * 1e-3) * 1e-12, 2), "frac_of_fp64_mfma_peak_kernel": round(flops / (ms / max(1, la) * 1e-3) * 1e-12 / FP64_MFMA_PEAK_TFLOPS, 4)}
+        cols = [0, 31, 32, 127]
+        err_n = sampled_rows_vs_oracle(torch, S, 0, Y, CN, cols, 1, nsample=16)
+        err_t = sampled_rows_vs_oracle(torch, S, 1, X, CT, cols, 1, nsample=16)
+        lhs, rhs = (X * CN).sum(dim=0), (CT * Y).sum(dim=0)
+        adj = float(((lhs - rhs).abs() / (X.abs() * CN.abs()).sum(dim=0)).max())
+        return {"workload": f"{snps} SNPs x {indiv} indiv (per-GPU shard of config 4), ncol={n}, centred", "N": res["N"], "T": res["T"],
+                "check": {"N_16_sampled_rows_vs_dense_oracle_max_rel_err": err_n, "T_16_sampled_rows_vs_dense_oracle_max_rel_err": err_t,
+                          "centred_adjoint_identity_max_rel_err": adj, "checker_tolerance": 1e-11}}
+    finally:
+        dg.free_compressed(S["obj"])
+        S.clear()
+        torch.cuda.empty_cache()
+
+
+def config3_crossprod_leg(torch, mx, L, dev, snps=500_000, indiv=100_000):
+    """BASELINE config 3: GRM crossproduct M = X X^T, 500k SNPs x 100k individuals, device-resident 80 GB fp64 result, with both engines
+    (FP4 MFMA = default while exact, int8 MFMA = the path BASELINE names).  Ops: 2 * snps * indiv^2 in the full-matrix count
+    (SURVEY.md 8d); executed = the upper-triangular 256 x 256 tiles only."""
+    import numpy as np
+    from _util import Oracle
+    X = synth_genotypes_device(torch, indiv, snps, 46, dev, p_along="cols")              # individual-major, 12.5 GB
+    M = torch.empty((indiv, indiv), dtype=torch.float64, device=dev)                     # 80 GB
+    o = Oracle()
+    nb = (indiv + 255) // 256
+    tiles = [(0, 0), (nb - 1, nb - 1), (0, nb - 1), (nb // 3, nb // 2)]
+    refs = []
+    for ti, tj in tiles:
+        ri = np.arange(ti * 256, min(indiv, ti * 256 + 256)); rj = np.arange(tj * 256, min(indiv, tj * 256 + 256))
+        rows = np.concatenate([ri, rj]) if ti != tj else ri
+        sub = np.ascontiguousarray(X[torch.from_numpy(rows).to(dev)].cpu().numpy())
+        ref = o.crossprod_i32(sub, snps, True).astype(np.float64)
+        refs.append((ri, rj, ref if ti == tj else ref[: len(ri), len(ri):]))
+    full_ops = 2.0 * snps * float(indiv) ** 2
+    exec_ops = 2.0 * snps * 256.0 * 256.0 * (nb * (nb + 1) // 2)
+    out = {"workload": f"GRM crossproduct, {snps} SNPs x {indiv} indiv, device-resident fp64 result ({indiv * indiv * 8 / 1e9:.0f} GB)"}
+    old = os.environ.get("MXA_XPROD_ENGINE")
+    try:
+        for eng, peak in (("f4", 10.0), ("i8", 5.0)):
+            if eng == "i8":
+                os.environ["MXA_XPROD_ENGINE"] = "i8"
+            else:
+                os.environ.pop("MXA_XPROD_ENGINE", None)
+            M.fill_(-1.0)
+            torch.cuda.synchronize()
+            L.mxa_profile_reset()
+            t0 = time.perf_counter()
+            mx.crossproduct.snp_crossprod(X, snps, indiv, is_snpmajor=False, is_plink_format=True, out=M)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            la, ms = kernel_profile(L)
+            exact = True
+            for ri, rj, ref in refs:
+                exact &= bool(np.array_equal(M[ri[0]:ri[-1] + 1, rj[0]:rj[-1] + 1].cpu().numpy(), ref))
+                exact &= bool(np.array_equal(M[rj[0]:rj[-1] + 1, ri[0]:ri[-1] + 1].cpu().numpy(), ref.T))
+            sym = bool(torch.equal(M[:2048, :], M[:, :2048].t())) and float(M[-4096:].min()) >= 0.0
+            k_ms = ms / max(1, la)
+            out["k_crossprod_f4 (FP4 MFMA, default)" if eng == "f4" else "k_crossprod2 (int8 MFMA)"] = {
+                "kernel_ms": round(k_ms, 2), "call_ms_incl_staging": round(wall * 1e3, 1), "Pop_s_full_matrix_count": round(full_ops / (k_ms * 1e-3) * 1e-15, 3),
+                "Pop_s_executed": round(exec_ops / (k_ms * 1e-3) * 1e-15, 3), "dense_peak_Pop_s": peak, "frac_of_peak_executed": round(exec_ops / (k_ms * 1e-3) * 1e-15 / peak, 4),
+                "check": {"four_256x256_tiles_and_mirrors_bit_exact_vs_int32_oracle": exact, "first_panel_symmetric_and_all_written": sym}}
+    finally:
+        if old is None:
+            os.environ.pop("MXA_XPROD_ENGINE", None)
+        else:
+            os.environ["MXA_XPROD_ENGINE"] = old
+        del X, M
+        torch.cuda.empty_cache()
+    return out
+
+
+# ====================================================================================================== the headline workload
+class Workload:
+    """config 2 staged for this process: the SNP block of this rank (one process per GPU) or the whole matrix behind a multi-device
+    object (in-process, MIRACULIX_NUM_GPUS), B and C resident in HBM"""
+
+
+def setup_process(args):
+    import torch
+    import torch.distributed as dist
+    W = Workload()
+    W.world = int(os.environ.get("WORLD_SIZE", "1"))
+    W.rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # single process asked for several GPUs (no torch.distributed launcher): the SNP shards live BEHIND the C ABI
+    # (MIRACULIX_NUM_GPUS, mxa_multi.cpp) -- the path a Julia / Fortran caller gets.  Under the launcher: one rank per GPU, RCCL.
+    W.inprocess = W.world == 1 and args.gpus > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # rehearsal knobs (never used by the driver): MXA_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and MXA_BENCH_BACKEND=gloo
+    # replaces RCCL, so the N > 1 control flow can be exercised on a one-GPU box
+    if os.environ.get("MXA_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("MXA_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local_rank)
+    W.device = torch.device("cuda", local_rank)
+    os.environ["HIP_DEVICE"] = str(local_rank)
+    W.force_dist = os.environ.get("MXA_BENCH_FORCE_DIST") == "1"   # exercise the RCCL path with a 1-rank group
+    if W.world > 1 or W.force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=W.device)
+        else:
+            dist.init_process_group(backend)
+    W.torch, W.dist = torch, dist
+    W.n_gpus = args.gpus if W.inprocess else W.world
+    return W
+
+
+def stage_headline(W, args, mx, L):
+    torch, dist, device = W.torch, W.dist, W.device
+    from miraculix_amd.distributed import HipLocalEngine, ShardedGenotypeOperator, shard_bounds
+    snps, indiv, n = args.snps, args.indiv, args.ncol
+    b, e = (0, snps) if W.inprocess else shard_bounds(snps, W.world, W.rank)
+    W.begin, W.end, W.snps_loc = b, e, e - b
+    if W.snps_loc <= 0:
+        raise SystemExit(f"bench.py: rank {W.rank} of {W.world} has no SNPs ({snps} SNPs): use fewer ranks")
+    # ---- synthetic data, generated on the device (SURVEY.md 8d: p_s ~ U(0.1, 0.6), g ~ Binomial(2, p_s), no missings)
+    plink = synth_genotypes_device(torch, W.snps_loc, indiv, 42 + W.rank, device)                  # SNP-major
+    plink_t = torch.empty((indiv, (W.snps_loc + 3) // 4), dtype=torch.uint8, device=device)        # individual-major
+    assert L.mxa_transpose_2bit(mx.lib.ptr(plink), W.snps_loc, indiv, mx.lib.ptr(plink_t)) == 0
+    freq = torch.empty(W.snps_loc, dtype=torch.float64, device=device)
+    assert L.mxa_allele_freq(mx.lib.ptr(plink), W.snps_loc, indiv, mx.lib.ptr(freq)) == 0
+    if W.inprocess:
+        os.environ["MIRACULIX_NUM_GPUS"] = str(args.gpus)
+    W.eng = HipLocalEngine(plink, plink_t, W.snps_loc, indiv, freq, n, centered=bool(args.centered))
+    os.environ.pop("MIRACULIX_NUM_GPUS", None)
+    W.n_shards = mx.dgemm_compressed.num_shards(W.eng.obj)
+    W.keep_raw = W.world == 1 and not W.inprocess and not args.no_cpu_baseline       # the CPU-baseline / parity leg samples the raw matrices
+    W.plink, W.plink_t, W.freq = (plink, plink_t, freq) if W.keep_raw else (None, None, None)
+    del plink, plink_t
+    torch.cuda.empty_cache()
+    W.op = ShardedGenotypeOperator(W.eng, snps, indiv)
+    W.op.force_collective = W.force_dist
+    g = torch.Generator(device=device); g.manual_seed(43)
+    W.B_N = torch.randn((n, snps), dtype=torch.float64, device=device, generator=g)[:, b:e].contiguous().t()   # snps_loc x n, column-major
+    W.B_T = torch.randn((n, indiv), dtype=torch.float64, device=device, generator=g).t()                       # indiv x n
+    W.C_N = torch.zeros((n, indiv), dtype=torch.float64, device=device).t()
+    W.C_T = torch.zeros((n, W.snps_loc), dtype=torch.float64, device=device).t()
+    if W.inprocess:
+        # operands PER SHARD, each on its shard's device: 'N' reads B[s_g, :] and 'T' writes C[s_g, :] where they live; nothing but the
+        # indiv x n partial sums crosses a device boundary (mxa_dgemm_compressed_multi).  The hub variant (all of B / C on the first
+        # device, through the plain dgemm_compressed symbol) is timed beside it as `hub_operands_on_first_device`.
+        dg = mx.dgemm_compressed
+        W.info0 = dg.multi_info(W.eng.obj)
+        W.bounds = dg.shard_bounds(W.eng.obj, snps)
+        W.devs = [torch.device("cuda", s["device"]) for s in W.info0["per_shard"]]
+        ld = max(e1 - b1 for b1, e1 in W.bounds)
+        W.BN_s, W.CT_s, W.BT_s = [], [], []
+        for (b1, e1), d in zip(W.bounds, W.devs):
+            buf = torch.zeros((n, ld), dtype=torch.float64, device=d)
+            buf[:, : e1 - b1] = W.B_N[b1:e1].t().to(d)
+            W.BN_s.append(buf.t()[: e1 - b1])
+            W.CT_s.append(torch.zeros((n, ld), dtype=torch.float64, device=d).t()[: e1 - b1])
+            W.BT_s.append(W.B_T if d == device else W.B_T.t().to(d).t())
+        W.CN_list = [W.C_N] + [None] * (W.n_shards - 1)
+
+
+def make_step_and_sync(W, mx, hub=False):
+    torch, dist = W.torch, W.dist
+    dg = mx.dgemm_compressed
+    if W.inprocess and not hub:
+        def step():
+            dg.dgemm_compressed_multi(False, W.eng.obj, W.BN_s, W.CN_list, sync=False)      # 'N': products, pushes and the addition are enqueued ...
+            dg.dgemm_compressed_multi(True, W.eng.obj, W.BT_s, W.CT_s, sync=False)          # ... and 'T' runs on the shard streams beside the reduction
+
+        def sync():
+            dg.multi_synchronize(W.eng.obj)
+            for d in set(W.devs):
+                torch.cuda.synchronize(d)
+    else:
+        def step():
+            _, work = W.op.matmul_N(W.B_N, out=W.C_N, async_op=True)
+            W.op.matmul_T(W.B_T, out=W.C_T)
+            if work is not None:
+                work.wait()
+
+        def sync():
+            if dist.is_initialized():
+                dist.barrier()
+            torch.cuda.synchronize()
+    return step, sync
+
+
+def run_timed(W, step, sync, warmup, steps):
+    torch, dist = W.torch, W.dist
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist.is_initialized():
+        t = torch.tensor([dt], dtype=torch.float64, device=W.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def adjoint_check(W):
+    """parity check on every run (size-independent property; the oracle cannot run at this size): the adjoint identity
+    <B_T[:,j], Z B_N[:,j]> == <Z^T B_T[:,j], B_N[:,j]> ties the 'N' result (individual-major copy, reduced over the SNP shards) to the
+    'T' result (SNP-major copy) column by column"""
+    torch, dist = W.torch, W.dist
+    lhs = (W.B_T * W.C_N).sum(dim=0)
+    if W.inprocess:
+        rhs = sum((c * b).sum(dim=0).to(W.device) for c, b in zip(W.CT_s, W.BN_s))
+    else:
+        rhs = (W.C_T * W.B_N).sum(dim=0)
+        if dist.is_initialized():
+            dist.all_reduce(rhs, op=dist.ReduceOp.SUM)
+    err = float(((lhs - rhs).abs() / lhs.abs().clamp_min(1.0)).max())
+    if not (err <= 1e-10):
+        raise SystemExit(f"bench.py: adjoint identity violated (rel err {err:.3e}): results are wrong, no number reported")
+    return err
+
+
+def per_shard_report(W, mx, args, flops_shard):
+    """in-process N > 1: what every shard did in the timed region (HIP events on the streams the work ran on)"""
+    info = mx.dgemm_compressed.multi_info(W.eng.obj)
+    rep = {"reduction": info["reduction"], "root_device": info["root_device"], "devices": info["devices"], "reductions": info["reductions"],
+           "avg_reduce_kernel_ms": round(info["reduce_ms"] / max(1, info["reductions"]), 4), "reduce_bytes_per_shard": int(8 * args.indiv * args.ncol),
+           "shards": []}
+    for s in info["per_shard"]:
+        k = s["kernel_ms"] / max(1, s["kernel_launches"])
+        rep["shards"].append({"device": s["device"], "snps": s["snp_end"] - s["snp_begin"], "peer_access_to_root": s["peer_to_root"], "peer_access_from_root": s["peer_from_root"],
+                              "k_gemm_launches": s["kernel_launches"], "avg_k_gemm_ms": round(k, 4), "k_gemm_TFLOPs": round(flops_shard / (k * 1e-3) * 1e-12, 2) if k > 0 else None,
+                              "operand_copies_in": s["in_copies"], "avg_copy_in_ms": round(s["in_ms"] / max(1, s["in_copies"]), 4),
+                              "result_copies_out": s["out_copies"], "avg_copy_out_ms": round(s["out_ms"] / max(1, s["out_copies"]), 4),
+                              "partial_pushes": s["pushes"], "avg_push_ms": round(s["push_ms"] / max(1, s["pushes"]), 4)})
+    return rep, info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,132 +598,90 @@ def main():
     ap.add_argument("--no-alt-engine", action="store_true", help="skip the extra (untimed, informational) pass with the opt-in int8 engine")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic")
     ap.add_argument("--no-abi", action="store_true", help="skip the ABI end-to-end leg (host B / C through dgemm_compressed)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the legs for BASELINE configs 3, 4 (shard) and 5 (shard)")
+    ap.add_argument("--configs-scale", type=float, default=1.0, help=argparse.SUPPRESS)   # rehearsals shrink the config legs
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # single process asked for several GPUs (no torch.distributed launcher): the SNP shards live BEHIND the C ABI
-    # (MIRACULIX_NUM_GPUS, mxa_multi.cpp) -- the path a Julia / Fortran caller gets.  The driver's N > 1 runs use one rank per GPU.
     inprocess = world == 1 and args.gpus > 1
     # roofline.traffic is measured first, before this process touches the GPU (N = 1 only; the children profile the same workload)
     traffic, traffic_detail = None, {"skipped": "N > 1" if (world > 1 or inprocess) else "--no-pmc"}
     if world == 1 and not inprocess and not args.no_pmc:
         traffic, traffic_detail = measure_traffic(args)
 
-    import torch
-    import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    # rehearsal knobs (never used by the driver): MXA_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and MXA_BENCH_BACKEND=gloo
-    # replaces RCCL, so the N > 1 control flow can be exercised on a one-GPU box
-    if os.environ.get("MXA_BENCH_SINGLE_DEVICE") == "1":
-        local_rank = 0
-    backend = os.environ.get("MXA_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    os.environ["HIP_DEVICE"] = str(local_rank)
-    force_dist = os.environ.get("MXA_BENCH_FORCE_DIST") == "1"   # exercise the RCCL path with a 1-rank group
-    if world > 1 or force_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
-
+    W = setup_process(args)
+    torch, dist = W.torch, W.dist
     import miraculix_amd as mx
-    from miraculix_amd.distributed import HipLocalEngine, ShardedGenotypeOperator, shard_bounds
     L = mx.load_shared_library()
     L.mxa_set_engine(0)   # the headline number is the fp64 engine, whatever MXA_ENGINE says
-
+    stage_headline(W, args, mx, L)
     snps, indiv, n = args.snps, args.indiv, args.ncol
-    b, e = (0, snps) if inprocess else shard_bounds(snps, world, rank)
-    snps_loc = e - b
-    if snps_loc <= 0:
-        raise SystemExit(f"bench.py: rank {rank} of {world} has no SNPs ({snps} SNPs): use fewer ranks")
-    # ---- synthetic data, generated on the device (p_s ~ U(0.1, 0.6), g ~ Binomial(2, p_s), no missings)
-    plink = synth_genotypes_device(torch, snps_loc, indiv, 42 + rank, device)                    # SNP-major
-    plink_t = torch.empty((indiv, (snps_loc + 3) // 4), dtype=torch.uint8, device=device)        # individual-major
-    assert L.mxa_transpose_2bit(mx.lib.ptr(plink), snps_loc, indiv, mx.lib.ptr(plink_t)) == 0
-    freq = torch.empty(snps_loc, dtype=torch.float64, device=device)
-    assert L.mxa_allele_freq(mx.lib.ptr(plink), snps_loc, indiv, mx.lib.ptr(freq)) == 0
-    if inprocess:
-        os.environ["MIRACULIX_NUM_GPUS"] = str(args.gpus)
-    eng = HipLocalEngine(plink, plink_t, snps_loc, indiv, freq, n, centered=bool(args.centered))
-    os.environ.pop("MIRACULIX_NUM_GPUS", None)
-    n_shards = mx.dgemm_compressed.num_shards(eng.obj)
-    keep_raw = world == 1 and not inprocess and not args.no_cpu_baseline       # the CPU-baseline / parity leg samples the raw matrices
-    if not keep_raw:
-        del plink, plink_t
-    torch.cuda.empty_cache()
-    op = ShardedGenotypeOperator(eng, snps, indiv)
-    op.force_collective = force_dist
+    dg = mx.dgemm_compressed
 
-    g = torch.Generator(device=device); g.manual_seed(43)
-    B_N = torch.randn((n, snps), dtype=torch.float64, device=device, generator=g)[:, b:e].contiguous().t()   # snps_loc x n, column-major
-    B_T = torch.randn((n, indiv), dtype=torch.float64, device=device, generator=g).t()                       # indiv x n
-    C_N = torch.zeros((n, indiv), dtype=torch.float64, device=device).t()
-    C_T = torch.zeros((n, snps_loc), dtype=torch.float64, device=device).t()
-
-    def step():
-        _, work = op.matmul_N(B_N, out=C_N, async_op=True)
-        op.matmul_T(B_T, out=C_T)
-        if work is not None:
-            work.wait()
-
-    def sync():
-        if dist.is_initialized():
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    # ---- the timed region: W untimed steps, then exactly K steps between barrier + synchronize on both sides
+    step, sync = make_step_and_sync(W, mx)
     for _ in range(args.warmup):
         step()
     sync()
     L.mxa_profile_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
-    if dist.is_initialized():
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    launches, total_ms = ctypes.c_int(0), ctypes.c_double(0.0)
-    L.mxa_profile_get(ctypes.byref(launches), ctypes.byref(total_ms))
-
-    # parity check on every run (size-independent property; the oracle cannot run at this size): the adjoint identity
-    # <B_T[:,j], Z B_N[:,j]> == <Z^T B_T[:,j], B_N[:,j]> ties the 'N' result (individual-major copy, all-reduced over the
-    # SNP shards) to the 'T' result (SNP-major copy) column by column.
-    lhs = (B_T * C_N).sum(dim=0)
-    rhs = (C_T * B_N).sum(dim=0)
-    if dist.is_initialized():
-        dist.all_reduce(rhs, op=dist.ReduceOp.SUM)
-    adj_err = float(((lhs - rhs).abs() / lhs.abs().clamp_min(1.0)).max())
-    if not (adj_err <= 1e-10):
-        raise SystemExit(f"bench.py: adjoint identity violated (rel err {adj_err:.3e}): results are wrong, no number reported")
+    if W.inprocess:
+        L.mxa_multi_reset_profile(W.eng.obj)
+    dt = run_timed(W, step, sync, 0, args.steps)
+    launches, total_ms = kernel_profile(L)
+    adj_err = adjoint_check(W)
     flops_step = 2 * 2.0 * snps * indiv * n
     value = flops_step * args.steps / dt * 1e-9
     ms_per_step = dt / args.steps * 1e3
     # dominant kernel: k_gemm; algorithmic flops per launch on one device = 2 * (SNPs of the shard) * indiv * n
-    flops_launch = 2.0 * snps_loc / n_shards * indiv * n
-    avg_ms = total_ms.value / max(1, launches.value)
+    flops_launch = 2.0 * W.snps_loc / W.n_shards * indiv * n
+    avg_ms = total_ms / max(1, launches)
+    per_shard = None
+    if W.inprocess:
+        per_shard, _ = per_shard_report(W, mx, args, flops_launch)
+        slowest = max(s["avg_k_gemm_ms"] for s in per_shard["shards"])
+        avg_ms = slowest if slowest > 0 else avg_ms        # the roofline line quotes the SLOWEST shard's average launch
+        per_shard["note"] = ("operands per shard on the shard's own device (mxa_dgemm_compressed_multi, asynchronous): the partial sums of 'N' travel on copy "
+                             "streams and are added on the root device while the 'T' products of the same step run")
     achieved = flops_launch / (avg_ms * 1e-3) * 1e-12 if avg_ms > 0 else 0.0
 
-    # N > 1: what every rank's dominant kernel took, and what the all-reduce of the indiv x n result costs on its own (untimed
-    # extra pass), so that a scaling curve explains itself
+    # in-process N > 1, extra (never `value`): (i) the same steps with the RCCL reduction (its first product is cross-checked against the
+    # peer-to-peer one inside the library), (ii) the hub variant: all of B / C on the first device through the plain dgemm_compressed symbol
+    extra_multi = None
+    if W.inprocess:
+        extra_multi = {}
+        if dg.multi_set_reduction(W.eng.obj, "rccl"):
+            L.mxa_multi_reset_profile(W.eng.obj)
+            dt_r = run_timed(W, step, sync, 1, args.steps)
+            rep_r, info_r = per_shard_report(W, mx, args, flops_launch)
+            adjoint_check(W)
+            extra_multi["rccl_reduction"] = {"value": round(flops_step * args.steps / dt_r * 1e-9, 1), "unit": "GFLOP/s", "ms_per_step": round(dt_r / args.steps * 1e3, 3),
+                                             "rccl_vs_p2p_max_rel_diff": info_r["rccl_vs_p2p_max_rel_diff"], "rccl_checked": bool(info_r["rccl_checked"]),
+                                             "avg_ncclReduce_ms_on_root_rank": rep_r["shards"][0]["avg_push_ms"]}
+            dg.multi_set_reduction(W.eng.obj, "p2p")
+        else:
+            extra_multi["rccl_reduction"] = {"skipped": "several shards share a device (RCCL needs one rank per device)"}
+        hub_step, hub_sync = make_step_and_sync(W, mx, hub=True)
+        hub_steps = max(1, min(args.steps, 5))
+        L.mxa_multi_reset_profile(W.eng.obj)
+        dt_h = run_timed(W, hub_step, hub_sync, 1, hub_steps)
+        rep_h, _ = per_shard_report(W, mx, args, flops_launch)
+        extra_multi["hub_operands_on_first_device"] = {"value": round(flops_step * hub_steps / dt_h * 1e-9, 1), "unit": "GFLOP/s", "ms_per_step": round(dt_h / hub_steps * 1e3, 3),
+                                                       "steps": hub_steps, "avg_copy_in_ms_per_shard": [s["avg_copy_in_ms"] for s in rep_h["shards"]],
+                                                       "avg_copy_out_ms_per_shard": [s["avg_copy_out_ms"] for s in rep_h["shards"]],
+                                                       "what": "B and C whole on the first device, plain dgemm_compressed, synchronous calls: every shard copies its slice from / to that device"}
+        step(); sync()     # the per-shard results are current again for the legs below
+
+    # N > 1 under the launcher: what every rank's dominant kernel took, and what the all-reduce of the indiv x n result costs on its own
+    # (untimed extra pass), so that a scaling curve explains itself
     per_rank = None
     if dist.is_initialized():
-        km = torch.tensor([avg_ms], dtype=torch.float64, device=device)
+        km = torch.tensor([avg_ms], dtype=torch.float64, device=W.device)
         allk = [torch.zeros_like(km) for _ in range(dist.get_world_size())]
         dist.all_gather(allk, km)
-        flat = C_N.t()
+        flat = W.C_N.t()
         sync()
         t1 = time.perf_counter()
         for _ in range(10):
@@ -385,95 +696,133 @@ def main():
     # informational second pass, outside the timed region: the same steps with the opt-in int8 engine (exact 7 x 8-bit slicing of
     # B, include/miraculix_amd.h mxa_set_engine).  Reported beside the headline, never as `value`.
     alt = None
-    if not args.no_alt_engine:
-        C_N64, C_T64 = C_N.clone(), C_T.clone()
+    if not args.no_alt_engine and not W.inprocess:
+        C_N64, C_T64 = W.C_N.clone(), W.C_T.clone()
         L.mxa_set_engine(1)
         step(); sync()
         L.mxa_profile_reset()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync()
-        dt8 = time.perf_counter() - t1
-        la8, ms8 = ctypes.c_int(0), ctypes.c_double(0.0)
-        L.mxa_profile_get(ctypes.byref(la8), ctypes.byref(ms8))
+        dt8 = run_timed(W, step, sync, 0, args.steps)
+        la8, ms8 = kernel_profile(L)
         L.mxa_set_engine(0)
-        if dist.is_initialized():
-            t = torch.tensor([dt8], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt8 = float(t.item())
-        dN = float(((C_N - C_N64).abs().amax(dim=0) / C_N64.abs().amax(dim=0)).max())
-        dT = float(((C_T - C_T64).abs().amax(dim=0) / C_T64.abs().amax(dim=0)).max())
+        dN = float(((W.C_N - C_N64).abs().amax(dim=0) / C_N64.abs().amax(dim=0)).max())
+        dT = float(((W.C_T - C_T64).abs().amax(dim=0) / C_T64.abs().amax(dim=0)).max())
         alt = {"engine": "i8: B split exactly into 7 radix-256 digits per column, v_mfma_i32_32x32x32_i8, exact int32 sums, fp64 recombination",
                "value": round(flops_step * args.steps / dt8 * 1e-9, 1), "unit": "GFLOP/s (fp64-equivalent: same 2*snps*indiv*ncol count)",
-               "ms_per_step": round(dt8 / args.steps * 1e3, 3), "avg_kernel_ms": round(ms8.value / max(1, la8.value), 3),
-               "int8_ops_per_s_P": round(2.0 * snps_loc / n_shards * indiv * n * 7 / (ms8.value / max(1, la8.value) * 1e-3) * 1e-15, 3),
+               "ms_per_step": round(dt8 / args.steps * 1e3, 3), "avg_kernel_ms": round(ms8 / max(1, la8), 3),
+               "int8_ops_per_s_P": round(2.0 * W.snps_loc / W.n_shards * indiv * n * 7 / (ms8 / max(1, la8) * 1e-3) * 1e-15, 3),
                "max_colwise_rel_diff_vs_f64_engine": max(dN, dT)}
-        C_N.copy_(C_N64); C_T.copy_(C_T64)
+        W.C_N.copy_(C_N64); W.C_T.copy_(C_T64)
         del C_N64, C_T64
 
     # ABI end-to-end (reference harness utils/benchmark/benchmark.f90:192-209): the same two products with HOST
     # B and C through the plain reference symbol dgemm_compressed -- what a Julia / Fortran caller sees, PCIe included.
     # 1 warm-up + 10 repetitions, mean and min.  Never `value`.
     abi = None
-    if world == 1 and not args.no_abi:
+    if W.world == 1 and not args.no_abi:
         import numpy as np
-        hB_N, hB_T = np.asfortranarray(B_N.cpu().numpy()), np.asfortranarray(B_T.cpu().numpy())
+        hB_N, hB_T = np.asfortranarray(W.B_N.cpu().numpy()), np.asfortranarray(W.B_T.cpu().numpy())
         hC_N, hC_T = np.zeros((indiv, n), order="F"), np.zeros((snps, n), order="F")
-        dg = mx.dgemm_compressed
 
         def abi_step():
-            dg.dgemm_compressed_main(False, eng.obj, hB_N, snps, indiv, out=hC_N)
-            dg.dgemm_compressed_main(True, eng.obj, hB_T, snps, indiv, out=hC_T)
+            dg.dgemm_compressed_main(False, W.eng.obj, hB_N, snps, indiv, out=hC_N)
+            dg.dgemm_compressed_main(True, W.eng.obj, hB_T, snps, indiv, out=hC_T)
         abi_step()
         ts = []
         for _ in range(10):
             t1 = time.perf_counter()
             abi_step()
             ts.append(time.perf_counter() - t1)
-        same = bool(np.array_equal(hC_N, C_N.cpu().numpy()) and np.array_equal(hC_T, C_T.cpu().numpy()))
+        dev_T = np.concatenate([c.cpu().numpy() for c in W.CT_s]) if W.inprocess else W.C_T.cpu().numpy()
+        same = bool(np.array_equal(hC_N, W.C_N.cpu().numpy()) and np.array_equal(hC_T, dev_T))
         abi = {"what": "dgemm_compressed 'N' + 'T' with host (pageable) B and C, PCIe transfers inside the call; 1 warm-up + 10 repetitions",
                "mean_GFLOPs": round(flops_step / (sum(ts) / len(ts)) * 1e-9, 1), "max_GFLOPs": round(flops_step / min(ts) * 1e-9, 1),
                "mean_ms_per_step": round(sum(ts) / len(ts) * 1e3, 3), "min_ms_per_step": round(min(ts) * 1e3, 3),
                "host_bytes_per_step": int(8 * 2 * (snps + indiv) * n), "bitwise_equal_to_device_resident_results": same}
-        del hB_N, hB_T, hC_N, hC_T
+        del hB_N, hB_T, hC_N, hC_T, dev_T
 
-    if rank == 0:
+    out = None
+    if W.rank == 0:
         out = {
             "metric": "effective GFLOP/s for dgemm_compressed (2-bit SNP x fp64)",
-            "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": args.gpus if inprocess else world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": W.n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{snps} SNPs x {indiv} indiv, ncol={n}, dgemm_compressed 'N' + 'T' per step, "
-                                   f"{'centred' if args.centered else 'uncentred'}, SNP-sharded over {args.gpus if inprocess else world} GPU(s)"
-                                   + (" inside one process behind the C ABI (MIRACULIX_NUM_GPUS)" if inprocess else ""),
-                       "snps": snps, "indiv": indiv, "ncol": n, "parallelism": f"snp-shard{args.gpus if inprocess else world}",
+                                   f"{'centred' if args.centered else 'uncentred'}, SNP-sharded over {W.n_gpus} GPU(s)"
+                                   + (" inside one process behind the C ABI (MIRACULIX_NUM_GPUS), operands per shard on the shards' devices" if W.inprocess else ""),
+                       "snps": snps, "indiv": indiv, "ncol": n, "parallelism": f"snp-shard{W.n_gpus}",
                        "genotypes": "p_s ~ U(0.1, 0.6), g ~ Binomial(2, p_s), no missings; B ~ N(0, 1)"},
             "check": {"adjoint_identity_max_rel_err": adj_err, "adjoint_tolerance": 1e-10},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "GB per launch, measured by this run (two rocprofv3 --pmc child passes of the same workload)", "traffic_detail": traffic_detail,
-                         "algorithmic_bytes_per_launch_GB": round((snps_loc / n_shards * ((indiv + 3) // 4) + 8.0 * (snps_loc / n_shards + indiv) * n) / 1e9, 3),
-                         "kernel": "k_gemm<8,8> (v_mfma_f64_4x4x4_4b_f64)", "launches": launches.value, "avg_launch_ms": round(avg_ms, 3)},
+                         "algorithmic_bytes_per_launch_GB": round((W.snps_loc / W.n_shards * ((indiv + 3) // 4) + 8.0 * (W.snps_loc / W.n_shards + indiv) * n) / 1e9, 3),
+                         "kernel": "k_gemm<8,8> (v_mfma_f64_4x4x4_4b_f64)", "launches": launches, "avg_launch_ms": round(avg_ms, 3)},
         }
         if per_rank is not None:
             out["per_rank"] = per_rank
+        if per_shard is not None:
+            out["per_shard"] = per_shard
+            out.update(extra_multi)
         if alt is not None:
             out["opt_in_engine"] = alt
         if abi is not None:
             out["abi_end_to_end"] = abi
-        if keep_raw:   # CPU baseline + parity against the checker: rank 0 at N = 1 only
+        if W.keep_raw:   # CPU baseline + parity against the checker: rank 0 at N = 1 only
             def rows_of_plink_t(ii):
-                return plink_t[torch.from_numpy(ii).to(device)].cpu().numpy()
-            base, chk = cpu_baseline_and_check(torch, mx, plink, freq, snps, indiv, n, B_T, C_T, B_N, C_N, rows_of_plink_t)
+                return W.plink_t[torch.from_numpy(ii).to(W.device)].cpu().numpy()
+            base, chk = cpu_baseline_and_check(torch, mx, W.plink, W.freq, snps, indiv, n, W.B_T, W.C_T, W.B_N, W.C_N, rows_of_plink_t)
             out["cpu_baseline"] = base
             out["check"].update(chk)
             if not (chk["gpu_T_rows_vs_cpu_library_max_rel_err"] <= 1e-11 and chk["gpu_N_64_sampled_rows_vs_dense_oracle_max_rel_err"] <= 1e-11):
                 raise SystemExit(f"bench.py: GPU results differ from the checker ({chk}): no number reported")
+    # the headline object and its operands are released before the other configs are staged
+    W.eng.close()
+    for name in ("plink", "plink_t", "freq", "B_N", "B_T", "C_N", "C_T", "BN_s", "CT_s", "BT_s", "CN_list", "op"):
+        if hasattr(W, name):
+            delattr(W, name)
+    torch.cuda.empty_cache()
+
+    # ---- BASELINE configs 3, 4 (per-GPU shard) and 5 (per-GPU shard), N = 1 only, each under its own checker; never `value`
+    if W.rank == 0 and W.world == 1 and not W.inprocess and not args.no_configs:
+        sc = args.configs_scale
+        r = lambda x, q: x if sc == 1.0 else max(q, int(x * sc) // q * q)
+        legs = (("config5_cg_step", lambda: config5_cg_step_leg(torch, mx, L, W.device, r(250_000, 4), r(100_000, 4))),
+                ("config4_shard", lambda: config4_shard_leg(torch, mx, L, W.device, r(625_000, 4), r(200_000, 4))),
+                ("config3_crossprod", lambda: config3_crossprod_leg(torch, mx, L, W.device, r(500_000, 4), r(100_000, 256))))
+        for name, fn in legs:
+            t_leg = time.perf_counter()
+            try:
+                out[name] = fn()
+                out[name]["leg_wall_s"] = round(time.perf_counter() - t_leg, 1)
+            except Exception as ex:   # a leg must not take the headline number down: it reports its failure instead
+                out[name] = {"failed": f"{type(ex).__name__}: {ex}"}
+        dg.set_options(use_gpu=True, not_center=not args.centered, verbose=0)
+        bad = [k for k in ("config5_cg_step", "config4_shard", "config3_crossprod") if not leg_checks_ok(out[k])]
+        if bad:
+            raise SystemExit(f"bench.py: parity check failed in {bad}: {json.dumps({k: out[k] for k in bad})}")
+    if W.rank == 0:
         print(json.dumps(out), flush=True)
-    eng.close()
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def leg_checks_ok(leg):
+    if "failed" in leg:
+        return False
+    ok = True
+
+    def walk(d):
+        nonlocal ok
+        for k, v in d.items():
+            if isinstance(v, dict):
+                walk(v)
+            elif k.endswith("max_rel_err"):
+                ok &= v <= 1e-11
+            elif k.startswith("four_256") or k.startswith("first_panel") or k.startswith("gram_matvec_bitwise"):
+                ok &= bool(v)
+    walk(leg)
+    return ok
 
 
 if __name__ == "__main__":

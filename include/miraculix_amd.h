@@ -176,7 +176,10 @@ int mxa_bed2compressed_range(const char *bed_path, int snps, int indiv, int snp_
  * operands travel over every GPU's own PCIe link side by side) and sum-reduces the indiv x n partials onto the first device --
  * by default with peer-to-peer pushes over xGMI and ONE addition kernel in ascending block order (bitwise reproducible),
  * with MXA_REDUCE=rccl by ncclReduce (RCCL is dlopen()ed; needs distinct devices); 'T' writes disjoint row blocks, no exchange.
- * B / C may be host memory or memory of any of the devices.  mxa_dgemm_compressed_device is not available on such a handle.
+ * B / C may be host memory or memory of any of the devices (work the caller enqueued on that device's default stream is waited for
+ * first).  mxa_dgemm_compressed_device is not available on such a handle; mxa_dgemm_compressed_multi (below) takes per-device operand slices.
+ * Peer access between the devices is enabled at creation and the verdicts are logged (PRINT_LEVEL > 0) and reported by mxa_multi_shard_info.
+ * NOT YET MEASURED on more than one physical GPU: all of it runs in the tests with several shards on one device.
  * snp_multiply_gpu with host operands follows the same variable: device g computes the column panel [c_g, c_g+1) of the symmetric result (equal
  * numbers of 256-column tiles = equal work), staging the packed matrix itself, and downloads it over its own PCIe link into its slab of the host
  * matrix -- independent units, no exchange; bit-identical to the single-device result.
@@ -184,6 +187,50 @@ int mxa_bed2compressed_range(const char *bed_path, int snps, int indiv, int snp_
  * partition of `snps` into `shards` blocks; returns the number of non-empty blocks. */
 int mxa_num_shards(void *compressed);
 int mxa_shard_bounds(long snps, int shards, int g, long *begin, long *end);
+
+/* dgemm_compressed on a multi-device object with the operands handed over PER SHARD, so that nothing but the indiv x n partial sums
+ * crosses a device boundary (with ONE B / C pointer, as through dgemm_compressed, the device that holds them is a hub: every shard
+ * copies its slice from / to it).  Arrays of mxa_num_shards(compressed) pointers; block g = mxa_shard_bounds(snps, shards, g, ..):
+ *   'N': B_per_shard[g] = rows [begin_g, end_g) of B (leading dimension ldb), normally memory of shard g's device;
+ *        C_per_shard[0] receives the reduced indiv x n result (leading dimension ldc; memory of the first shard's device, of any other
+ *        device, or of the host); the other entries of C_per_shard are ignored.
+ *   'T': B_per_shard[g] = the whole indiv x n matrix B as shard g reads it (leading dimension ldb; a NULL entry g > 0 makes shard g read
+ *        B_per_shard[0] across devices); C_per_shard[g] = rows [begin_g, end_g) of C (leading dimension ldc >= end_g - begin_g; rows
+ *        beyond the block are not touched).
+ * sync == 0: the call returns when the work is enqueued (device operands only; a host operand makes the call synchronous).  Products
+ * issued back to back on one object are ordered like calls on one stream, but the transfers of an 'N' product's partial sums and their
+ * addition on the first device run BESIDE the next product ('T' of the same step) on copy streams.  mxa_multi_synchronize() waits for
+ * everything issued on the object.  Results are those of dgemm_compressed on the same object (same kernels, same fixed-order reduction).
+ * Reference counterpart of the need: src/cuda/dgemm_compressed_cuda.cu:251-252 (operands cross PCIe on every call).  Returns 0 / 1. */
+int mxa_dgemm_compressed_multi(char trans, void *compressed, int n, const double *const *B_per_shard, long ldb,
+                               double *const *C_per_shard, long ldc, int sync);
+int mxa_multi_synchronize(void *compressed);
+
+/* reduction of the 'N' partial sums on a multi-device object: 0 = peer-to-peer pushes + ONE addition kernel in ascending shard order
+ * (default; bitwise reproducible), 1 = RCCL ncclReduce (one rank per shard, all in this process; needs one device per shard).
+ * Returns 0, 1 (error) or 2 (RCCL not applicable: several shards share a device; the reduction is unchanged).  The FIRST RCCL reduction of
+ * an object is cross-checked: the same partial sums are also reduced peer-to-peer and the two results compared (<= 1e-13 of the largest
+ * entry, else the product fails with error 18); mxa_multi_get_info reports the difference. */
+int mxa_multi_set_reduction(void *compressed, int kind);
+
+/* what a multi-device object is made of and what it has done since mxa_multi_reset_profile (HIP events on the streams the work ran on) */
+typedef struct mxa_multi_info {
+  int shards, devices, root_device;
+  int reduction;                     /* 0 peer-to-peer fixed order, 1 RCCL */
+  int reductions; double reduce_ms;  /* addition kernel on the root device (RCCL: the ld-padded copy of the received sum) */
+  int rccl_checked; double rccl_vs_p2p_max_rel_diff;   /* -1 until an RCCL reduction has been cross-checked */
+} mxa_multi_info;
+typedef struct mxa_shard_info {
+  int device; long snp_begin, snp_end;
+  int peer_to_root, peer_from_root;          /* 1 peer access enabled (direct xGMI), 0 not available (copies are staged through the host), -1 same device */
+  int kernel_launches; double kernel_ms;     /* dominant kernel of this shard's products */
+  int in_copies; double in_ms;               /* operand distribution: copies of a B that did not live on this shard's device */
+  int out_copies; double out_ms;             /* result gather: copies of a 'T' row block to a C that did not live on this shard's device */
+  int pushes; double push_ms;                /* partial sums pushed to the root device (RCCL: shard 0 = the ncclReduce) */
+} mxa_shard_info;
+int mxa_multi_get_info(void *compressed, mxa_multi_info *out);
+int mxa_multi_shard_info(void *compressed, int shard, mxa_shard_info *out);
+int mxa_multi_reset_profile(void *compressed);
 
 /* Output-tile sharding of the crossproduct for one-process-per-GPU use (packed matrix replicated, independent
  * units, no collective): columns [col_begin, col_end) of the symmetric result of snp_multiply_gpu, i.e. the contiguous slab

@@ -144,10 +144,8 @@ static int stage_matrix(PackedMatrix &M, const uint8_t *src, size_t src_pitch, l
     int cur = 0;
     MXA_HIP(hipGetDevice(&cur));
     if (src_dev != cur) {   // the recode kernel reads the other GPU's memory over xGMI
-      int can = 0;
-      if (hipDeviceCanAccessPeer(&can, cur, src_dev) != hipSuccess) { (void)hipGetLastError(); can = 0; }
-      if (!can) { set_error(15, "plink2compressed: device %d cannot read the source matrix in the memory of device %d (no peer access)", cur, src_dev); return 1; }
-      if (hipDeviceEnablePeerAccess(src_dev, 0) != hipSuccess) (void)hipGetLastError();
+      if (!enable_peer(cur, src_dev)) { set_error(15, "plink2compressed: device %d cannot read the source matrix in the memory of device %d (peer access not available or could not be enabled)", cur, src_dev); return 1; }
+      if (sync_foreign_producer(src_dev)) return 1;   // the matrix may still be being written by work on the source device's default stream
     }
     if (launch_recode(src, src_pitch, 0, rows, k, 0, M, s)) return 1;
     MXA_HIP(hipStreamSynchronize(s));
@@ -184,8 +182,7 @@ void destroy_handle(Handle *h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void *ptrs[] = {h->snp_major.d, h->ind_major.d, h->d_f, h->ws.d_Bstage, h->ws.d_Cstage, h->ws.d_Bp, h->ws.d_P, h->ws.d_colpart, h->ws.d_i8, h->ws.d_tmp, h->ws.d_exp, h->ws.d_denflag};
   for (void *p : ptrs) if (p) (void)hipFree(p);
-  if (h->ev0) (void)hipEventDestroy(h->ev0);
-  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  for (hipEvent_t e : {h->ev0[0], h->ev0[1], h->ev1[0], h->ev1[1], h->ev_in[0], h->ev_in[1], h->ev_out[0], h->ev_out[1]}) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->pev) if (e) (void)hipEventDestroy(e);
   for (hipStream_t ps : h->pipe) if (ps) (void)hipStreamDestroy(ps);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -290,14 +287,54 @@ static hipError_t copy_columns(void *dst, size_t dpitch, const void *src, size_t
 }
 
 // ------------------------------------------------------------------------------------------------ multiply
-void harvest_profile(Handle *h) {
-  if (!h || !h->prof_pending) return;
-  h->prof_pending = false;
-  if (hipEventSynchronize(h->ev1) != hipSuccess) { (void)hipGetLastError(); return; }
+static bool elapsed_ms(hipEvent_t a, hipEvent_t b, float *ms) {
+  if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(ms, a, b) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return true;
+}
+static void harvest_slot(Handle *h, int slot) {
+  if (!h->prof_pending[slot]) return;
+  h->prof_pending[slot] = false;
   float ms = 0.f;
-  if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) { (void)hipGetLastError(); return; }
+  if (!elapsed_ms(h->ev0[slot], h->ev1[slot], &ms)) return;
   std::lock_guard<std::mutex> lk(g_prof_mutex);
   profile().launches += 1; profile().total_ms += ms;
+  h->prof.launches += 1; h->prof.kernel_ms += ms;
+}
+static void harvest_copies(Handle *h) {
+  float ms = 0.f;
+  if (h->in_pending) { h->in_pending = false; if (elapsed_ms(h->ev_in[0], h->ev_in[1], &ms)) { h->prof.in_copies += 1; h->prof.in_ms += ms; } }
+  if (h->out_pending) { h->out_pending = false; if (elapsed_ms(h->ev_out[0], h->ev_out[1], &ms)) { h->prof.out_copies += 1; h->prof.out_ms += ms; } }
+}
+void harvest_profile(Handle *h) {
+  if (!h) return;
+  harvest_slot(h, 0); harvest_slot(h, 1);
+  harvest_copies(h);
+}
+
+int sync_foreign_producer(int src_dev) {
+  int cur = 0;
+  MXA_HIP(hipGetDevice(&cur));
+  if (src_dev < 0 || src_dev == cur) return 0;
+  MXA_HIP(hipSetDevice(src_dev));
+  const hipError_t e = hipStreamSynchronize(nullptr);
+  MXA_HIP(hipSetDevice(cur));
+  MXA_HIP(e);
+  return 0;
+}
+
+int enable_peer(int cur, int peer) {
+  if (cur == peer) return 1;
+  int prev = 0, can = 0;
+  if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (hipSetDevice(cur) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (hipDeviceCanAccessPeer(&can, cur, peer) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+  if (can) {
+    const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+    if (e != hipSuccess) (void)hipGetLastError();
+    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0;
+  }
+  (void)hipSetDevice(prev);
+  return can;
 }
 
 // Device operands only; asynchronous on s.  With timing, ev0/ev1 bracket the dominant kernel and harvest_profile() reads them later.
@@ -311,13 +348,18 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   if (n > 65535) { set_error(7, "dgemm_compressed: n = %d exceeds the supported 65535 columns per call", n); return 1; }
   if (n > h->max_n) { h->max_n = n; }
   if (ensure_workspace(h, n)) return 1;
-  harvest_profile(h);   // a previous asynchronous call's events are reused below
   Workspace &w = h->ws;
   double *d_sumB = w.d_colpart + (size_t)n * 128, *d_sumfB = d_sumB + n;
   static const int mode = [] { const char *e = getenv("MXA_GEMM_MODE"); return e ? atoi(e) : 2; }();
   const int engine = g_engine.load();
   const bool prof = g_profile_on && timing;
-  if (prof && !h->ev0) { MXA_HIP(hipEventCreate(&h->ev0)); MXA_HIP(hipEventCreate(&h->ev1)); }
+  const int slot = h->prof_slot;
+  if (prof) {
+    if (!h->ev0[slot]) { MXA_HIP(hipEventCreate(&h->ev0[slot])); MXA_HIP(hipEventCreate(&h->ev1[slot])); }
+    harvest_slot(h, slot);   // the pair of the product before last is read before it is recorded again
+    h->prof_slot = slot ^ 1;
+  }
+  hipEvent_t pe0 = prof ? h->ev0[slot] : nullptr, pe1 = prof ? h->ev1[slot] : nullptr;
   if (centered && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
   // Engine 0 at n <= 2 (the CG / GBLUP iteration, HBM-bound): the exact int8 slicing is used WHEN IT IS EXACT -- every column of B
   // finite with an exponent span that fits its 32 (n = 1) / 16 (n = 2) digits, checked on the device per call (gemm_i8_device,
@@ -330,7 +372,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     const int *d_flag = nullptr;
     // auto_i8: the verdict of the exactness check stays on the device (guard = 2) -- the int8 chain and the fp64 fallback are both enqueued and
     // test the flag themselves, so the product has no host round trip in its middle (44 us of a 1.2 ms product in the kernel timeline)
-    const int rc8 = gemm_i8_device(G, trans, n, dB, ldb, dC, ldc, fill_rows, centered, d_sumB, d_sumfB, h->d_f, w, s, prof ? h->ev0 : nullptr, prof ? h->ev1 : nullptr,
+    const int rc8 = gemm_i8_device(G, trans, n, dB, ldb, dC, ldc, fill_rows, centered, d_sumB, d_sumfB, h->d_f, w, s, pe0, pe1,
                                    &splits8, auto_i8 ? 2 : 0, &d_flag);
     if (rc8 == 0 || rc8 == 3) {
       if (rc8 == 3) {   // fp64 pair tables, run only if the flag is set
@@ -341,7 +383,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
       std::lock_guard<std::mutex> lk(g_prof_mutex);
       Geometry &geo = last_geometry();
       geo.m = m; geo.k = k; geo.n = n; geo.splits = splits8; geo.a = 0; geo.c = 0; geo.path = rc8 == 3 ? 4 : 2; geo.d_flag = d_flag; geo.flag_dev = h->device;
-      h->prof_pending = prof;
+      h->prof_pending[slot] = prof;
       return 0;
     }
     if (rc8 != 2) return 1;   // 2: the host-checked guard declined (B not exactly representable): fp64 path below
@@ -382,9 +424,9 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     d_E = w.d_exp;
   }
   if (!use_lut && launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, d_E)) return 1;
-  if (prof) MXA_HIP(hipEventRecord(h->ev0, s));
+  if (prof) MXA_HIP(hipEventRecord(pe0, s));
   int rc = use_lut ? launch_lut(G, dB, ldb, n, w.d_P, p, s) : launch_gemm(G, w.d_Bp, w.d_P, p, mode, s);
-  if (prof && !rc) { MXA_HIP(hipEventRecord(h->ev1, s)); h->prof_pending = true; }
+  if (prof && !rc) { MXA_HIP(hipEventRecord(pe1, s)); h->prof_pending[slot] = true; }
   if (!rc && d_E) {   // fallback of the denormal-operand mode, run only when the guard raised the flag: unscaled B, two-instruction conversion
     rc = launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, nullptr, 0, -1, w.d_denflag);
     if (!rc) rc = launch_gemm(G, w.d_Bp, w.d_P, p, 0, s, 0, -1, w.d_denflag);
@@ -561,6 +603,7 @@ int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, double *C,
   int b_devno = -1, c_devno = -1;
   const bool b_local = ptr_location(B, &b_devno) == 1 && b_devno == h->device;
   const bool c_local = ptr_location(C, &c_devno) == 1 && c_devno == h->device;
+  if (b_devno >= 0 && !b_local && sync_foreign_producer(b_devno)) return 1;   // B may still be being produced on the other device's default stream
   if (sync && (b_devno < 0 || c_devno < 0)) {   // a host operand on a synchronous call: transfers hidden behind the product when they are large
     const int rcp = gemm_host_pipelined(h, trans, n, B, ldb, b_devno < 0, b_local, C, ldc, c_devno < 0, c_local, fill_rows);
     if (rcp != 2) return rcp;
@@ -568,10 +611,17 @@ int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, double *C,
   const double *dB = B; long dldb = ldb;
   double *dC = C; long dldc = ldc;
   Workspace &w = h->ws;
+  if (!b_local || !c_local) {
+    harvest_copies(h);
+    for (hipEvent_t *e : {&h->ev_in[0], &h->ev_in[1], &h->ev_out[0], &h->ev_out[1]}) if (!*e) MXA_HIP(hipEventCreate(e));
+  }
   if (!b_local) {   // host memory, or memory of another device (peer copy over xGMI): dense k x n copy into this device's staging buffer
     if (grow(&w.d_Bstage, &w.cap_Bstage, (size_t)k * n)) return 1;
+    MXA_HIP(hipEventRecord(h->ev_in[0], s));
     if (ldb == k) MXA_HIP(hipMemcpyAsync(w.d_Bstage, B, sizeof(double) * (size_t)k * n, hipMemcpyDefault, s));
     else MXA_HIP(copy_columns(w.d_Bstage, sizeof(double) * k, B, sizeof(double) * ldb, sizeof(double) * k, n, s));
+    MXA_HIP(hipEventRecord(h->ev_in[1], s));
+    h->in_pending = true;
     dB = w.d_Bstage; dldb = k;
   }
   if (!c_local) {
@@ -580,8 +630,11 @@ int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, double *C,
   }
   if (gemm_device(h, trans, n, dB, dldb, dC, dldc, fill_rows, s, timing)) return 1;
   if (!c_local) {
+    MXA_HIP(hipEventRecord(h->ev_out[0], s));
     if (ldc == fill_rows) MXA_HIP(hipMemcpyAsync(C, dC, sizeof(double) * (size_t)fill_rows * n, hipMemcpyDefault, s));
     else MXA_HIP(copy_columns(C, sizeof(double) * ldc, dC, sizeof(double) * fill_rows, sizeof(double) * fill_rows, n, s));
+    MXA_HIP(hipEventRecord(h->ev_out[1], s));
+    h->out_pending = true;
   }
   if (sync) { MXA_HIP(hipStreamSynchronize(s)); harvest_profile(h); }
   return 0;
@@ -603,6 +656,7 @@ int gram_any(Handle *h, int n, const double *V, long ldv, double *out, long ldo,
   double *dO = out; long dldo = ldo;
   if (!v_local) {
     if (grow(&w.d_Bstage, &w.cap_Bstage, (size_t)std::max(snps, indiv) * n)) return 1;
+    if (v_devno >= 0 && sync_foreign_producer(v_devno)) return 1;
     if (ldv == indiv) MXA_HIP(hipMemcpyAsync(w.d_Bstage, V, sizeof(double) * (size_t)indiv * n, hipMemcpyDefault, s));
     else MXA_HIP(copy_columns(w.d_Bstage, sizeof(double) * indiv, V, sizeof(double) * ldv, sizeof(double) * indiv, n, s));
     dV = w.d_Bstage; dldv = indiv;
@@ -699,7 +753,7 @@ int mxa_dgemm_compressed_device(char trans, void *compressed, int n, const doubl
                                 int sync) {
   clear_error();
   const int t = trans_flag(&trans);
-  if (is_multi(compressed)) { set_error(16, "mxa_dgemm_compressed_device: not available on a multi-device object (MIRACULIX_NUM_GPUS > 1); use dgemm_compressed"); return 1; }
+  if (is_multi(compressed)) { set_error(16, "mxa_dgemm_compressed_device: not available on a multi-device object (MIRACULIX_NUM_GPUS > 1); use dgemm_compressed or mxa_dgemm_compressed_multi"); return 1; }
   Handle *h = as_handle(compressed, "mxa_dgemm_compressed_device");
   if (!h) return 1;
   if (n <= 0) return 0;

@@ -56,6 +56,14 @@ struct Workspace {
 constexpr uint32_t kMagic = 0x4d584131u;  // "MXA1"
 constexpr uint32_t kMagicMulti = 0x4d58414du;  // "MXAM": SNP-sharded object over several devices (mxa_multi.cpp)
 
+// what one object has done since the last reset: the dominant kernel (HIP events on the stream it ran on) and, when an operand did not
+// live on the object's device, the staging copies in (B) and out (C)
+struct ObjectProfile {
+  int launches = 0;  double kernel_ms = 0.0;
+  int in_copies = 0; double in_ms = 0.0;
+  int out_copies = 0; double out_ms = 0.0;
+};
+
 struct Handle {
   uint32_t magic = kMagic;
   int device = 0;
@@ -68,8 +76,14 @@ struct Handle {
   int max_n = 0;
   Workspace ws;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;   // timing of the dominant kernel (created once, not per call)
-  bool prof_pending = false;                 // ev0/ev1 were recorded by the last call and have not been read yet
+  // timing of the dominant kernel: two event pairs used alternately (created once, not per call), so that reading the pair of the product
+  // before last never waits for work that was just enqueued (asynchronous callers keep two products in flight)
+  hipEvent_t ev0[2] = {nullptr, nullptr}, ev1[2] = {nullptr, nullptr};
+  bool prof_pending[2] = {false, false};     // the pair was recorded and has not been read yet
+  int prof_slot = 0;                         // pair the next product records
+  hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};   // around the staging copies of a non-local B / C
+  bool in_pending = false, out_pending = false;
+  ObjectProfile prof;                        // per object, next to the process-wide profile()
   // host-operand pipeline (mxa_api.cpp: gemm_host_pipelined): two compute streams for alternating chunks, events per chunk
   hipStream_t pipe[2] = {nullptr, nullptr};
   hipEvent_t pev[18] = {};                   // [0] start, [1] operands ready, [2..9] upload of chunk c, [10..17] chunk c computed
@@ -100,6 +114,12 @@ int ptr_location(const void *p, int *dev);
 int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, double *C, long ldc, long fill_rows, bool sync, bool timing);
 int gram_any(Handle *h, int n, const double *V, long ldv, double *out, long ldo, bool sync);
 void harvest_profile(Handle *h);
+// B / V lives in the memory of device `src_dev` != the current one: whatever the caller enqueued on that device's default stream (the
+// producer of the operand, e.g. a PyTorch op) must be complete before another device's stream reads it -- a blocking stream orders
+// itself against the legacy default stream of ITS OWN device only.  Host-blocking; restores the current device.
+int sync_foreign_producer(int src_dev);
+// peer access cur -> peer: 1 enabled (now or before), 0 not available; errors other than "already enabled" are reported as 0
+int enable_peer(int cur, int peer);
 // called once by every shard worker thread: this thread issues transfers at the same time as other threads
 void mark_thread_concurrent();
 int select_device();                       // honours HIP_DEVICE / CUDA_DEVICE; -1 + error when no device

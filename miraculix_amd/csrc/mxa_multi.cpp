@@ -20,6 +20,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cmath>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -137,21 +138,39 @@ struct DeviceRestore {
   ~DeviceRestore() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+struct Shard {
+  Handle *h = nullptr;
+  long begin = 0, end = 0;                   // SNP block
+  Worker *worker = nullptr;                  // borrowed from worker_pool()
+  double *d_part = nullptr; size_t cap_part = 0;   // dense indiv x n partial on the shard's device
+  double *d_land = nullptr; size_t cap_land = 0;   // its landing buffer on the ROOT device (remote shards, peer-to-peer mode; RCCL: shard 0 = receive buffer)
+  // copy stream on the shard's device (non-blocking): pushes the partial to the root / runs the shard's ncclReduce while the shard's own
+  // stream goes on with the next product (the 'T' product of the same step)
+  hipStream_t cs = nullptr;
+  hipEvent_t ev_part = nullptr;              // shard stream: the partial is complete
+  hipEvent_t ev_pushed = nullptr;            // copy stream: the partial has landed on the root
+  hipEvent_t ev_push0 = nullptr, ev_push1 = nullptr;   // timing of the push (or of ncclReduce on shard 0's copy stream)
+  bool push_pending = false;
+  int pushes = 0; double push_ms = 0.0;
+  int peer_to_root = -1, peer_from_root = -1;
+};
+
 struct Multi {
   uint32_t magic = kMagicMulti;
   long snps = 0, indiv = 0;
-  int root = 0;                              // device that holds the reduced result
-  std::vector<Handle *> shard;
-  std::vector<long> begin, end;              // SNP block of every shard
-  std::vector<Worker *> worker;              // borrowed from worker_pool()
-  // per shard: dense indiv x n partial on the shard's device; on the root: one landing buffer per remote shard + the reduced result
-  std::vector<double *> d_part, d_land;
-  std::vector<size_t> cap_part, cap_land;
-  std::vector<hipEvent_t> ev_done;           // recorded on the shard's stream when its partial (or its copy on the root) is ready
-  double *d_red = nullptr; size_t cap_red = 0;
+  int root = 0;                              // device that holds the reduced result (device of shard 0)
+  std::vector<Shard> sh;
+  double *d_red = nullptr; size_t cap_red = 0;     // reduced result when C is not memory of the root device
+  double *d_chk = nullptr; size_t cap_chk = 0;     // RCCL cross-check: the same partials reduced peer-to-peer
   hipStream_t root_stream = nullptr;
-  bool use_rccl = false;
-  std::vector<void *> comm;                  // ncclComm_t per shard (use_rccl)
+  hipEvent_t ev_red0 = nullptr, ev_red1 = nullptr; // around the reduction kernel; ev_red1 doubles as "the previous reduction has read all partials"
+  bool red_recorded = false, red_pending = false;
+  int reductions = 0; double reduce_ms = 0.0;
+  bool use_rccl = false, rccl_checked = false;
+  double rccl_diff = -1.0;
+  std::vector<void *> comm;                  // ncclComm_t per shard (created on first use of the RCCL reduction)
+  bool distinct_devices = false;
+  int ndevices = 0;
 };
 
 Multi *as_multi(void *p) {
@@ -195,33 +214,66 @@ int pick_devices(int nshards, std::vector<int> &dev) {
   return 0;
 }
 
+// RCCL communicators: one rank per shard, all in this process (ncclCommInitAll); needs one device per shard
+int init_rccl(Multi *m) {
+  if (!m->comm.empty()) return 0;
+  const int G = (int)m->sh.size();
+  if (!m->distinct_devices) return 2;
+  if (!rccl().ok) { set_error(17, "RCCL reduction requested but librccl.so could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing"); return 1; }
+  std::vector<int> devs(G);
+  for (int g = 0; g < G; g++) devs[g] = m->sh[g].h->device;
+  m->comm.assign(G, nullptr);
+  const int rc = rccl().CommInitAll(m->comm.data(), G, devs.data());
+  if (rc != 0) { set_error(17, "ncclCommInitAll failed: %s", rccl().GetErrorString ? rccl().GetErrorString(rc) : "?"); m->comm.clear(); return 1; }
+  return 0;
+}
+
 int finish_setup(Multi *m) {
-  const int G = (int)m->shard.size();
-  m->root = m->shard[0]->device;
-  m->d_part.assign(G, nullptr); m->cap_part.assign(G, 0);
-  m->d_land.assign(G, nullptr); m->cap_land.assign(G, 0);
-  m->ev_done.assign(G, nullptr);
+  const int G = (int)m->sh.size();
+  m->root = m->sh[0].h->device;
+  m->distinct_devices = true;
+  std::vector<int> seen;
   for (int g = 0; g < G; g++) {
-    MXA_HIP(hipSetDevice(m->shard[g]->device));
-    MXA_HIP(hipEventCreateWithFlags(&m->ev_done[g], hipEventDisableTiming));
+    const int d = m->sh[g].h->device;
+    if (std::find(seen.begin(), seen.end(), d) != seen.end()) m->distinct_devices = false; else seen.push_back(d);
+  }
+  m->ndevices = (int)seen.size();
+  for (int g = 0; g < G; g++) {
+    Shard &S = m->sh[g];
+    MXA_HIP(hipSetDevice(S.h->device));
+    MXA_HIP(hipStreamCreateWithFlags(&S.cs, hipStreamNonBlocking));
+    MXA_HIP(hipEventCreateWithFlags(&S.ev_part, hipEventDisableTiming));
+    MXA_HIP(hipEventCreateWithFlags(&S.ev_pushed, hipEventDisableTiming));
+    MXA_HIP(hipEventCreate(&S.ev_push0));
+    MXA_HIP(hipEventCreate(&S.ev_push1));
+  }
+  // Peer access, explicit and recorded: root <-> every shard device (partials are pushed to the root, operands that live on one device are
+  // read from it) and between all shard devices (operands may live on any of them).  Without it hipMemcpyPeerAsync still works, but
+  // is staged through host memory instead of crossing xGMI directly.
+  for (int a : seen) for (int b : seen) if (a != b) (void)enable_peer(a, b);
+  std::string verdicts;
+  for (int g = 0; g < G; g++) {
+    Shard &S = m->sh[g];
+    const int d = S.h->device;
+    S.peer_to_root = d == m->root ? -1 : enable_peer(d, m->root);
+    S.peer_from_root = d == m->root ? -1 : enable_peer(m->root, d);
+    char buf[64];
+    snprintf(buf, sizeof(buf), " %d:dev%d(%d/%d)", g, d, S.peer_to_root, S.peer_from_root);
+    verdicts += buf;
   }
   MXA_HIP(hipSetDevice(m->root));
   MXA_HIP(hipStreamCreateWithFlags(&m->root_stream, hipStreamDefault));
+  MXA_HIP(hipEventCreate(&m->ev_red0));
+  MXA_HIP(hipEventCreate(&m->ev_red1));
   const char *red = getenv("MXA_REDUCE");
   if (red && std::string(red) == "rccl") {
-    bool distinct = true;
-    for (int g = 0; g < G; g++) for (int q = 0; q < g; q++) if (m->shard[g]->device == m->shard[q]->device) distinct = false;
-    if (!distinct) debug_info("MXA_REDUCE=rccl ignored: several shards share a device (RCCL needs one rank per device); using the peer-to-peer reduction");
-    else if (!rccl().ok) { set_error(17, "MXA_REDUCE=rccl: librccl.so could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing"); return 1; }
-    else {
-      std::vector<int> devs(G);
-      for (int g = 0; g < G; g++) devs[g] = m->shard[g]->device;
-      m->comm.assign(G, nullptr);
-      const int rc = rccl().CommInitAll(m->comm.data(), G, devs.data());
-      if (rc != 0) { set_error(17, "ncclCommInitAll failed: %s", rccl().GetErrorString ? rccl().GetErrorString(rc) : "?"); m->comm.clear(); return 1; }
-      m->use_rccl = true;
-    }
+    const int rc = init_rccl(m);
+    if (rc == 1) return 1;
+    if (rc == 2) debug_info("MXA_REDUCE=rccl ignored: several shards share a device (RCCL needs one rank per device); using the peer-to-peer reduction");
+    else m->use_rccl = true;
   }
+  debug_info("multi-device object: %d SNP shards on %d device(s), root device %d, reduction %s; shard:device(peer access to root / from root; -1 = same device):%s", G,
+             m->ndevices, m->root, m->use_rccl ? "RCCL ncclReduce" : "peer-to-peer, fixed order", verdicts.c_str());
   return 0;
 }
 
@@ -252,24 +304,31 @@ void multi_destroy(void *obj) {
   Multi *m = as_multi(obj);
   if (!m) return;
   DeviceRestore restore;
-  if (m->use_rccl) for (void *c : m->comm) if (c) (void)rccl().CommDestroy(c);
+  // everything in flight ends first (asynchronous products, pushes, the reduction)
+  for (Shard &S : m->sh) if (S.h) { (void)hipSetDevice(S.h->device); (void)hipStreamSynchronize(S.h->stream); if (S.cs) (void)hipStreamSynchronize(S.cs); }
+  if (m->root_stream) { (void)hipSetDevice(m->root); (void)hipStreamSynchronize(m->root_stream); }
+  for (void *c : m->comm) if (c) (void)rccl().CommDestroy(c);
   // every shard is released by the thread that worked on it
-  for (size_t g = 0; g < m->shard.size(); g++) {
-    if (!m->shard[g] || g >= m->worker.size()) continue;
-    m->worker[g]->submit([m, g] {
-      (void)hipSetDevice(m->shard[g]->device);
-      if (g < m->d_part.size() && m->d_part[g]) (void)hipFree(m->d_part[g]);
-      if (g < m->ev_done.size() && m->ev_done[g]) (void)hipEventDestroy(m->ev_done[g]);
-      destroy_handle(m->shard[g]);
+  for (Shard &S : m->sh) {
+    if (!S.h || !S.worker) continue;
+    Shard *sp = &S;
+    S.worker->submit([sp] {
+      (void)hipSetDevice(sp->h->device);
+      if (sp->d_part) (void)hipFree(sp->d_part);
+      for (hipEvent_t e : {sp->ev_part, sp->ev_pushed, sp->ev_push0, sp->ev_push1}) if (e) (void)hipEventDestroy(e);
+      if (sp->cs) (void)hipStreamDestroy(sp->cs);
+      destroy_handle(sp->h);
       return 0;
     });
   }
-  for (size_t g = 0; g < m->shard.size(); g++) if (m->shard[g] && g < m->worker.size()) (void)m->worker[g]->wait();
-  for (Worker *w : m->worker) worker_pool().give_back(w);   // idle: every job has been waited for
-  m->worker.clear();
+  for (Shard &S : m->sh) if (S.h && S.worker) (void)S.worker->wait();
+  for (Shard &S : m->sh) if (S.worker) { worker_pool().give_back(S.worker); S.worker = nullptr; }   // idle: every job has been waited for
   (void)hipSetDevice(m->root);
-  for (double *p : m->d_land) if (p) (void)hipFree(p);
+  for (Shard &S : m->sh) if (S.d_land) (void)hipFree(S.d_land);
   if (m->d_red) (void)hipFree(m->d_red);
+  if (m->d_chk) (void)hipFree(m->d_chk);
+  if (m->ev_red0) (void)hipEventDestroy(m->ev_red0);
+  if (m->ev_red1) (void)hipEventDestroy(m->ev_red1);
   if (m->root_stream) (void)hipStreamDestroy(m->root_stream);
   m->magic = 0;
   delete m;
@@ -282,32 +341,31 @@ static int multi_build(long snps, long indiv, int shards, void **out, const std:
   DeviceRestore restore;
   Multi *m = new Multi();
   m->snps = snps; m->indiv = indiv;
-  shard_blocks(snps, shards, m->begin, m->end);
-  const int G = (int)m->begin.size();
+  std::vector<long> b, e;
+  shard_blocks(snps, shards, b, e);
+  const int G = (int)b.size();
   std::vector<int> dev;
   if (pick_devices(G, dev)) { delete m; return 1; }
-  m->shard.assign(G, nullptr);
-  for (int g = 0; g < G; g++) m->worker.push_back(worker_pool().borrow());
+  m->sh.resize(G);
+  for (int g = 0; g < G; g++) { m->sh[g].begin = b[g]; m->sh[g].end = e[g]; m->sh[g].worker = worker_pool().borrow(); }
   // stage all shards side by side: every worker uploads over its own GPU's PCIe link
   for (int g = 0; g < G; g++) {
-    m->worker[g]->submit([&, g] {
+    m->sh[g].worker->submit([&, g] {
       void *h = nullptr;
-      const int rc = make(g, m->begin[g], m->end[g], dev[g], &h);
-      m->shard[g] = reinterpret_cast<Handle *>(h);
+      const int rc = make(g, m->sh[g].begin, m->sh[g].end, dev[g], &h);
+      m->sh[g].h = reinterpret_cast<Handle *>(h);
       return rc;
     });
   }
   int rc = 0;
-  for (int g = 0; g < G; g++) rc |= m->worker[g]->wait();
-  for (int g = 0; g < G && !rc; g++) if (!m->shard[g]) rc = 1;
+  for (int g = 0; g < G; g++) rc |= m->sh[g].worker->wait();
+  for (int g = 0; g < G && !rc; g++) if (!m->sh[g].h) rc = 1;
   if (!rc) rc = finish_setup(m);
   if (rc) {
-    // destroy what exists (multi_destroy needs shard[0] for the root device only when present)
-    if (m->shard[0]) m->root = m->shard[0]->device;
+    if (m->sh[0].h) m->root = m->sh[0].h->device;
     multi_destroy(m);
     return 1;
   }
-  debug_info("multi-device object: %d SNP shards over devices starting at %d, reduction %s", G, m->root, m->use_rccl ? "RCCL ncclReduce" : "peer-to-peer, fixed order");
   *out = m;
   return 0;
 }
@@ -331,104 +389,257 @@ int multi_create_from_bed(const char *base, long snps, long indiv, int max_n, in
 void multi_freq(void *obj, double *f) {
   Multi *m = as_multi(obj);
   if (!m) return;
-  for (size_t g = 0; g < m->shard.size(); g++) memcpy(f + m->begin[g], m->shard[g]->h_f, sizeof(double) * (size_t)(m->end[g] - m->begin[g]));
+  for (const Shard &S : m->sh) memcpy(f + S.begin, S.h->h_f, sizeof(double) * (size_t)(S.end - S.begin));
 }
 
-// reduce the shards' dense m x n partials (d_part[g], complete when ev_done[g] fires) into C (host or any device), ascending order
-static int multi_reduce(Multi *m, long rows, int n, double *C, long ldc) {
-  const int G = (int)m->shard.size();
+static void harvest_push(Shard &S) {
+  if (!S.push_pending) return;
+  S.push_pending = false;
+  float ms = 0.f;
+  if (hipEventSynchronize(S.ev_push1) != hipSuccess || hipEventElapsedTime(&ms, S.ev_push0, S.ev_push1) != hipSuccess) { (void)hipGetLastError(); return; }
+  S.pushes += 1; S.push_ms += ms;
+}
+static void harvest_reduce(Multi *m) {
+  if (!m->red_pending) return;
+  m->red_pending = false;
+  float ms = 0.f;
+  if (hipEventSynchronize(m->ev_red1) != hipSuccess || hipEventElapsedTime(&ms, m->ev_red0, m->ev_red1) != hipSuccess) { (void)hipGetLastError(); return; }
+  m->reductions += 1; m->reduce_ms += ms;
+}
+
+static int run_all(Multi *m, const std::function<int(int)> &job) {
+  const int G = (int)m->sh.size();
+  for (int g = 0; g < G; g++) m->sh[g].worker->submit([&job, g] { return job(g); });
+  int rc = 0;
+  for (int g = 0; g < G; g++) rc |= m->sh[g].worker->wait();
+  return rc;
+}
+
+static int prepare_partials(Multi *m, long rows, int n) {
+  for (Shard &S : m->sh) {
+    if (grow_on(S.h->device, &S.d_part, &S.cap_part, (size_t)rows * n)) return 1;
+    if (S.h->device != m->root && grow_on(m->root, &S.d_land, &S.cap_land, (size_t)rows * n)) return 1;   // also the scratch of the RCCL cross-check
+  }
+  if (m->use_rccl && grow_on(m->root, &m->sh[0].d_land, &m->sh[0].cap_land, (size_t)rows * n)) return 1;   // receive buffer of ncclReduce
+  return 0;
+}
+
+// Worker of shard g, after its product was enqueued on the shard's stream: mark the partial ready and (peer-to-peer mode, remote shard)
+// push it to the root over the shard's own xGMI link, on the COPY stream -- the shard's stream is free for the next product at once.
+static int publish_partial(Multi *m, int g, long rows, int n, bool push) {
+  Shard &S = m->sh[g];
+  Handle *h = S.h;
+  MXA_HIP(hipEventRecord(S.ev_part, h->stream));
+  if (push && h->device != m->root) {
+    harvest_push(S);
+    MXA_HIP(hipStreamWaitEvent(S.cs, S.ev_part, 0));
+    MXA_HIP(hipEventRecord(S.ev_push0, S.cs));
+    MXA_HIP(hipMemcpyPeerAsync(S.d_land, m->root, S.d_part, h->device, sizeof(double) * (size_t)rows * n, S.cs));
+    MXA_HIP(hipEventRecord(S.ev_push1, S.cs));
+    MXA_HIP(hipEventRecord(S.ev_pushed, S.cs));
+    S.push_pending = true;
+  }
+  return 0;
+}
+
+// peer-to-peer reduction of the published partials into dC (memory of the root device), ascending shard order, on the root stream
+static int reduce_p2p(Multi *m, long rows, int n, double *dC, long ldc, long fill_rows, bool timed) {
+  const int G = (int)m->sh.size();
+  MXA_HIP(hipSetDevice(m->root));
+  PartList pl{}; pl.count = G;
+  for (int g = 0; g < G; g++) {
+    Shard &S = m->sh[g];
+    const bool remote = S.h->device != m->root;
+    pl.p[g] = remote ? S.d_land : S.d_part;
+    MXA_HIP(hipStreamWaitEvent(m->root_stream, remote ? S.ev_pushed : S.ev_part, 0));
+  }
+  if (timed) { harvest_reduce(m); MXA_HIP(hipEventRecord(m->ev_red0, m->root_stream)); }
+  if (launch_reduce_parts(pl, rows, n, dC, ldc, fill_rows, m->root_stream)) return 1;
+  if (timed) { MXA_HIP(hipEventRecord(m->ev_red1, m->root_stream)); m->red_recorded = true; m->red_pending = true; }
+  return 0;
+}
+
+// ncclReduce of the partials onto shard 0's device: every rank's call is issued from this thread inside ONE group, each on its shard's copy
+// stream behind the event of its partial.  ncclGroupEnd is reached on every path (an open group would poison RCCL for the rest of the process).
+static int reduce_rccl(Multi *m, long rows, int n, double *dC, long ldc, long fill_rows) {
+  const int G = (int)m->sh.size();
+  Rccl &r = rccl();
+  Shard &S0 = m->sh[0];
+  harvest_push(S0);
+  hipError_t he = hipSuccess;
+  for (int g = 0; g < G && he == hipSuccess; g++) {
+    he = hipSetDevice(m->sh[g].h->device);
+    if (he == hipSuccess) he = hipStreamWaitEvent(m->sh[g].cs, m->sh[g].ev_part, 0);
+  }
+  if (he == hipSuccess) he = hipSetDevice(S0.h->device);
+  if (he == hipSuccess) he = hipEventRecord(S0.ev_push0, S0.cs);
+  MXA_HIP(he);
+  int rc = r.GroupStart();
+  if (!rc) {
+    for (int g = 0; g < G && !rc && he == hipSuccess; g++) {
+      he = hipSetDevice(m->sh[g].h->device);
+      if (he == hipSuccess) rc = r.Reduce(m->sh[g].d_part, g == 0 ? S0.d_land : nullptr, (size_t)rows * n, kNcclFloat64, kNcclSum, 0, m->comm[g], m->sh[g].cs);
+    }
+    const int rc_end = r.GroupEnd();   // always
+    if (!rc) rc = rc_end;
+  }
+  if (rc) { set_error(17, "ncclReduce failed: %s", r.GetErrorString ? r.GetErrorString(rc) : "?"); return 1; }
+  MXA_HIP(he);
+  MXA_HIP(hipSetDevice(m->root));
+  MXA_HIP(hipEventRecord(S0.ev_push1, S0.cs));
+  MXA_HIP(hipEventRecord(S0.ev_pushed, S0.cs));
+  S0.push_pending = true;
+  MXA_HIP(hipStreamWaitEvent(m->root_stream, S0.ev_pushed, 0));
+  harvest_reduce(m);
+  MXA_HIP(hipEventRecord(m->ev_red0, m->root_stream));
+  PartList pl{}; pl.count = 1; pl.p[0] = S0.d_land;
+  if (launch_reduce_parts(pl, rows, n, dC, ldc, fill_rows, m->root_stream)) return 1;
+  MXA_HIP(hipEventRecord(m->ev_red1, m->root_stream));
+  m->red_recorded = true; m->red_pending = true;
+  return 0;
+}
+
+// First RCCL reduction of an object: the same partials are also pushed peer-to-peer and added in fixed order, and the two sums are
+// compared on the host (<= 1e-13 of the largest entry; they differ only in the summation order).  This is the multi-rank evidence for
+// the grouped ncclReduce: a mismatch fails the call.
+static int rccl_cross_check(Multi *m, long rows, int n) {
+  const int G = (int)m->sh.size();
+  if (grow_on(m->root, &m->d_chk, &m->cap_chk, (size_t)rows * n)) return 1;
+  for (int g = 0; g < G; g++) {
+    Shard &S = m->sh[g];
+    if (S.h->device == m->root) continue;
+    MXA_HIP(hipSetDevice(S.h->device));
+    MXA_HIP(hipMemcpyPeerAsync(S.d_land, m->root, S.d_part, S.h->device, sizeof(double) * (size_t)rows * n, S.cs));
+    MXA_HIP(hipEventRecord(S.ev_pushed, S.cs));
+  }
+  if (reduce_p2p(m, rows, n, m->d_chk, rows, rows, false)) return 1;
+  MXA_HIP(hipStreamSynchronize(m->root_stream));
+  std::vector<double> a((size_t)rows * n), b((size_t)rows * n);
+  MXA_HIP(hipMemcpy(a.data(), m->sh[0].d_land, sizeof(double) * a.size(), hipMemcpyDeviceToHost));
+  MXA_HIP(hipMemcpy(b.data(), m->d_chk, sizeof(double) * b.size(), hipMemcpyDeviceToHost));
+  double dmax = 0.0, amax = 0.0;
+  bool bad = false;
+  for (size_t i = 0; i < a.size(); i++) {
+    if (a[i] != a[i] || b[i] != b[i]) { if ((a[i] != a[i]) != (b[i] != b[i])) bad = true; continue; }
+    dmax = std::max(dmax, std::fabs(a[i] - b[i])); amax = std::max(amax, std::fabs(b[i]));
+  }
+  m->rccl_diff = amax > 0.0 ? dmax / amax : dmax;
+  m->rccl_checked = true;
+  debug_info("RCCL reduction cross-checked against the peer-to-peer fixed-order reduction: max rel diff %.3e", m->rccl_diff);
+  if (bad || !(m->rccl_diff <= 1e-13)) {
+    set_error(18, "RCCL reduction disagrees with the peer-to-peer fixed-order reduction (max rel diff %.3e > 1e-13): results are not trusted", m->rccl_diff);
+    return 1;
+  }
+  return 0;
+}
+
+// reduce the shards' dense rows x n partials (d_part, complete when ev_part fires) into C (host or any device)
+static int multi_reduce(Multi *m, long rows, int n, double *C, long ldc, bool sync) {
   MXA_HIP(hipSetDevice(m->root));
   int c_devno = -1;
-  const bool c_local = ptr_location(C, &c_devno) == 1 && c_devno == m->root;
+  const bool c_dev = ptr_location(C, &c_devno) == 1, c_local = c_dev && c_devno == m->root;
   double *dC = C; long dldc = ldc;
   if (!c_local) {
     if (grow_on(m->root, &m->d_red, &m->cap_red, (size_t)ldc * n)) return 1;
     dC = m->d_red;
   }
   if (m->use_rccl) {
-    // ncclReduce into the root's landing buffer 0; every rank's call is issued from this thread inside one group
-    if (grow_on(m->root, &m->d_land[0], &m->cap_land[0], (size_t)rows * n)) return 1;
-    Rccl &r = rccl();
-    int rc = r.GroupStart();
-    for (int g = 0; g < G && !rc; g++) {
-      MXA_HIP(hipSetDevice(m->shard[g]->device));
-      rc = r.Reduce(m->d_part[g], g == 0 ? m->d_land[0] : nullptr, (size_t)rows * n, kNcclFloat64, kNcclSum, 0, m->comm[g], m->shard[g]->stream);
-    }
-    if (!rc) rc = r.GroupEnd();
-    if (rc) { set_error(17, "ncclReduce failed: %s", r.GetErrorString ? r.GetErrorString(rc) : "?"); return 1; }
-    MXA_HIP(hipSetDevice(m->root));
-    MXA_HIP(hipEventRecord(m->ev_done[0], m->shard[0]->stream));
-    MXA_HIP(hipStreamWaitEvent(m->root_stream, m->ev_done[0], 0));
-    PartList pl{}; pl.count = 1; pl.p[0] = m->d_land[0];
-    if (launch_reduce_parts(pl, rows, n, dC, dldc, ldc, m->root_stream)) return 1;
-  } else {
-    PartList pl{}; pl.count = G;
-    for (int g = 0; g < G; g++) {
-      pl.p[g] = m->shard[g]->device == m->root ? m->d_part[g] : m->d_land[g];
-      MXA_HIP(hipStreamWaitEvent(m->root_stream, m->ev_done[g], 0));
-    }
-    if (launch_reduce_parts(pl, rows, n, dC, dldc, ldc, m->root_stream)) return 1;
-  }
+    if (reduce_rccl(m, rows, n, dC, dldc, ldc)) return 1;
+    if (!m->rccl_checked && rccl_cross_check(m, rows, n)) return 1;
+  } else if (reduce_p2p(m, rows, n, dC, dldc, ldc, true)) return 1;
+  MXA_HIP(hipSetDevice(m->root));
   if (!c_local) MXA_HIP(hipMemcpyAsync(C, dC, sizeof(double) * (size_t)ldc * n, hipMemcpyDefault, m->root_stream));
+  if (sync || !c_dev) MXA_HIP(hipStreamSynchronize(m->root_stream));
+  return 0;
+}
+
+static void harvest_all(Multi *m) {
+  for (Shard &S : m->sh) { (void)hipSetDevice(S.h->device); harvest_profile(S.h); harvest_push(S); }
+  (void)hipSetDevice(m->root);
+  harvest_reduce(m);
+}
+
+int multi_synchronize(void *obj) {
+  Multi *m = as_multi(obj);
+  if (!m) { set_error(2, "mxa_multi_synchronize: not a multi-device object"); return 1; }
+  DeviceRestore restore;
+  for (Shard &S : m->sh) { MXA_HIP(hipSetDevice(S.h->device)); MXA_HIP(hipStreamSynchronize(S.h->stream)); MXA_HIP(hipStreamSynchronize(S.cs)); }
+  MXA_HIP(hipSetDevice(m->root));
   MXA_HIP(hipStreamSynchronize(m->root_stream));
+  harvest_all(m);
   return 0;
 }
 
-// after the shard's product: push the partial to the root (peer-to-peer mode, remote shard) and mark it ready
-static int publish_partial(Multi *m, int g, long rows, int n) {
-  Handle *h = m->shard[g];
-  if (!m->use_rccl && h->device != m->root)
-    MXA_HIP(hipMemcpyPeerAsync(m->d_land[g], m->root, m->d_part[g], h->device, sizeof(double) * (size_t)rows * n, h->stream));
-  MXA_HIP(hipEventRecord(m->ev_done[g], h->stream));
-  return 0;
-}
-
-static int prepare_partials(Multi *m, long rows, int n) {
-  const int G = (int)m->shard.size();
-  for (int g = 0; g < G; g++) {
-    if (grow_on(m->shard[g]->device, &m->d_part[g], &m->cap_part[g], (size_t)rows * n)) return 1;
-    if (!m->use_rccl && m->shard[g]->device != m->root && grow_on(m->root, &m->d_land[g], &m->cap_land[g], (size_t)rows * n)) return 1;
+// One product on a multi-device object.  Operands either as ONE pointer each (the plain ABI: B / C host memory or memory of any device) or
+// per shard (Bs / Cs: shard g's own slice, normally memory of shard g's device -- nothing crosses a device boundary but the partials):
+//   'N': Bs[g] = rows [begin_g, end_g) of B (ld ldb);  the reduced result goes to Cs[0] (ld ldc; memory of any device or host)
+//   'T': Bs[g] = the whole B (indiv x n, ld ldb) as shard g sees it (a NULL entry: Bs[0] is read across devices);  Cs[g] = rows
+//        [begin_g, end_g) of C (ld ldc)
+// sync == 0 (device operands only): returns when everything is enqueued -- the next product may be issued at once (the 'T' product of a step
+// then runs on the shard streams while the partials of 'N' travel and are added on the root); mxa_multi_synchronize() waits.
+static int multi_product(Multi *m, bool trans, int n, const double *B, const double *const *Bs, long ldb, double *C, double *const *Cs, long ldc, bool sync) {
+  if (n <= 0) return 0;
+  DeviceRestore restore;
+  const long snps = m->snps, indiv = m->indiv;
+  const int G = (int)m->sh.size();
+  const bool per_shard = Bs != nullptr;
+  if (per_shard) {
+    if (!Cs || !Bs[0] || !Cs[0]) { set_error(1, "mxa_dgemm_compressed_multi: B_per_shard[0] and C_per_shard[0] must not be NULL"); return 1; }
+    for (int g = 0; g < G; g++) if ((trans && !Cs[g]) || (!trans && !Bs[g])) { set_error(1, "mxa_dgemm_compressed_multi: shard %d has no %s slice", g, trans ? "C" : "B"); return 1; }
+  } else if (!B || !C) { set_error(1, "dgemm_compressed: B and C must not be NULL"); return 1; }
+  const long k_all = trans ? indiv : snps, m_all = trans ? snps : indiv;
+  if (!per_shard && (ldb < k_all || ldc < m_all)) { set_error(7, "dgemm_compressed: leading dimension too small (ldb %ld < %ld or ldc %ld < %ld)", ldb, k_all, ldc, m_all); return 1; }
+  int rc;
+  if (trans) {
+    // C (snps x n): shard g owns rows [begin_g, end_g); with ONE C the last shard also zero-fills the ld padding rows [snps, ldc)
+    rc = run_all(m, [&](int g) {
+      Shard &S = m->sh[g];
+      const long rows = S.end - S.begin;
+      const double *Bg = per_shard ? (Bs[g] ? Bs[g] : Bs[0]) : B;
+      double *Cg = per_shard ? Cs[g] : C + S.begin;
+      const long fill = per_shard ? rows : (g == G - 1 ? ldc - S.begin : rows);
+      const bool host_op = ptr_location(Bg, nullptr) == 0 || ptr_location(Cg, nullptr) == 0;
+      if (gemm_any(S.h, true, n, Bg, ldb, Cg, ldc, fill, sync || host_op, true)) return 1;
+      return 0;
+    });
+  } else {
+    if (prepare_partials(m, indiv, n)) return 1;
+    rc = run_all(m, [&](int g) {
+      Shard &S = m->sh[g];
+      MXA_HIP(hipSetDevice(S.h->device));
+      // the previous reduction has read this shard's partial (and its landing buffer) before the product overwrites it
+      if (m->red_recorded) MXA_HIP(hipStreamWaitEvent(S.h->stream, m->ev_red1, 0));
+      const double *Bg = per_shard ? Bs[g] : B + S.begin;
+      // a host B: synchronous inside the shard's own worker thread, so that a big one is uploaded in K ranges behind the product (gemm_host_pipelined)
+      const bool host_op = ptr_location(Bg, nullptr) == 0;
+      if (gemm_any(S.h, false, n, Bg, ldb, S.d_part, indiv, indiv, host_op, true)) return 1;
+      return publish_partial(m, g, indiv, n, !m->use_rccl);
+    });
+    if (!rc) rc = multi_reduce(m, indiv, n, per_shard ? Cs[0] : C, ldc, sync);
   }
-  return 0;
-}
-
-static int run_all(Multi *m, const std::function<int(int)> &job) {
-  const int G = (int)m->shard.size();
-  for (int g = 0; g < G; g++) m->worker[g]->submit([&job, g] { return job(g); });
-  int rc = 0;
-  for (int g = 0; g < G; g++) rc |= m->worker[g]->wait();
+  if (sync && !rc) {
+    for (Shard &S : m->sh) { MXA_HIP(hipSetDevice(S.h->device)); MXA_HIP(hipStreamSynchronize(S.h->stream)); }
+    harvest_all(m);
+  }
   return rc;
 }
 
 int multi_gemm(void *obj, bool trans, int n, const double *B, long ldb, double *C, long ldc) {
   Multi *m = as_multi(obj);
   if (!m) { set_error(2, "dgemm_compressed: invalid or uninitialised compressed object"); return 1; }
-  if (n <= 0) return 0;
-  DeviceRestore restore;
-  if (!B || !C) { set_error(1, "dgemm_compressed: B and C must not be NULL"); return 1; }
-  const long snps = m->snps, indiv = m->indiv;
-  const int G = (int)m->shard.size();
-  int rc;
-  if (trans) {
-    // C (snps x n): shard g owns rows [begin_g, end_g); the last shard also zero-fills the ld padding rows [snps, ldc)
-    if (ldb < indiv || ldc < snps) { set_error(7, "dgemm_compressed: leading dimension too small (ldb %ld < %ld or ldc %ld < %ld)", ldb, indiv, ldc, snps); return 1; }
-    rc = run_all(m, [&](int g) {
-      const long rows = m->end[g] - m->begin[g];
-      const long fill = g == G - 1 ? ldc - m->begin[g] : rows;
-      return gemm_any(m->shard[g], true, n, B, ldb, C + m->begin[g], ldc, fill, true, true);
-    });
-  } else {
-    if (ldb < snps || ldc < indiv) { set_error(7, "dgemm_compressed: leading dimension too small (ldb %ld < %ld or ldc %ld < %ld)", ldb, snps, ldc, indiv); return 1; }
-    if (prepare_partials(m, indiv, n)) return 1;
-    rc = run_all(m, [&](int g) {
-      // synchronous inside the shard's own worker thread: a big host B is then uploaded in K ranges behind the product (gemm_host_pipelined)
-      if (gemm_any(m->shard[g], false, n, B + m->begin[g], ldb, m->d_part[g], indiv, indiv, true, true)) return 1;
-      return publish_partial(m, g, indiv, n);
-    });
-    if (!rc) rc = multi_reduce(m, indiv, n, C, ldc);
-    for (int g = 0; g < G; g++) { (void)hipSetDevice(m->shard[g]->device); (void)hipStreamSynchronize(m->shard[g]->stream); harvest_profile(m->shard[g]); }
+  return multi_product(m, trans, n, B, nullptr, ldb, C, nullptr, ldc, true);
+}
+
+int multi_gemm_slices(void *obj, bool trans, int n, const double *const *Bs, long ldb, double *const *Cs, long ldc, bool sync) {
+  Multi *m = as_multi(obj);
+  if (!m) { set_error(2, "mxa_dgemm_compressed_multi: not a multi-device object (create it under MIRACULIX_NUM_GPUS > 1)"); return 1; }
+  if (!Bs || !Cs) { set_error(1, "mxa_dgemm_compressed_multi: the per-shard pointer arrays must not be NULL"); return 1; }
+  if (!sync) {   // asynchronous only with device operands
+    const int G = (int)m->sh.size();
+    for (int g = 0; g < G; g++)
+      if ((Bs[g] && ptr_location(Bs[g], nullptr) == 0) || (Cs[g] && (trans || g == 0) && ptr_location(Cs[g], nullptr) == 0)) sync = true;
   }
-  return rc;
+  return multi_product(m, trans, n, nullptr, Bs, ldb, nullptr, Cs, ldc, sync);
 }
 
 // out (indiv x n) = sum_g Zc_g (Zc_g^T V): every shard keeps its snps_g x n intermediate on its own device; one reduction
@@ -442,15 +653,34 @@ int multi_gram(void *obj, int n, const double *V, long ldv, double *out, long ld
   if (ldv < indiv || ldo < indiv) { set_error(7, "mxa_gram_matvec: leading dimension too small (ldv %ld, ldo %ld < %ld)", ldv, ldo, indiv); return 1; }
   if (prepare_partials(m, indiv, n)) return 1;
   int rc = run_all(m, [&](int g) {
-    if (gram_any(m->shard[g], n, V, ldv, m->d_part[g], indiv, false)) return 1;
-    return publish_partial(m, g, indiv, n);
+    Shard &S = m->sh[g];
+    MXA_HIP(hipSetDevice(S.h->device));
+    if (m->red_recorded) MXA_HIP(hipStreamWaitEvent(S.h->stream, m->ev_red1, 0));
+    if (gram_any(S.h, n, V, ldv, S.d_part, indiv, false)) return 1;
+    return publish_partial(m, g, indiv, n, !m->use_rccl);
   });
-  if (!rc) rc = multi_reduce(m, indiv, n, out, ldo);
-  for (size_t g = 0; g < m->shard.size(); g++) { (void)hipSetDevice(m->shard[g]->device); (void)hipStreamSynchronize(m->shard[g]->stream); }
+  if (!rc) rc = multi_reduce(m, indiv, n, out, ldo, true);
+  for (Shard &S : m->sh) { (void)hipSetDevice(S.h->device); (void)hipStreamSynchronize(S.h->stream); }
   return rc;
 }
 
+int multi_set_reduction(void *obj, int kind) {
+  Multi *m = as_multi(obj);
+  if (!m) { set_error(2, "mxa_multi_set_reduction: not a multi-device object"); return 1; }
+  if (kind != 0 && kind != 1) { set_error(1, "mxa_multi_set_reduction: kind must be 0 (peer-to-peer, fixed order) or 1 (RCCL)"); return 1; }
+  DeviceRestore restore;
+  if (multi_synchronize(obj)) return 1;
+  if (kind == 1) {
+    const int rc = init_rccl(m);
+    if (rc) return rc;   // 2: not applicable (several shards share a device)
+  }
+  m->use_rccl = kind == 1;
+  return 0;
+}
+
 }  // namespace mxa
+
+using namespace mxa;
 
 extern "C" int mxa_shard_bounds(long snps, int shards, int g, long *begin, long *end) {
   std::vector<long> b, e;
@@ -463,5 +693,49 @@ extern "C" int mxa_shard_bounds(long snps, int shards, int g, long *begin, long 
 extern "C" int mxa_num_shards(void *compressed) {
   if (!compressed) return 0;
   if (!mxa::is_multi(compressed)) return 1;
-  return (int)reinterpret_cast<mxa::Multi *>(compressed)->shard.size();
+  return (int)reinterpret_cast<mxa::Multi *>(compressed)->sh.size();
+}
+
+extern "C" int mxa_dgemm_compressed_multi(char trans, void *compressed, int n, const double *const *B_per_shard, long ldb, double *const *C_per_shard, long ldc, int sync) {
+  clear_error();
+  bool t;
+  if (trans == 'T' || trans == 't' || trans == 'Y' || trans == 'y') t = true;
+  else if (trans == 'N' || trans == 'n') t = false;
+  else exit(99);   // as dgemm_compressed (5codesAPI.c:73-77)
+  return multi_gemm_slices(compressed, t, n, B_per_shard, ldb, C_per_shard, ldc, sync != 0);
+}
+
+extern "C" int mxa_multi_synchronize(void *compressed) { clear_error(); return multi_synchronize(compressed); }
+extern "C" int mxa_multi_set_reduction(void *compressed, int kind) { clear_error(); return multi_set_reduction(compressed, kind); }
+
+extern "C" int mxa_multi_get_info(void *compressed, mxa_multi_info *out) {
+  Multi *m = as_multi(compressed);
+  if (!m || !out) return 1;
+  out->shards = (int)m->sh.size(); out->devices = m->ndevices; out->root_device = m->root;
+  out->reduction = m->use_rccl ? 1 : 0;
+  out->reductions = m->reductions; out->reduce_ms = m->reduce_ms;
+  out->rccl_checked = m->rccl_checked ? 1 : 0; out->rccl_vs_p2p_max_rel_diff = m->rccl_diff;
+  return 0;
+}
+
+extern "C" int mxa_multi_shard_info(void *compressed, int shard, mxa_shard_info *out) {
+  Multi *m = as_multi(compressed);
+  if (!m || !out || shard < 0 || shard >= (int)m->sh.size()) return 1;
+  const Shard &S = m->sh[shard];
+  out->device = S.h->device; out->snp_begin = S.begin; out->snp_end = S.end;
+  out->peer_to_root = S.peer_to_root; out->peer_from_root = S.peer_from_root;
+  out->kernel_launches = S.h->prof.launches; out->kernel_ms = S.h->prof.kernel_ms;
+  out->in_copies = S.h->prof.in_copies; out->in_ms = S.h->prof.in_ms;
+  out->out_copies = S.h->prof.out_copies; out->out_ms = S.h->prof.out_ms;
+  out->pushes = S.pushes; out->push_ms = S.push_ms;
+  return 0;
+}
+
+extern "C" int mxa_multi_reset_profile(void *compressed) {
+  Multi *m = as_multi(compressed);
+  if (!m) return 1;
+  if (multi_synchronize(compressed)) return 1;
+  for (Shard &S : m->sh) { S.h->prof = ObjectProfile(); S.pushes = 0; S.push_ms = 0.0; }
+  m->reductions = 0; m->reduce_ms = 0.0;
+  return 0;
 }

@@ -101,6 +101,83 @@ def num_shards(obj_ref):
     return _lib.check_library_handle().mxa_num_shards(obj_ref)
 
 
+def shard_bounds(obj_ref, snps):
+    """SNP blocks [(begin, end), ...] of the per-device objects behind a handle (mxa_shard_bounds)"""
+    L = _lib.check_library_handle()
+    G = L.mxa_num_shards(obj_ref)
+    out = []
+    for g in range(G):
+        b, e = ctypes.c_long(0), ctypes.c_long(0)
+        L.mxa_shard_bounds(int(snps), G, g, ctypes.byref(b), ctypes.byref(e))
+        out.append((b.value, e.value))
+    return out
+
+
+def dgemm_compressed_multi(transpose, obj_ref, B_per_shard, C_per_shard, sync=True):
+    """Additive (mxa_dgemm_compressed_multi): one product on a multi-device object with the operands handed over per shard -- lists of
+    column-major torch tensors (entries may be None where the header allows it).  'N': B_per_shard[g] = rows of shard g's SNP block,
+    C_per_shard[0] = the reduced indiv x n result; 'T': B_per_shard[g] = B as shard g reads it, C_per_shard[g] = shard g's row block.
+    All B slices share one leading dimension, all C slices too.  sync=False returns when the work is enqueued (multi_synchronize waits)."""
+    check_storage_object(obj_ref)
+    L = _lib.check_library_handle()
+    G = L.mxa_num_shards(obj_ref)
+    if len(B_per_shard) != G or len(C_per_shard) != G:
+        raise ValueError(f"need {G} entries per operand list")
+    n = next(b for b in B_per_shard if b is not None).shape[1]
+    lds = []
+    for ops in (B_per_shard, C_per_shard):
+        ld = None
+        for t in ops:
+            if t is None:
+                continue
+            tc, l = _colmajor(t)
+            if tc is not t:
+                raise ValueError("per-shard operands must be column-major")
+            if ld is not None and l != ld and t.shape[1] > 1:
+                raise ValueError("per-shard operands must share one leading dimension")
+            ld = l if ld is None or t.shape[1] > 1 else max(ld, l)
+        lds.append(ld)
+    Bp = (ctypes.c_void_p * G)(*[None if t is None else t.data_ptr() for t in B_per_shard])
+    Cp = (ctypes.c_void_p * G)(*[None if t is None else t.data_ptr() for t in C_per_shard])
+    if L.mxa_dgemm_compressed_multi(b"T" if transpose else b"N", obj_ref, int(n), Bp, int(lds[0]), Cp, int(lds[1]), int(bool(sync))):
+        raise RuntimeError("mxa_dgemm_compressed_multi failed: " + _lib.last_error()[1])
+
+
+def multi_synchronize(obj_ref):
+    if _lib.check_library_handle().mxa_multi_synchronize(obj_ref):
+        raise RuntimeError("mxa_multi_synchronize failed: " + _lib.last_error()[1])
+
+
+def multi_set_reduction(obj_ref, kind):
+    """'p2p' (peer-to-peer pushes + one fixed-order addition kernel, the default) or 'rccl' (ncclReduce).  Returns False when RCCL is not
+    applicable (several shards share a device); raises on errors."""
+    rc = _lib.check_library_handle().mxa_multi_set_reduction(obj_ref, {"p2p": 0, "rccl": 1}[kind])
+    if rc == 1:
+        raise RuntimeError("mxa_multi_set_reduction failed: " + _lib.last_error()[1])
+    return rc == 0
+
+
+def multi_info(obj_ref, reset=False):
+    """dict with the object's layout and what it has done since the last reset: per shard the device, the SNP block, the peer-access
+    verdicts, the dominant-kernel launches / ms, operand-distribution, result-gather and partial-push copies / ms; the reduction kind,
+    count and ms; the RCCL-vs-peer-to-peer cross-check (mxa_multi_get_info / mxa_multi_shard_info)."""
+    L = _lib.check_library_handle()
+    mi = _lib.MultiInfo()
+    L.mxa_multi_synchronize(obj_ref)          # everything issued has finished and its events have been read
+    if L.mxa_multi_get_info(obj_ref, ctypes.byref(mi)):
+        raise RuntimeError("mxa_multi_get_info: not a multi-device object")
+    out = {k: getattr(mi, k) for k, _ in _lib.MultiInfo._fields_}
+    out["reduction"] = "rccl" if mi.reduction else "p2p-fixed-order"
+    out["per_shard"] = []
+    for g in range(mi.shards):
+        si = _lib.ShardInfo()
+        L.mxa_multi_shard_info(obj_ref, g, ctypes.byref(si))
+        out["per_shard"].append({k: getattr(si, k) for k, _ in _lib.ShardInfo._fields_})
+    if reset:
+        L.mxa_multi_reset_profile(obj_ref)
+    return out
+
+
 def init_compressed_shard(plink, plink_transposed, snps_total, indiv, snp_begin, snp_end, freq, max_ncol):
     """SNP-sharded variant (mxa_plink2compressed_shard): this object holds SNPs [snp_begin, snp_end) only."""
     obj_ref = ctypes.c_void_p(None)

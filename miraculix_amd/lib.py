@@ -12,6 +12,17 @@ c_u8p = ctypes.POINTER(ctypes.c_uint8)
 c_f64p = ctypes.POINTER(ctypes.c_double)
 
 
+class MultiInfo(ctypes.Structure):   # include/miraculix_amd.h: mxa_multi_info
+    _fields_ = [("shards", ctypes.c_int), ("devices", ctypes.c_int), ("root_device", ctypes.c_int), ("reduction", ctypes.c_int),
+                ("reductions", ctypes.c_int), ("reduce_ms", ctypes.c_double), ("rccl_checked", ctypes.c_int), ("rccl_vs_p2p_max_rel_diff", ctypes.c_double)]
+
+
+class ShardInfo(ctypes.Structure):   # include/miraculix_amd.h: mxa_shard_info
+    _fields_ = [("device", ctypes.c_int), ("snp_begin", ctypes.c_long), ("snp_end", ctypes.c_long), ("peer_to_root", ctypes.c_int), ("peer_from_root", ctypes.c_int),
+                ("kernel_launches", ctypes.c_int), ("kernel_ms", ctypes.c_double), ("in_copies", ctypes.c_int), ("in_ms", ctypes.c_double),
+                ("out_copies", ctypes.c_int), ("out_ms", ctypes.c_double), ("pushes", ctypes.c_int), ("push_ms", ctypes.c_double)]
+
+
 def set_library_path(path):
     _LIBRARY_PATH[0] = path
     _LIBRARY_HANDLE[0] = None
@@ -49,6 +60,18 @@ def load_shared_library():
     L.mxa_num_shards.restype = ctypes.c_int
     L.mxa_shard_bounds.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]
     L.mxa_shard_bounds.restype = ctypes.c_int
+    L.mxa_dgemm_compressed_multi.argtypes = [ctypes.c_char, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_long, ctypes.POINTER(ctypes.c_void_p), ctypes.c_long, ctypes.c_int]
+    L.mxa_dgemm_compressed_multi.restype = ctypes.c_int
+    L.mxa_multi_synchronize.argtypes = [ctypes.c_void_p]
+    L.mxa_multi_synchronize.restype = ctypes.c_int
+    L.mxa_multi_set_reduction.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.mxa_multi_set_reduction.restype = ctypes.c_int
+    L.mxa_multi_get_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(MultiInfo)]
+    L.mxa_multi_get_info.restype = ctypes.c_int
+    L.mxa_multi_shard_info.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ShardInfo)]
+    L.mxa_multi_shard_info.restype = ctypes.c_int
+    L.mxa_multi_reset_profile.argtypes = [ctypes.c_void_p]
+    L.mxa_multi_reset_profile.restype = ctypes.c_int
     L.mxa_grm.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     L.mxa_grm.restype = ctypes.c_int
     L.mxa_ld.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]

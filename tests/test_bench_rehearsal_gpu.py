@@ -30,7 +30,7 @@ def test_bench_two_ranks_one_gpu_gloo():
 
 
 def _run_bench(extra, env=None):
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--snps", "60002", "--indiv", "8000", "--ncol", "32"] + extra
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--snps", "60002", "--indiv", "8000", "--ncol", "32", "--configs-scale", "0.02"] + extra
     r = subprocess.run(cmd, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=900, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-1500:]
@@ -52,6 +52,15 @@ def test_bench_single_gpu_line_is_complete():
     assert ab["bitwise_equal_to_device_resident_results"] is True and ab["max_GFLOPs"] >= ab["mean_GFLOPs"] > 0
     ck = out["check"]
     assert ck["gpu_T_rows_vs_cpu_library_max_rel_err"] <= 1e-11 and ck["gpu_N_64_sampled_rows_vs_dense_oracle_max_rel_err"] <= 1e-11
+    # the legs for BASELINE configs 3, 4 (shard) and 5 (shard), here at 2 % of their sizes: each carries its rates, its roofline fraction and its checks
+    c5, c4, c3 = out["config5_cg_step"], out["config4_shard"], out["config3_crossprod"]
+    assert c5["ms_per_cg_step"] > 0 and c5["check"]["gram_matvec_bitwise_equals_T_then_N"] is True and 0 < c5["frac_of_8_TBs_spec"] < 1
+    assert c5["check"]["T_32_sampled_rows_vs_dense_oracle_max_rel_err"] <= 1e-11 and c5["check"]["N_32_sampled_rows_vs_dense_oracle_max_rel_err"] <= 1e-11
+    for t in ("N", "T"):
+        assert c4[t]["k_gemm_ms"] > 0 and 0 < c4[t]["frac_of_fp64_mfma_peak_kernel"] < 1
+    assert c4["check"]["N_16_sampled_rows_vs_dense_oracle_max_rel_err"] <= 1e-11 and c4["check"]["T_16_sampled_rows_vs_dense_oracle_max_rel_err"] <= 1e-11
+    for eng in ("k_crossprod_f4 (FP4 MFMA, default)", "k_crossprod2 (int8 MFMA)"):
+        assert c3[eng]["kernel_ms"] > 0 and c3[eng]["check"]["four_256x256_tiles_and_mirrors_bit_exact_vs_int32_oracle"] is True
 
 
 def test_bench_inprocess_two_shards_behind_the_c_abi():
@@ -61,3 +70,13 @@ def test_bench_inprocess_two_shards_behind_the_c_abi():
     assert out["n_gpus"] == 2 and "behind the C ABI" in out["config"]["workload"]
     assert out["check"]["adjoint_identity_max_rel_err"] <= 1e-10 and out["roofline"]["launches"] == 8
     assert out["abi_end_to_end"]["bitwise_equal_to_device_resident_results"] is True
+    # the line explains itself: per shard the kernel time, the copies and the pushes; the reduction that ran and its kernel time; the
+    # RCCL variant (not applicable with two shards on one device) and the hub variant beside it
+    ps = out["per_shard"]
+    assert ps["reduction"] == "p2p-fixed-order" and ps["reductions"] == 2 and ps["avg_reduce_kernel_ms"] > 0 and len(ps["shards"]) == 2
+    for s in ps["shards"]:
+        assert s["k_gemm_launches"] == 4 and s["avg_k_gemm_ms"] > 0 and s["operand_copies_in"] == 0 and s["result_copies_out"] == 0
+        assert s["peer_access_to_root"] == -1 and s["partial_pushes"] == 0      # one device: nothing to push
+    assert "skipped" in out["rccl_reduction"]
+    hub = out["hub_operands_on_first_device"]
+    assert hub["value"] > 0 and len(hub["avg_copy_in_ms_per_shard"]) == 2

@@ -38,27 +38,10 @@ def _stage(torch, mx, dev, snps, indiv, n, seed):
 
 
 def _sampled_vs_oracle(S, trans, Bdev, Cdev, cols, centered, nsample=64, seed=1):
-    """nsample rows of the result (individuals for 'N', SNPs for 'T'), columns `cols`, against the long-double dense oracle on the
-    extracted rows of the packed matrix."""
-    torch, dev, snps, indiv = S["torch"], S["dev"], S["snps"], S["indiv"]
-    o = Oracle()
-    rng = np.random.default_rng(seed)
-    f = S["f"].cpu().numpy()
-    Bs = np.ascontiguousarray(Bdev[:, cols].t().cpu().numpy())                        # len(cols) x k, row j = column cols[j]
-    if not trans:
-        ii = np.sort(rng.choice(indiv, nsample, replace=False))
-        rows = S["plink_t"][torch.from_numpy(ii).to(dev)].cpu().numpy()               # nsample x ceil(snps/4)
-        sub_plink = o.transpose_2bit(np.ascontiguousarray(rows), nsample, snps)        # snps x ceil(nsample/4)
-        prob = dict(snps=snps, indiv=nsample, plink=sub_plink, plink_t=rows, f=f)
-        ref = o.dgemm_dense(0, prob, Bs, centered)                                     # len(cols) x nsample
-        got = Cdev[torch.from_numpy(ii).to(dev)][:, cols].t().cpu().numpy()
-    else:
-        ss = np.sort(rng.choice(snps, nsample, replace=False))
-        srows = S["plink"][torch.from_numpy(ss).to(dev)].cpu().numpy()                # nsample x ceil(indiv/4)
-        prob = dict(snps=nsample, indiv=indiv, plink=np.ascontiguousarray(srows), plink_t=None, f=np.ascontiguousarray(f[ss]))
-        ref = o.dgemm_dense(1, prob, Bs, centered)
-        got = Cdev[torch.from_numpy(ss).to(dev)][:, cols].t().cpu().numpy()
-    err = np.abs(got - ref).max() / np.abs(ref).max()
+    """nsample rows of the result against the long-double dense oracle on the extracted rows of the packed matrix (the helper bench.py's
+    config legs use too)"""
+    from bench import sampled_rows_vs_oracle
+    err = sampled_rows_vs_oracle(S["torch"], S, trans, Bdev, Cdev, cols, centered, nsample=nsample, seed=seed)
     assert err <= RTOL, (trans, err)
 
 
