@@ -203,9 +203,10 @@ static int ensure_workspace(Handle *h, int n) {
   if (grow(&w.d_Bp, &w.cap_Bp, bp)) return 1;
   if (grow(&w.d_P, &w.cap_P, pp)) return 1;
   if (grow(&w.d_colpart, &w.cap_colpart, (size_t)n * (64 * 2 + 2) + 16)) return 1;
-  if (!w.d_denflag) {
-    MXA_HIP(hipMalloc(reinterpret_cast<void **>(&w.d_denflag), 4 * sizeof(int)));
-    MXA_HIP(hipMemset(w.d_denflag, 0, 4 * sizeof(int)));
+  if (!w.d_denflag) {   // flags + the work-queue counters of k_gemm, one small block for the life of the handle
+    MXA_HIP(hipMalloc(reinterpret_cast<void **>(&w.d_denflag), (16 + 16 * 16) * sizeof(int)));
+    MXA_HIP(hipMemset(w.d_denflag, 0, (16 + 16 * 16) * sizeof(int)));
+    w.d_ctr = w.d_denflag + 16;
   }
   return 0;
 }
@@ -350,7 +351,6 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   if (ensure_workspace(h, n)) return 1;
   Workspace &w = h->ws;
   double *d_sumB = w.d_colpart + (size_t)n * 128, *d_sumfB = d_sumB + n;
-  static const int mode = [] { const char *e = getenv("MXA_GEMM_MODE"); return e ? atoi(e) : 2; }();
   const int engine = g_engine.load();
   const bool prof = g_profile_on && timing;
   const int slot = h->prof_slot;
@@ -409,9 +409,10 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     Geometry &geo = last_geometry();
     geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c; geo.path = use_lut ? 1 : 0;
   }
-  // MODE 2 (default): genotype operand as the denormal z * 2^-1074 (one VALU per fragment instead of two); B scaled per column
+  // MODE 2 / 3 (default): genotype operand as the denormal z * 2^-1074 (one VALU per fragment instead of two); B scaled per column
+  const int mode = gemm_default_mode(p.c);
   const int *d_E = nullptr;
-  if (!use_lut && mode == 2) {
+  if (!use_lut && (mode == 2 || mode == 3)) {
     if (w.cap_exp < (size_t)n) {
       MXA_HIP(hipStreamSynchronize(s));
       if (w.d_exp) { MXA_HIP(hipFree(w.d_exp)); w.d_exp = nullptr; w.cap_exp = 0; }
@@ -423,13 +424,13 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     if (launch_colexp(dB, ldb, k, n, w.d_colpart, w.d_exp, 0, s, w.d_denflag, kDenMaxSpan, -100000)) return 1;
     d_E = w.d_exp;
   }
-  if (!use_lut && launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, d_E)) return 1;
+  if (!use_lut && launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, d_E, 0, -1, nullptr, mode == 3)) return 1;
   if (prof) MXA_HIP(hipEventRecord(pe0, s));
-  int rc = use_lut ? launch_lut(G, dB, ldb, n, w.d_P, p, s) : launch_gemm(G, w.d_Bp, w.d_P, p, mode, s);
+  int rc = use_lut ? launch_lut(G, dB, ldb, n, w.d_P, p, s) : launch_gemm(G, w.d_Bp, w.d_P, p, mode, s, next_ctr(w));
   if (prof && !rc) { MXA_HIP(hipEventRecord(pe1, s)); h->prof_pending[slot] = true; }
   if (!rc && d_E) {   // fallback of the denormal-operand mode, run only when the guard raised the flag: unscaled B, two-instruction conversion
     rc = launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, nullptr, 0, -1, w.d_denflag);
-    if (!rc) rc = launch_gemm(G, w.d_Bp, w.d_P, p, 0, s, 0, -1, w.d_denflag);
+    if (!rc) rc = launch_gemm(G, w.d_Bp, w.d_P, p, 0, s, next_ctr(w), 0, -1, w.d_denflag);
   }
   if (!rc) rc = launch_finish(w.d_P, p, m, n, dC, ldc, fill_rows, trans ? 1 : 0, centered, d_sumB, d_sumfB, h->d_f, s, d_E, 0, 0, nullptr, d_E ? w.d_denflag : nullptr);
   return rc;
@@ -460,9 +461,8 @@ static int pipe_setup(Handle *h) {
 static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, long ldb, bool b_host, bool b_local, double *C, long ldc, bool c_host, bool c_local,
                                long fill_rows) {
   static const bool enabled = [] { const char *e = getenv("MXA_HOST_PIPELINE"); return !e || atoi(e) != 0; }();
-  static const int mode = [] { const char *e = getenv("MXA_GEMM_MODE"); return e ? atoi(e) : 2; }();
   const int engine = g_engine.load();
-  if (!enabled || mode != 2 || (engine != 0 && engine != 3) || n < 3 || getenv("MXA_DIAG")) return 2;
+  if (!enabled || (engine != 0 && engine != 3) || n < 3 || getenv("MXA_DIAG")) return 2;
   const PackedMatrix &G = trans ? h->snp_major : h->ind_major;
   const long m = G.rows, k = G.k;
   const size_t b_bytes = b_host ? sizeof(double) * (size_t)k * n : 0, c_bytes = c_host ? sizeof(double) * (size_t)m * n : 0;
@@ -512,6 +512,8 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
     else if (rc8 != 2) return 1;
   }
   const GemmPlan p = plan_gemm(m, G.k_pad, n);
+  const int mode = gemm_default_mode(p.c);
+  if (mode != 2 && mode != 3) return 2;
   { std::lock_guard<std::mutex> lk(g_prof_mutex); Geometry &geo = last_geometry(); geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c; geo.path = 0; }
   MXA_HIP(hipMemsetAsync(w.d_denflag, 0, sizeof(int), s));   // range guard of the denormal-operand mode, raised by any K group's launch_colexp
   MXA_HIP(hipEventRecord(h->pev[0], s));
@@ -521,7 +523,7 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
     const int spc = (p.splits + want_chunks - 1) / want_chunks, nch = (p.splits + spc - 1) / spc;
     for (int c = 0; c < nch; c++) {
       const int sb = c * spc, se = std::min(p.splits, sb + spc);
-      const long slab0 = (long)sb * p.slabs_per_split, slab1 = std::min<long>(p.slabs_total, (long)se * p.slabs_per_split);
+      const long slab0 = plan_split_begin(p, sb), slab1 = std::min<long>(p.slabs_total, plan_split_begin(p, se));
       const long k0 = std::min(k, slab0 * kSlabK), k1 = std::min(k, slab1 * kSlabK);
       if (!b_local && k1 > k0)
         MXA_HIP(copy_columns(w.d_Bstage + k0, sizeof(double) * k, B + k0, sizeof(double) * ldb, sizeof(double) * (k1 - k0), n, s));
@@ -530,8 +532,8 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
       MXA_HIP(hipStreamWaitEvent(cs, h->pev[2 + c], 0));
       int *d_Ec = w.d_exp + (size_t)c * n;
       if (launch_colexp(dB + k0, dldb, k1 - k0, n, w.d_colpart + (size_t)c * 128 * n, d_Ec, 0, cs, w.d_denflag, kDenMaxSpan, -100000, false)) return 1;
-      if (launch_pack_B(dB, dldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, cs, d_Ec, slab0 * kSlabSteps, (slab1 - slab0) * kSlabSteps)) return 1;
-      if (launch_gemm(G, w.d_Bp, w.d_P, p, 2, cs, sb, se)) return 1;
+      if (launch_pack_B(dB, dldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, cs, d_Ec, slab0 * kSlabSteps, (slab1 - slab0) * kSlabSteps, nullptr, mode == 3)) return 1;
+      if (launch_gemm(G, w.d_Bp, w.d_P, p, mode, cs, next_ctr(w), sb, se)) return 1;
       MXA_HIP(hipEventRecord(h->pev[10 + c], cs));
     }
     for (int c = 0; c < nch; c++) MXA_HIP(hipStreamWaitEvent(s, h->pev[10 + c], 0));
@@ -547,13 +549,13 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
       else MXA_HIP(copy_columns(w.d_Bstage, sizeof(double) * k, B, sizeof(double) * ldb, sizeof(double) * k, n, s));
     }
     if (launch_colexp(dB, dldb, k, n, w.d_colpart, w.d_exp, 0, s, w.d_denflag, kDenMaxSpan, -100000, false)) return 1;
-    if (launch_pack_B(dB, dldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, w.d_exp)) return 1;
+    if (launch_pack_B(dB, dldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, w.d_exp, 0, -1, nullptr, mode == 3)) return 1;
     if (centered && launch_colsums(dB, dldb, k, n, trans ? nullptr : h->d_f, d_sumscratch, d_sumB, d_sumfB, s)) return 1;
     MXA_HIP(hipEventRecord(h->pev[1], s));
     const long rows_chunk = ((m + want_chunks - 1) / want_chunks + kRowAlign - 1) / kRowAlign * kRowAlign;
     {   // the row ranges pad to whole row blocks each: a few blocks more than the one-launch plan
       size_t total = 0;
-      for (long r0 = 0; r0 < m; r0 += rows_chunk) { const GemmPlan pc = plan_gemm(std::min(m, r0 + rows_chunk) - r0, G.k_pad, n, p.splits); total += (size_t)pc.splits * pc.n_pad * pc.m_pad; }
+      for (long r0 = 0; r0 < m; r0 += rows_chunk) { const GemmPlan pc = plan_gemm(std::min(m, r0 + rows_chunk) - r0, G.k_pad, n, &p); total += (size_t)pc.splits * pc.n_pad * pc.m_pad; }
       if (total > w.cap_P) { MXA_HIP(hipStreamSynchronize(s)); if (grow(&w.d_P, &w.cap_P, total)) return 1; }
     }
     size_t p_off = 0;
@@ -565,13 +567,12 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
       PackedMatrix V = G;   // rows [r0, r1): whole 256-row tiles, so the view starts at a tile boundary of the tiled layout
       V.d = G.d + (size_t)(r0 / kTileRows) * G.nslabs * kTileBytes;
       V.rows = rows_c; V.rows_pad = last ? G.rows_pad - r0 : rows_chunk;
-      const GemmPlan pc = plan_gemm(rows_c, G.k_pad, n, p.splits);   // the one-launch plan's K splits: identical sums
-      if (pc.slabs_per_split != p.slabs_per_split) { set_error(4, "internal: chunk plan differs from the launch plan"); return 1; }
+      const GemmPlan pc = plan_gemm(rows_c, G.k_pad, n, &p);   // the one-launch plan's K pieces: identical sums
       const size_t p_need = (size_t)pc.splits * pc.n_pad * pc.m_pad;
       if (p_off + p_need > w.cap_P) { set_error(4, "internal: partial-result workspace too small for the row-range pipeline"); return 1; }
       hipStream_t cs = h->pipe[c & 1];
       MXA_HIP(hipStreamWaitEvent(cs, h->pev[1], 0));
-      if (launch_gemm(V, w.d_Bp, w.d_P + p_off, pc, 2, cs)) return 1;
+      if (launch_gemm(V, w.d_Bp, w.d_P + p_off, pc, mode, cs, next_ctr(w))) return 1;
       const long fill_c = last ? fill_rows - r0 : rows_c;
       if (launch_finish(w.d_P + p_off, pc, rows_c, n, dC + r0, dldc, fill_c, trans ? 1 : 0, centered, d_sumB, d_sumfB, (h->d_f && trans) ? h->d_f + r0 : h->d_f, cs, w.d_exp)) return 1;
       MXA_HIP(hipEventRecord(h->pev[10 + c], cs));

@@ -49,7 +49,8 @@ struct Workspace {
   double *d_colpart = nullptr; size_t cap_colpart = 0; // column-sum partials + sums
   double *d_tmp = nullptr;    size_t cap_tmp = 0;      // snps x n intermediate of mxa_gram_matvec
   int *d_exp = nullptr;       size_t cap_exp = 0;      // per-column exponents of B (denormal-operand mode)
-  int *d_denflag = nullptr;                            // != 0: a column of B spans more binades than the denormal-operand mode carries (kDenMaxSpan)
+  int *d_denflag = nullptr;                            // [0] != 0: a column of B spans more binades than the denormal-operand mode carries (kDenMaxSpan); [1]: guard of the int8 route
+  int *d_ctr = nullptr; unsigned ctr_next = 0;         // 16 blocks of 16 ints: work-queue counters of k_gemm launches, handed out in turn (next_ctr)
   void *d_i8 = nullptr;       size_t cap_i8 = 0;       // int8 engine: exponents, slices of B, int32 partials (bytes)
 };
 
@@ -88,6 +89,8 @@ struct Handle {
   hipStream_t pipe[2] = {nullptr, nullptr};
   hipEvent_t pev[18] = {};                   // [0] start, [1] operands ready, [2..9] upload of chunk c, [10..17] chunk c computed
 };
+
+inline int *next_ctr(Workspace &w) { return w.d_ctr + 16 * (w.ctr_next++ & 15); }
 
 struct Profile {
   int launches = 0;
@@ -169,16 +172,22 @@ int launch_colexp(const double *dB, long ldb, long k, int n, double *d_part, int
 // K-steps (16 genotypes) [S0, S0 + S_cnt) only; S_cnt < 0: to the end
 // run_if_set (nullable, device int): the kernel does nothing unless *run_if_set != 0
 int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k_pad, int n_pad, int c, hipStream_t s, const int *d_E = nullptr, long S0 = 0,
-                  long S_cnt = -1, const int *run_if_set = nullptr);
+                  long S_cnt = -1, const int *run_if_set = nullptr, bool rowscale = false);
 int launch_colsums(const double *dB, long ldb, long k, int n, const double *d_f /*nullable*/, double *d_part,
                    double *d_sumB, double *d_sumfB, hipStream_t s);
 // p_rows: rows per tile of the partial-result array P[split][m_pad / p_rows][n_pad][p_rows] (k_gemm: the workgroup's row block, so a
 // workgroup writes one contiguous chunk; lookup kernel: m_pad, i.e. plain [split][n_pad][m_pad])
-struct GemmPlan { int a, c, nchunks, n_pad, splits, slabs_per_split, slabs_total, rowblocks; long m_pad; long p_rows; };
-GemmPlan plan_gemm(long m, long k_pad, int n, int force_splits = 0);
+// K splits: [0, s1) are l1 slabs long, [s1, splits) l2 (tapered tail of k_gemm; elsewhere s1 = splits); slabs_per_split = l1
+struct GemmPlan { int a, c, nchunks, n_pad, splits, slabs_per_split, slabs_total, rowblocks; long m_pad; long p_rows; int s1, l1, l2; };
+inline long plan_split_begin(const GemmPlan &p, int sp) { return sp < p.s1 ? (long)sp * p.l1 : (long)p.s1 * p.l1 + (long)(sp - p.s1) * p.l2; }
+// ksplits_like: take the K pieces of another plan (row ranges of one product: identical sums)
+GemmPlan plan_gemm(long m, long k_pad, int n, const GemmPlan *ksplits_like = nullptr);
+// conversion variant of k_gemm for a tile of c column groups: 2 (v_bfe_u32) or 3 (v_and_b32 + B rows pre-scaled); MXA_GEMM_MODE overrides
+int gemm_default_mode(int c);
 // K splits [split_begin, split_end) only (split_end < 0: all)
 // run_if_set (nullable, device int; MODE 0 only): the kernel does nothing unless *run_if_set != 0 (fallback of the denormal-operand mode)
-int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, int mode, hipStream_t s, int split_begin = 0, int split_end = -1,
+// d_ctr: 9 ints of device memory for the work queues of this launch (zeroed here, on s); must not be shared with a launch that may run at the same time
+int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, int mode, hipStream_t s, int *d_ctr, int split_begin = 0, int split_end = -1,
                 const int *run_if_set = nullptr);
 GemmPlan plan_lut(long m, long k_pad, int n);
 // run_if_set (nullable, device int): the kernel does nothing unless *run_if_set != 0 (fallback of the guarded small-n route)

@@ -91,7 +91,7 @@ int launch_recode(const uint8_t *d_src, size_t src_pitch, long row0, long nrows,
 // K-steps [S0, S0 + S_cnt) only (the host-operand pipeline packs B in K ranges as they arrive); the whole array: S0 = 0, S_cnt = S_total.
 __global__ void __launch_bounds__(256) k_pack_B(const double *__restrict__ B, long ldb, long k, int n,
                                                 double *__restrict__ Bp, long total, int C, long S_total, const int *__restrict__ E, int up, long S0, long S_cnt,
-                                                const int *__restrict__ run_if_set) {
+                                                const int *__restrict__ run_if_set, int rowscale) {
   if (run_if_set && *run_if_set == 0) return;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int l = (int)(idx & 63);
@@ -105,7 +105,9 @@ __global__ void __launch_bounds__(256) k_pack_B(const double *__restrict__ B, lo
     double v = 0.0;
     if (row < k && col < n) {
       v = B[row + (long)col * ldb];
-      if (E) v = ldexp(v, up - E[col]);      // denormal-operand mode: column scaled to just below 2^up (exact)
+      // denormal-operand mode: column scaled to just below 2^up (exact); rowscale (k_gemm MODE 3): row 16 S + j also by 4^-j, because
+      // the genotype operand of that row is z * 4^j (the field is masked where it stands)
+      if (E) v = ldexp(v, up - E[col] - (rowscale ? 2 * (l >> 2) : 0));
     }
     Bp[(((size_t)chunk * S_total + S) * C + h) * 64 + l] = v;
   }
@@ -165,13 +167,13 @@ int launch_colexp(const double *dB, long ldb, long k, int n, double *d_part, int
 }
 
 int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k_pad, int n_pad, int c, hipStream_t s, const int *d_E, long S0, long S_cnt,
-                  const int *run_if_set) {
+                  const int *run_if_set, bool rowscale) {
   const long S_total = k_pad / 16;
   if (S_cnt < 0) S_cnt = S_total - S0;
   const long total = S_cnt * (long)(n_pad / 4) * 64;
   if (total <= 0) return 0;
   const int grid = (int)std::min<long>((total + 255) / 256, 256L * 64);
-  hipLaunchKernelGGL(k_pack_B, dim3(grid), dim3(256), 0, s, dB, ldb, k, n, dBp, total, c, S_total, d_E, kDenUp, S0, S_cnt, run_if_set);
+  hipLaunchKernelGGL(k_pack_B, dim3(grid), dim3(256), 0, s, dB, ldb, k, n, dBp, total, c, S_total, d_E, kDenUp, S0, S_cnt, run_if_set, rowscale ? 1 : 0);
   MXA_HIP(hipGetLastError());
   return 0;
 }
@@ -280,72 +282,103 @@ struct GemmCfg {
 // MODE 1 63.6 TFLOP/s, MODE 0 69.7 TFLOP/s; with the LDS-DMA addresses computed on the VALU instead of the scalar
 // unit MODE 0 drops to 65.5.  MODE 2 vs MODE 0 at 1M x 50k: n = 32 (C = 8) 17.1k vs 17.3k cycles per slab (+1 %),
 // n = 20 (C = 5) 72.0 vs 68.7 TFLOP/s, n = 10 (C = 3) 56.0 vs 52.0.
+// K splits of a launch plan: splits [0, s1) are l1 slabs long, the rest l2 (the TAPERED TAIL: the last workgroup-sized pieces of a launch are a
+// quarter as long, so that the resident slots run dry within a quarter of a long piece's duration -- measured on C2 with in-kernel stamps
+// (MXA_DIAG): 0.95-1.0 ms of idle slot time in the last 2 ms of a 44.6 ms launch with equal pieces, whatever their length)
+struct KSplit { int s1, l1, l2; };
+__host__ __device__ __forceinline__ int ksplit_begin(const KSplit &ks, int sp) { return sp < ks.s1 ? sp * ks.l1 : ks.s1 * ks.l1 + (sp - ks.s1) * ks.l2; }
+__host__ __device__ __forceinline__ int ksplit_len(const KSplit &ks, int sp) { return sp < ks.s1 ? ks.l1 : ks.l2; }
+
+// PERSISTENT workgroups.  The launch has one workgroup per resident slot (2 per CU); each pulls work pieces "unit" = (row block, column chunk,
+// K split) from queues in device memory until they are empty.  Why (MXA_DIAG stamps, C2): with one workgroup per piece the hardware needs
+// 8-14 us to replace a finished workgroup (0.36-0.42 ms of idle slot time per 44.6 ms launch) and every piece begins with an exposed first
+// slab load (2.8 us); here the next piece's first slab is in flight during the epilogue of the current one.
+// Queues: pieces are numbered like the block index of the former one-piece-per-workgroup launch -- row block fastest inside a (column chunk,
+// K split) group, whose workgroups stream the same B slabs.  With xcd_order the first 8 * floor(groups / 8) groups are dealt whole to the 8
+// XCDs (each has its own L2: group g is worked on by XCD g % 8 only, its B slabs cross the fabric once instead of once per XCD): queue x
+// holds the pieces of XCD x in order, queue 8 the remaining groups in plain order for everybody; a workgroup whose queues are empty steals
+// from the other XCDs' queues.  The XCD of a workgroup is read from the hardware (HW_REG_XCC_ID), not assumed.  ctr: 9 counters, zeroed by
+// the launcher on the same stream.  Every fetch is one returning atomic add by one lane; every wave leaves when the fetch returns "none".
 template <int A, int C, int MODE, bool DIAG = false>
 __global__ void __launch_bounds__(256, 2)
 k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ Bp, int H, double *__restrict__ P,
-       long m_pad, int n_pad, int rowblocks, int nchunks, int slabs_total, int slabs_per_split, int xcd_order,
-       unsigned long long *__restrict__ diag = nullptr, int split0 = 0, const int *__restrict__ run_if_set = nullptr) {
+       long m_pad, int n_pad, int rowblocks, int nchunks, int slabs_total, KSplit ks, int xcd_order,
+       unsigned long long *__restrict__ diag, int split0, const int *__restrict__ run_if_set, int nunits, int *__restrict__ ctr, int g8) {
   using Cfg = GemmCfg<A, C>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_next;
   // MODE 0 as the fallback of the denormal-operand mode: runs only when launch_colexp found a column outside its range (kDenMaxSpan)
   if (MODE == 0) { if (run_if_set && *run_if_set == 0) return; }
-  unsigned long long rt_begin = 0;
-  if (DIAG) rt_begin = __builtin_amdgcn_s_memrealtime();
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // Workgroups that share a B slab stream are all row blocks of one (column chunk, K split) group.  Plain order: row block fastest.
-  // XCD-aware order: consecutive blockIdx.x are dealt round-robin to the 8 XCDs, each with its own L2, so group g (of the first
-  // 8 * floor(groups / 8)) is given to XCD g % 8 only -- its B slabs cross the fabric once instead of once per XCD.
-  int bid = blockIdx.x;
-  const int ngroups = (int)(gridDim.x / rowblocks);
-  int rb, grp;
-  const int g8 = ngroups & ~7;                       // groups dealt to XCDs whole; the last ngroups % 8 groups keep the plain order
-  if (xcd_order && bid < g8 * rowblocks) { const int xcd = bid & 7, slot = bid >> 3; rb = slot % rowblocks; grp = xcd + 8 * (slot / rowblocks); }
-  else { const int t = bid - g8 * rowblocks * (xcd_order ? 1 : 0); rb = t % rowblocks; grp = (xcd_order ? g8 : 0) + t / rowblocks; }
-  const int nc = grp % nchunks;
-  const int sp = grp / nchunks + split0;              // split0: first K split of this launch (host-operand pipeline: K ranges as B arrives)
-  const int slab0 = sp * slabs_per_split;
-  const int slab1 = min(slab0 + slabs_per_split, slabs_total);
-  const long row0 = (long)rb * Cfg::kRowsWG;
+  // g8 (a multiple of 8, from the launcher): groups dealt to the XCDs whole -- LONG pieces only, the same number for every XCD, so that
+  // the XCD queues hold equal work; the remaining long groups and the short ones (the tapered tail) form the common queue
+  const int n1 = (g8 / 8) * rowblocks;               // pieces in every XCD queue
+  const int n2 = nunits - g8 * rowblocks;            // pieces in the common queue
+  int xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+  xcc &= 7;
+  int phase = 0;                                      // 0 own XCD queue, 1 common queue, 2..8 the other XCDs' queues (only thread 0 uses it)
+  auto fetch = [&]() -> int {
+    while (phase <= 8) {
+      if (phase == 1) {
+        const int t = __hip_atomic_fetch_add(ctr + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t < n2) return g8 * rowblocks + t;
+      } else {
+        const int y = phase == 0 ? xcc : ((xcc + phase - 1) & 7);
+        const int sl = n1 > 0 ? __hip_atomic_fetch_add(ctr + y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : n1;
+        if (sl < n1) return sl * 8 + y;
+      }
+      phase++;
+    }
+    return -1;
+  };
 
   // ---- DMA issue for one slab into buffer `buf`.  Every source address is (wave-uniform 64-bit base) + (per-lane 32-bit
   // offset that never changes), so the per-slab address arithmetic is scalar: VALU instructions are expensive beside the
   // fp64 MFMA stream (see MODE comment above).
   const uint32_t b_lane = lane * 16;
   const uint32_t a_lane = lane * 16;
-  // chunk-major B fragments: this workgroup's column chunk nc is one contiguous array [S_total][C][64]
-  const char *Bp_u = reinterpret_cast<const char *>(Bp) + (size_t)nc * ((size_t)slabs_total * kSlabSteps * C * 512);
-  // tiled layout: the rows [row0, row0 + kRowsWG) of slab s are one contiguous run inside tile (row0/256, s)
   const size_t nslabs_all = pitch / kSlabBytes;
-  const char *G_u = reinterpret_cast<const char *>(G) + (size_t)(row0 / kTileRows) * nslabs_all * kTileBytes + (size_t)(row0 % kTileRows) * kSlabBytes;
   const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
-  auto issue = [&](int slab, int buf) {
+  struct Unit { int rb, nc, sp, slab0, slab1; const char *Bp_u, *G_u; };
+  auto decode = [&](int bid) -> Unit {
+    Unit u;
+    int grp;
+    if (bid < g8 * rowblocks) { const int xcd = bid & 7, slot = bid >> 3; u.rb = slot % rowblocks; grp = xcd + 8 * (slot / rowblocks); }
+    else { const int t = bid - g8 * rowblocks; u.rb = t % rowblocks; grp = g8 + t / rowblocks; }
+    u.nc = grp % nchunks;
+    u.sp = grp / nchunks + split0;                   // split0: first K split of this launch (host-operand pipeline: K ranges as B arrives)
+    u.slab0 = ksplit_begin(ks, u.sp);
+    u.slab1 = min(u.slab0 + ksplit_len(ks, u.sp), slabs_total);
+    const long row0 = (long)u.rb * Cfg::kRowsWG;
+    // chunk-major B fragments: the column chunk nc is one contiguous array [S_total][C][64]
+    u.Bp_u = reinterpret_cast<const char *>(Bp) + (size_t)u.nc * ((size_t)slabs_total * kSlabSteps * C * 512);
+    // tiled layout: the rows [row0, row0 + kRowsWG) of slab s are one contiguous run inside tile (row0/256, s)
+    u.G_u = reinterpret_cast<const char *>(G) + (size_t)(row0 / kTileRows) * nslabs_all * kTileBytes + (size_t)(row0 % kTileRows) * kSlabBytes;
+    return u;
+  };
+  auto issue = [&](const Unit &u, int slab, int buf) {
     const uint32_t base = lds0 + buf * Cfg::kBufBytes;
     // B fragments of the slab: one contiguous run of C*4 KiB -> C units per wave
-    const char *bslab = Bp_u + (size_t)slab * ((size_t)kSlabSteps * C * 512);
+    const char *bslab = u.Bp_u + (size_t)slab * ((size_t)kSlabSteps * C * 512);
 #pragma unroll
     for (int i = 0; i < Cfg::kBUnits / kWaves; i++) {
-      const int u = wave + i * kWaves;
-      dma16_s(bslab + u * 1024, b_lane, base + u * 1024);
+      const int q = wave + i * kWaves;
+      dma16_s(bslab + q * 1024, b_lane, base + q * 1024);
     }
     // packed genotype rows: unit = 32 rows x 32 B = 1 KiB, contiguous in the tiled layout
-    const char *aslab = G_u + (size_t)slab * kTileBytes;
+    const char *aslab = u.G_u + (size_t)slab * kTileBytes;
 #pragma unroll
     for (int i = 0; i < (Cfg::kAUnits + kWaves - 1) / kWaves; i++) {
-      const int u = wave + i * kWaves;
-      if (Cfg::kAUnits % kWaves == 0 || u < Cfg::kAUnits) dma16_s(aslab + u * 1024, a_lane, base + Cfg::kBBytes + u * 1024);
+      const int q = wave + i * kWaves;
+      if (Cfg::kAUnits % kWaves == 0 || q < Cfg::kAUnits) dma16_s(aslab + q * 1024, a_lane, base + Cfg::kBBytes + q * 1024);
     }
   };
 
-  double acc[A][C];
-#pragma unroll
-  for (int g = 0; g < A; g++)
-#pragma unroll
-    for (int h = 0; h < C; h++) acc[g][h] = 0.0;
-
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-  u32x2 ap[A];                                                    // MODE 2: A operands as (low, high) word pairs, high words stay 0
+  u32x2 ap[A];                                                    // MODE 2 / 3: A operands as (low, high) word pairs, high words stay 0
 #pragma unroll
   for (int g = 0; g < A; g++) {
     uint32_t zero;   // opaque to the optimiser: a known constant would be re-materialised next to every low word (one v_mov per fragment)
@@ -353,121 +386,177 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
     ap[g].x = 0; ap[g].y = zero;
   }
   const int sh = 2 * (lane >> 2);                                 // field of this lane inside a 16-genotype dword
+  const uint32_t fmask = 3u << sh;                                // MODE 3: the field stays where it is
   const int a_off = (wave * Cfg::kRowsWave + (lane & 3)) * kSlabBytes;  // + g*4 rows -> + g*4*32 bytes
   const int b_off = lane * 8;
+  const int j = lane & 3, blk = (lane >> 2) & 3, i = lane >> 4;
 
-  if (slab0 < slab1) issue(slab0, 0);
+  if (threadIdx.x == 0) s_next = fetch();
+  __syncthreads();
+  int bid = s_next;
+  if (bid < 0) return;
+  Unit u = decode(bid);
+  __syncthreads();                                                 // everybody has read s_next before thread 0 writes the next one
+  if (u.slab0 < u.slab1) issue(u, u.slab0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  // DIAG build only (never the shipped instantiation): shader-clock and 100 MHz real-time stamps around the K loop
-  unsigned long long t0 = 0, r0 = 0;
-  if (DIAG) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
 
-  for (int slab = slab0; slab < slab1; slab++) {
-    const int buf = (slab - slab0) & 1;
-    if (slab + 1 < slab1) issue(slab + 1, buf ^ 1);
-    const char *bbase = smem + buf * Cfg::kBufBytes + b_off;
-    const char *abase = smem + buf * Cfg::kBufBytes + Cfg::kBBytes + a_off;
+  for (;;) {
+    unsigned long long rt_begin = 0, t0 = 0, r0 = 0;
+    if (DIAG) { rt_begin = __builtin_amdgcn_s_memrealtime(); t0 = __builtin_amdgcn_s_memtime(); r0 = rt_begin; }
+    // the piece after this one: fetched now, read by everybody after the K loop (its barriers lie in between)
+    if (threadIdx.x == 0) s_next = fetch();
+    if (u.slab0 >= u.slab1) __syncthreads();
+
+    double acc[A][C];
 #pragma unroll
-    for (int ks2 = 0; ks2 < kSlabSteps / 2; ks2++) {
-      uint2 aw[A];
+    for (int g = 0; g < A; g++)
 #pragma unroll
-      for (int g = 0; g < A; g++) aw[g] = *reinterpret_cast<const uint2 *>(abase + g * 4 * kSlabBytes + ks2 * 8);
+      for (int h = 0; h < C; h++) acc[g][h] = 0.0;
+
+    for (int slab = u.slab0; slab < u.slab1; slab++) {
+      const int buf = (slab - u.slab0) & 1;
+      if (slab + 1 < u.slab1) issue(u, slab + 1, buf ^ 1);
+      const char *bbase = smem + buf * Cfg::kBufBytes + b_off;
+      const char *abase = smem + buf * Cfg::kBufBytes + Cfg::kBBytes + a_off;
 #pragma unroll
-      for (int kk = 0; kk < 2; kk++) {
-        const int ks = 2 * ks2 + kk;
-        double bf[C];
+      for (int ks2 = 0; ks2 < kSlabSteps / 2; ks2++) {
+        uint2 aw[A];
 #pragma unroll
-        for (int h = 0; h < C; h++) bf[h] = *reinterpret_cast<const double *>(bbase + (ks * C + h) * 512);
-        if (MODE == 2) {
-          // denormal operand: the pair (low word = z, high word = 0) IS the double z * 2^-1074.  Only the low word is rewritten
-          // (one v_bfe_u32); the high words were zeroed once before the K loop and stay in place (loop-carried register pairs).
-          double af[A];
+        for (int g = 0; g < A; g++) aw[g] = *reinterpret_cast<const uint2 *>(abase + g * 4 * kSlabBytes + ks2 * 8);
 #pragma unroll
-          for (int g = 0; g < A; g++) { ap[g].x = __builtin_amdgcn_ubfe(kk ? aw[g].y : aw[g].x, sh, 2); af[g] = __builtin_bit_cast(double, ap[g]); }
-          __builtin_amdgcn_sched_barrier(0);
+        for (int kk = 0; kk < 2; kk++) {
+          const int kst = 2 * ks2 + kk;
+          double bf[C];
 #pragma unroll
-          for (int g = 0; g < A; g++)
+          for (int h = 0; h < C; h++) bf[h] = *reinterpret_cast<const double *>(bbase + (kst * C + h) * 512);
+          if (MODE == 2 || MODE == 3) {
+            // denormal operand: the pair (low word = z, high word = 0) IS the double z * 2^-1074.  Only the low word is rewritten
+            // (one VALU instruction); the high words were zeroed once and stay in place (loop-carried register pairs).
+            // MODE 2: v_bfe_u32 (VOP3).  MODE 3: v_and_b32 (VOP2) with the lane's field mask -- the field stays at its bit position 2 j, i.e.
+            // the operand is z * 4^j * 2^-1074, and k_pack_B has scaled row (16 S + j) of B by 4^-j (exact): beside the MFMA stream the
+            // two-operand form costs ~4.5 cycles against ~6.5 (tools/mfma_f64_probe6.hip; it matters where one extraction feeds few MFMAs).
+            double af[A];
 #pragma unroll
-            for (int h = 0; h < C; h++) acc[g][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[g], bf[h], acc[g][h], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        } else if (MODE == 0) {
-          double af[A];
+            for (int g = 0; g < A; g++) {
+              if (MODE == 2) ap[g].x = __builtin_amdgcn_ubfe(kk ? aw[g].y : aw[g].x, sh, 2);
+              else asm volatile("v_and_b32 %0, %1, %2" : "=v"(ap[g].x) : "v"(fmask), "v"(kk ? aw[g].y : aw[g].x));
+              af[g] = __builtin_bit_cast(double, ap[g]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int g = 0; g < A; g++) af[g] = (double)__builtin_amdgcn_ubfe(kk ? aw[g].y : aw[g].x, sh, 2);
-          __builtin_amdgcn_sched_barrier(0);
+            for (int g = 0; g < A; g++)
 #pragma unroll
-          for (int g = 0; g < A; g++)
+              for (int h = 0; h < C; h++) acc[g][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[g], bf[h], acc[g][h], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          } else if (MODE == 0) {
+            double af[A];
 #pragma unroll
-            for (int h = 0; h < C; h++) acc[g][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[g], bf[h], acc[g][h], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        } else {
+            for (int g = 0; g < A; g++) af[g] = (double)__builtin_amdgcn_ubfe(kk ? aw[g].y : aw[g].x, sh, 2);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int g = 0; g < A; g++) {
-            const uint32_t z = __builtin_amdgcn_ubfe(kk ? aw[g].y : aw[g].x, sh, 2);
-            uint32_t hi = (z << 20) + 0x3FE00000u;   // 1.0 -> 0x3FF00000, 2.0 -> 0x40000000
-            hi = z ? hi : 0u;
-            const double af = __hiloint2double((int)hi, 0);
+            for (int g = 0; g < A; g++)
 #pragma unroll
-            for (int h = 0; h < C; h++) acc[g][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(af, bf[h], acc[g][h], 0, 0, 0);
+              for (int h = 0; h < C; h++) acc[g][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[g], bf[h], acc[g][h], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          } else {
+#pragma unroll
+            for (int g = 0; g < A; g++) {
+              const uint32_t z = __builtin_amdgcn_ubfe(kk ? aw[g].y : aw[g].x, sh, 2);
+              uint32_t hi = (z << 20) + 0x3FE00000u;   // 1.0 -> 0x3FF00000, 2.0 -> 0x40000000
+              hi = z ? hi : 0u;
+              const double af = __hiloint2double((int)hi, 0);
+#pragma unroll
+              for (int h = 0; h < C; h++) acc[g][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(af, bf[h], acc[g][h], 0, 0, 0);
+            }
           }
         }
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    unsigned long long t1 = 0, r1 = 0;
+    if (DIAG) { t1 = __builtin_amdgcn_s_memtime(); r1 = __builtin_amdgcn_s_memrealtime(); }
+    // ---- the next piece's first slab goes into buffer 0 while this piece's results leave through buffer 1 (both buffers are idle: the
+    // K loop ended with a barrier)
+    const int next = s_next;
+    Unit un = u;
+    if (next >= 0) { un = decode(next); if (un.slab0 < un.slab1) issue(un, un.slab0, 0); }
+    // ---- epilogue: add the 4 K-blocks (lane bits 2..3); lane (j, blk, i) stores column group hq+blk.  The exchange goes through the
+    // (now idle) second LDS buffer, not through cross-lane VALU shuffles: while this wave is in its epilogue the other workgroup of the CU
+    // is in its MFMA stream, where every VALU instruction of this wave waits for the shared pipe and costs the other one MFMA time
+    // (shuffle version: ~330 VALU per lane, 15 us per workgroup; here 3 v_add_f64 per output).
+    constexpr int kPitch = 68;                                   // doubles per accumulator image: 64 lanes + pad (2-way conflicts at most)
+    constexpr int kPerWave = Cfg::kBufBytes / kWaves / 8;        // doubles of scratch per wave (a quarter of the second buffer)
+    constexpr int GP = (kPerWave / (C * kPitch)) < A ? (kPerWave / (C * kPitch)) : A;   // row groups per pass
+    static_assert(GP >= 1, "epilogue scratch");
+    double *scr = reinterpret_cast<double *>(smem + Cfg::kBufBytes) + wave * kPerWave;
+    // P[split][row block][n_pad][rows of the block]: the workgroup's results form one contiguous chunk
+    double *Pbase = P + ((size_t)u.sp * rowblocks + u.rb) * ((size_t)n_pad * Cfg::kRowsWG);
+#pragma unroll
+    for (int g0 = 0; g0 < A; g0 += GP) {
+#pragma unroll
+      for (int gg = 0; gg < GP; gg++)
+#pragma unroll
+        for (int h = 0; h < C; h++)
+          if (g0 + gg < A) scr[(gg * C + h) * kPitch + lane] = acc[g0 + gg][h];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the wave's own LDS writes are done before any of its lanes reads them
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int gg = 0; gg < GP; gg++) {
+        if (g0 + gg < A) {
+          const int row = wave * Cfg::kRowsWave + (g0 + gg) * 4 + i;   // row inside the block
+#pragma unroll
+          for (int hq = 0; hq < C; hq += 4) {
+            if (hq + blk < C) {
+              const double *q = scr + (gg * C + hq + blk) * kPitch + j + 16 * i;
+              const double out = (q[0] + q[4]) + (q[8] + q[12]);
+              const int col = 4 * (u.nc * C + hq + blk) + j;
+              Pbase[(size_t)col * Cfg::kRowsWG + row] = out;
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (DIAG && threadIdx.x == 0 && diag) {   // per piece: cycles / ticks in the K loop, begin, loop start, end (DIAG build only)
+      diag[2 * (size_t)bid] = t1 - t0; diag[2 * (size_t)bid + 1] = r1 - r0;
+      diag[2 * (size_t)nunits + 2 * (size_t)bid] = rt_begin; diag[2 * (size_t)nunits + 2 * (size_t)bid + 1] = r0;
+      diag[4 * (size_t)nunits + bid] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (next < 0) break;
+    u = un; bid = next;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the next piece's first slab has landed (and this piece's stores are out)
     __syncthreads();
   }
-
-  if (DIAG) {
-    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0 && diag) {
-      diag[2 * (size_t)blockIdx.x] = t1 - t0; diag[2 * (size_t)blockIdx.x + 1] = r1 - r0;
-      diag[2 * (size_t)gridDim.x + 2 * (size_t)blockIdx.x] = rt_begin; diag[2 * (size_t)gridDim.x + 2 * (size_t)blockIdx.x + 1] = r0;   // entry, loop start
-    }
-  }
-  // ---- epilogue: add the 4 K-blocks (lane bits 2..3); lane (j, blk, i) stores column group hq+blk.  The exchange goes through the
-  // (now idle) LDS ring, not through cross-lane VALU shuffles: while this wave is in its epilogue the other workgroup of the CU is
-  // in its MFMA stream, where every VALU instruction of this wave waits for the shared pipe and costs the other one MFMA time
-  // (shuffle version: ~330 VALU per lane, 15 us per workgroup; here 3 v_add_f64 per output).
-  const int j = lane & 3, blk = (lane >> 2) & 3, i = lane >> 4;
-  constexpr int kPitch = 68;                                   // doubles per accumulator image: 64 lanes + pad (2-way conflicts at most)
-  constexpr int kPerWave = Cfg::kLds / kWaves / 8;             // doubles of scratch per wave
-  constexpr int GP = (kPerWave / (C * kPitch)) < A ? (kPerWave / (C * kPitch)) : A;   // row groups per pass
-  static_assert(GP >= 1, "epilogue scratch");
-  double *scr = reinterpret_cast<double *>(smem) + wave * kPerWave;
-  // P[split][row block][n_pad][rows of the block]: the workgroup's results form one contiguous chunk
-  double *Pbase = P + ((size_t)sp * rowblocks + rb) * ((size_t)n_pad * Cfg::kRowsWG);
-#pragma unroll
-  for (int g0 = 0; g0 < A; g0 += GP) {
-#pragma unroll
-    for (int gg = 0; gg < GP; gg++)
-#pragma unroll
-      for (int h = 0; h < C; h++)
-        if (g0 + gg < A) scr[(gg * C + h) * kPitch + lane] = acc[g0 + gg][h];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the wave's own LDS writes are done before any of its lanes reads them
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int gg = 0; gg < GP; gg++) {
-      if (g0 + gg < A) {
-        const int row = wave * Cfg::kRowsWave + (g0 + gg) * 4 + i;   // row inside the block
-#pragma unroll
-        for (int hq = 0; hq < C; hq += 4) {
-          if (hq + blk < C) {
-            const double *q = scr + (gg * C + hq + blk) * kPitch + j + 16 * i;
-            const double out = (q[0] + q[4]) + (q[8] + q[12]);
-            const int col = 4 * (nc * C + hq + blk) + j;
-            Pbase[(size_t)col * Cfg::kRowsWG + row] = out;
-          }
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (DIAG && threadIdx.x == 0 && diag) diag[4 * (size_t)gridDim.x + blockIdx.x] = __builtin_amdgcn_s_memrealtime();   // exit
 }
 
-GemmPlan plan_gemm(long m, long k_pad, int n, int force_splits) {
+int gemm_default_mode(int c) {
+  // MODE 2 (v_bfe_u32) / MODE 3 (v_and_b32, field in place, B rows pre-scaled): the two-operand form is cheaper beside the MFMA stream
+  // (tools/mfma_f64_probe6.hip: 4.5 against 6.5 cycles per extraction); it shows where one extraction feeds few MFMAs (C <= 4)
+  static const int env = [] { const char *e = getenv("MXA_GEMM_MODE"); return e ? atoi(e) : -1; }();
+  if (env >= 0) return env;
+  return c <= 4 ? 3 : 2;
+}
+
+// resident workgroups of k_gemm per CU by tile: the narrow tiles need few registers (110 / 148 VGPRs for C = 1 / 2 -> 4 / 3 waves per SIMD),
+// and more resident waves hide their extraction VALU (n = 4: 55-59 -> 58-64 TFLOP/s); the wide ones fill the register file with 2
+static int gemm_wg_per_cu(int c) {
+  static const int cap = [] { const char *e = getenv("MXA_GEMM_WG_PER_CU"); return e ? atoi(e) : 4; }();
+  return std::max(1, std::min(cap, c == 1 ? 4 : c == 2 ? 3 : 2));
+}
+static long device_cus() {
+  static const long r = [] {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return 256L; }
+    return (long)prop.multiProcessorCount;
+  }();
+  return r > 0 ? r : 256;
+}
+
+GemmPlan plan_gemm(long m, long k_pad, int n, const GemmPlan *ksplits_like) {
   GemmPlan p{};
   // tile choice by n: column chunks of at most 32 columns, C = groups of 4 columns per chunk (balanced over the chunks, so at most
   // 3 padded columns per chunk), A = row groups of 4 per wave: A*C <= 64 accumulators (128 VGPRs)
@@ -482,79 +571,132 @@ GemmPlan plan_gemm(long m, long k_pad, int n, int force_splits) {
   p.m_pad = (long)p.rowblocks * rows_wg;
   p.p_rows = rows_wg;
   p.slabs_total = (int)(k_pad / kSlabK);
-  // aim for >= ~24 rounds of 512 resident workgroups (2 per CU) so the tail is small; keep >= 8 slabs per unit.  Around that
-  // target pick the split count whose number of workgroups fills whole rounds best: 391 row blocks x 32 splits = 24.4 rounds
-  // costs a 25th round at 44 % occupancy, 34 splits = 25.96 rounds does not.
-  const long units = (long)p.rowblocks * p.nchunks;
-  const long want = (12288 + units - 1) / units;
-  const long max_splits = std::max<long>(1, p.slabs_total / 8);
-  static const long resident = [] { const char *e = getenv("MXA_GEMM_RESIDENT"); return e ? atol(e) : 512L; }();   // 0: no search
-  long best_splits = std::max<long>(1, std::min<long>(want, max_splits));
-  if (resident > 0) {
-    double best_eff = -1.0;
-    for (long cand = std::max<long>(1, want - want / 4); cand <= std::min<long>(max_splits, want + want / 3 + 1); cand++) {
-      const long per = (p.slabs_total + cand - 1) / cand;
-      const long actual = (p.slabs_total + per - 1) / per;
-      const long wgs = units * actual;
-      const double eff = (double)wgs / (double)(resident * ((wgs + resident - 1) / resident));
-      if (eff > best_eff + 1e-9) { best_eff = eff; best_splits = cand; }
-    }
+  if (ksplits_like) {   // the same K pieces as another plan (row-range launches of the host-operand pipeline: identical sums)
+    p.splits = ksplits_like->splits; p.s1 = ksplits_like->s1; p.l1 = ksplits_like->l1; p.l2 = ksplits_like->l2; p.slabs_per_split = ksplits_like->slabs_per_split;
+    return p;
   }
-  const long splits = force_splits > 0 ? std::min<long>(force_splits, std::max<long>(1, p.slabs_total)) : best_splits;
-  p.slabs_per_split = (int)((p.slabs_total + splits - 1) / splits);
-  p.splits = (p.slabs_total + p.slabs_per_split - 1) / p.slabs_per_split;
+  // K pieces.  The persistent workgroups (launch_gemm_t) pull pieces = (row block, column chunk, K split) from queues, so what matters is
+  // (i) the fixed cost per piece (its epilogue and the turn-around, ~8 us) against its duration and (ii) how the launch ends: the
+  // slots run dry over about one piece's duration, half a piece of idle time per slot on average (measured with MXA_DIAG stamps at C2:
+  // 0.95-1.0 ms of a 44.6 ms launch with equal pieces).  Hence LONG pieces of ~1.5 ms for the bulk and a TAPERED TAIL: the last
+  // ~2.5 rounds' worth of pieces ~0.2 ms long.  Durations from the MFMA count of a slab at the waves per SIMD this tile runs with.
+  static const double piece_us = [] { const char *e = getenv("MXA_GEMM_PIECE_US"); return e ? atof(e) : 1500.0; }();
+  static const double tail_us = [] { const char *e = getenv("MXA_GEMM_TAIL_US"); return e ? atof(e) : 200.0; }();   // 0: no taper
+  const long units = (long)p.rowblocks * p.nchunks;
+  const long resident = gemm_wg_per_cu(p.c) * device_cus();
+  const double slab_us = (double)kSlabSteps * p.a * p.c * 16.0 * gemm_wg_per_cu(p.c) / 2390.0;
+  long l1 = std::max<long>(8, std::min<long>(p.slabs_total, (long)(piece_us / slab_us + 0.5)));
+  while (l1 > 16 && units * ((p.slabs_total + l1 - 1) / l1) < 6 * resident) l1 = l1 * 3 / 4;   // at least ~6 rounds of pieces: the queues balance the slots
+  long s1 = (p.slabs_total + l1 - 1) / l1, l2 = l1;
+  l1 = (p.slabs_total + s1 - 1) / s1;                       // equal pieces
+  s1 = (p.slabs_total + l1 - 1) / l1;
+  p.splits = (int)s1;
+  const long lt = tail_us > 0 ? std::max<long>(8, (long)(tail_us / slab_us + 0.5)) : l1;
+  if (lt * 2 <= l1 && units * s1 >= 3 * resident) {
+    const long s2 = std::max<long>(1, (5 * resident / 2 + units - 1) / units);         // short splits: about 2.5 rounds of short pieces
+    const long tail = std::min<long>(s2 * lt, p.slabs_total / 2);
+    const long s1n = std::max<long>(1, (p.slabs_total - tail + l1 - 1) / l1);          // long splits cover the rest ...
+    const long l1n = (p.slabs_total - tail + s1n - 1) / s1n;                            // ... in equal pieces
+    const long rest = p.slabs_total - s1n * l1n;
+    if (rest > 0 && l1n >= 2 * lt) { s1 = s1n; l1 = l1n; l2 = lt; p.splits = (int)(s1 + (rest + lt - 1) / lt); }
+  }
+  p.s1 = (int)s1; p.l1 = (int)l1; p.l2 = (int)l2;
+  p.slabs_per_split = (int)l1;
   if (p.splits < 1) p.splits = 1;
   return p;
 }
 
 template <int A, int C, int MODE>
-static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, hipStream_t s, int split_begin, int split_end, const int *run_if_set) {
+static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, hipStream_t s, int split_begin, int split_end, const int *run_if_set,
+                         int *d_ctr) {
   using Cfg = GemmCfg<A, C>;
   static unsigned long long attr_mask = 0;   // function attributes are per device
   if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm<A, C, MODE>), Cfg::kLds, &attr_mask)) return 1;
-  const long grid = (long)p.rowblocks * p.nchunks * (split_end - split_begin);
-  if (grid > 0x7fffffffL) { set_error(3, "grid too large"); return 1; }
-  if (grid <= 0) return 0;
-  static const int xcd_order = [] { const char *e = getenv("MXA_XCD_ORDER"); return e ? atoi(e) : 1; }();   // 0: plain order (A/B measurement)
+  const long nunits = (long)p.rowblocks * p.nchunks * (split_end - split_begin);
+  if (nunits > 0x3fffffffL) { set_error(3, "launch too large"); return 1; }
+  if (nunits <= 0) return 0;
+  if (!d_ctr) { set_error(4, "internal: k_gemm needs its queue counters"); return 1; }
+  // persistent workgroups: one per resident slot (the occupancy of this instantiation x the CUs), fewer if there are fewer pieces
+  static int per_cu[64] = {};
+  int dev = 0;
+  MXA_HIP(hipGetDevice(&dev));
+  if (!per_cu[dev & 63]) {
+    int nb = 0;
+    MXA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_gemm<A, C, MODE>), 256, Cfg::kLds));
+    hipDeviceProp_t prop;
+    MXA_HIP(hipGetDeviceProperties(&prop, dev));
+    per_cu[dev & 63] = std::max(1, std::min(nb, gemm_wg_per_cu(C))) * prop.multiProcessorCount;
+  }
+  const long grid = std::min<long>(nunits, per_cu[dev & 63]);
+  static const int xcd_order = [] { const char *e = getenv("MXA_XCD_ORDER"); return e ? atoi(e) : 1; }();   // 0: one queue in plain order (A/B measurement)
+  const KSplit ks{p.s1, p.l1, p.l2};
+  const int long_groups = (std::min(split_end, p.s1) - std::min(split_begin, p.s1)) * p.nchunks;
+  const int g8 = xcd_order ? (long_groups & ~7) : 0;
+  MXA_HIP(hipMemsetAsync(d_ctr, 0, 9 * sizeof(int), s));
   static const bool diag_on = getenv("MXA_DIAG") != nullptr;
   if (diag_on && A == 8 && C == 8 && split_begin == 0 && split_end == p.splits && !run_if_set) {   // diagnostic instantiation: in-kernel clock + cycles per slab
     static unsigned long long attr2 = 0;
     if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm<A, C, MODE, true>), Cfg::kLds, &attr2)) return 1;
     unsigned long long *d_diag = nullptr;
-    MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_diag), sizeof(unsigned long long) * 5 * grid));
+    MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_diag), sizeof(unsigned long long) * 5 * nunits));
+    MXA_HIP(hipMemsetAsync(d_diag, 0, sizeof(unsigned long long) * 5 * nunits, s));
     hipLaunchKernelGGL((k_gemm<A, C, MODE, true>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBp, p.n_pad / 4, dP,
-                       p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, p.slabs_per_split, xcd_order, d_diag);
+                       p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, ks, xcd_order, d_diag, split_begin, (const int *)nullptr, (int)nunits, d_ctr, g8);
     MXA_HIP(hipStreamSynchronize(s));
-    std::vector<unsigned long long> h(5 * grid);
-    MXA_HIP(hipMemcpy(h.data(), d_diag, sizeof(unsigned long long) * 5 * grid, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> h(5 * nunits);
+    MXA_HIP(hipMemcpy(h.data(), d_diag, sizeof(unsigned long long) * 5 * nunits, hipMemcpyDeviceToHost));
     std::vector<double> ghz, cyc;
-    for (long i = 0; i < grid; i++) if (h[2 * i + 1]) { ghz.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1); cyc.push_back((double)h[2 * i] / p.slabs_per_split); }
+    for (long i = 0; i < nunits; i++) if (h[2 * i + 1]) {
+      const int sp = (int)(i < (long)g8 * p.rowblocks ? ((i & 7) + 8 * ((i >> 3) / p.rowblocks)) / p.nchunks : (i / p.rowblocks) / p.nchunks);
+      const int len = sp < p.s1 ? p.l1 : p.l2;
+      ghz.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1); cyc.push_back((double)h[2 * i] / len);
+    }
     std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end());
-    if (!ghz.empty()) printf("MXA_DIAG k_gemm<%d,%d,%d>: grid %ld, in-kernel clock median %.3f GHz (min %.3f max %.3f); shader cycles per slab median %.0f (ideal %d)\n",
-                             A, C, MODE, grid, ghz[ghz.size() / 2], ghz.front(), ghz.back(), cyc[cyc.size() / 2], kSlabSteps * A * C * 16 * 2);
-    double ticks = 0.0;   // 100 MHz ticks spent inside the K loops, summed over the workgroups
-    for (long i = 0; i < grid; i++) ticks += (double)h[2 * i + 1];
-    printf("MXA_DIAG k_gemm: K loops of all workgroups = %.3f ms if packed perfectly on 512 resident slots (compare with the kernel duration)\n", ticks * 1e-5 / 512.0);
-    {   // workgroup lifetimes (100 MHz real-time counter): entry -> loop start -> loop end -> exit, and the span of the whole grid
-      double pro = 0, epi = 0, life = 0; unsigned long long first = ~0ull, last = 0;
-      for (long i = 0; i < grid; i++) {
-        const unsigned long long b = h[2 * grid + 2 * i], ls = h[2 * grid + 2 * i + 1], e = h[4 * grid + i], le = ls + h[2 * i + 1];
-        pro += (double)(ls - b); epi += (double)(e - le); life += (double)(e - b);
+    if (!ghz.empty()) printf("MXA_DIAG k_gemm<%d,%d,%d>: %ld pieces on %ld workgroups (splits %d = %d x %d + short x %d), in-kernel clock median %.3f GHz (min %.3f max %.3f); shader cycles per slab median %.0f (ideal %d)\n",
+                             A, C, MODE, nunits, grid, p.splits, p.s1, p.l1, p.l2, ghz[ghz.size() / 2], ghz.front(), ghz.back(), cyc[cyc.size() / 2], kSlabSteps * A * C * 16 * 2);
+    double ticks = 0.0;   // 100 MHz ticks spent inside the K loops, summed over the pieces
+    for (long i = 0; i < nunits; i++) ticks += (double)h[2 * i + 1];
+    printf("MXA_DIAG k_gemm: K loops of all pieces = %.3f ms if packed perfectly on %ld resident slots (compare with the kernel duration)\n", ticks * 1e-5 / (double)grid, grid);
+    {   // piece lifetimes (100 MHz real-time counter): begin -> end, and where the resident slots stand idle
+      double life = 0; unsigned long long first = ~0ull, last = 0;
+      for (long i = 0; i < nunits; i++) {
+        const unsigned long long b = h[2 * nunits + 2 * i], e = h[4 * nunits + i];
+        life += (double)(e - b);
         first = std::min(first, b); last = std::max(last, e);
       }
-      printf("MXA_DIAG k_gemm: per workgroup mean prologue %.2f us, epilogue %.2f us, lifetime %.1f us; grid span %.3f ms; sum of lifetimes / 512 = %.3f ms\n",
-             pro / grid * 1e-2, epi / grid * 1e-2, life / grid * 1e-2, (double)(last - first) * 1e-5, life * 1e-5 / 512.0);
+      printf("MXA_DIAG k_gemm: mean piece lifetime %.1f us; span first begin -> last end %.3f ms; sum of lifetimes / slots = %.3f ms\n",
+             life / nunits * 1e-2, (double)(last - first) * 1e-5, life * 1e-5 / (double)grid);
+      std::vector<std::pair<unsigned long long, int>> ev;
+      ev.reserve(2 * nunits);
+      for (long i = 0; i < nunits; i++) { ev.emplace_back(h[2 * nunits + 2 * i], +1); ev.emplace_back(h[4 * nunits + i], -1); }
+      std::sort(ev.begin(), ev.end());
+      const unsigned long long win = 200000;   // 2 ms in 100 MHz ticks
+      double idle[3] = {0, 0, 0}; long active = 0, max_active = 0; unsigned long long prev_t = first;
+      for (auto &e : ev) {
+        unsigned long long t0 = prev_t, t1 = e.first;
+        while (t0 < t1) {   // split the interval at the window borders
+          const int zone = t0 < first + win ? 0 : (t0 >= last - win ? 2 : 1);
+          const unsigned long long border = zone == 0 ? first + win : (zone == 1 ? last - win : last);
+          const unsigned long long te = std::min(t1, std::max(border, t0 + 1));
+          idle[zone] += (double)(te - t0) * (double)(grid - std::min(active, grid));
+          t0 = te;
+        }
+        active += e.second; max_active = std::max(max_active, active); prev_t = e.first;
+      }
+      printf("MXA_DIAG k_gemm: idle slot-time first 2 ms %.3f ms, middle %.3f ms, last 2 ms %.3f ms; max pieces in flight %ld\n",
+             idle[0] * 1e-5 / (double)grid, idle[1] * 1e-5 / (double)grid, idle[2] * 1e-5 / (double)grid, max_active);
     }
     (void)hipFree(d_diag);
     return 0;
   }
   hipLaunchKernelGGL((k_gemm<A, C, MODE>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBp, p.n_pad / 4, dP,
-                     p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, p.slabs_per_split, xcd_order, nullptr, split_begin, run_if_set);
+                     p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, ks, xcd_order, (unsigned long long *)nullptr, split_begin, run_if_set, (int)nunits, d_ctr, g8);
   MXA_HIP(hipGetLastError());
   return 0;
 }
 
-int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, int mode, hipStream_t s, int split_begin, int split_end, const int *run_if_set) {
+int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, int mode, hipStream_t s, int *d_ctr, int split_begin, int split_end,
+                const int *run_if_set) {
   if (split_end < 0) split_end = p.splits;
   // host-side shape checks: the kernel reads rows [0, m_pad) x [0, slabs_total*32) bytes and Bp[(k_pad/16)][H][64]
   if (p.m_pad > G.rows_pad || (size_t)p.slabs_total * kSlabBytes > G.pitch) {
@@ -564,9 +706,10 @@ int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const Gemm
   }
 #define MXA_DISPATCH(AA, CC)                                              \
   if (p.a == AA && p.c == CC) {                                           \
-    if (mode == 1) return launch_gemm_t<AA, CC, 1>(G, dBp, dP, p, s, split_begin, split_end, nullptr);     \
-    if (mode == 2) return launch_gemm_t<AA, CC, 2>(G, dBp, dP, p, s, split_begin, split_end, nullptr);     \
-    return launch_gemm_t<AA, CC, 0>(G, dBp, dP, p, s, split_begin, split_end, run_if_set);                 \
+    if (mode == 1) return launch_gemm_t<AA, CC, 1>(G, dBp, dP, p, s, split_begin, split_end, nullptr, d_ctr);     \
+    if (mode == 2) return launch_gemm_t<AA, CC, 2>(G, dBp, dP, p, s, split_begin, split_end, nullptr, d_ctr);     \
+    if (mode == 3) return launch_gemm_t<AA, CC, 3>(G, dBp, dP, p, s, split_begin, split_end, nullptr, d_ctr);     \
+    return launch_gemm_t<AA, CC, 0>(G, dBp, dP, p, s, split_begin, split_end, run_if_set, d_ctr);                 \
   }
   MXA_DISPATCH(16, 1)
   MXA_DISPATCH(16, 2)
@@ -749,6 +892,7 @@ GemmPlan plan_lut(long m, long k_pad, int n) {
   long splits = std::max<long>(1, std::min<long>(want, max_splits));
   p.slabs_per_split = (int)((p.slabs_total + splits - 1) / splits);
   p.splits = (p.slabs_total + p.slabs_per_split - 1) / p.slabs_per_split;
+  p.s1 = p.splits; p.l1 = p.l2 = p.slabs_per_split;
   return p;
 }
 
