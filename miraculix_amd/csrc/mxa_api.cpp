@@ -360,7 +360,8 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     h->prof_slot = slot ^ 1;
   }
   hipEvent_t pe0 = prof ? h->ev0[slot] : nullptr, pe1 = prof ? h->ev1[slot] : nullptr;
-  if (centered && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
+  const bool auto_i8_pre = engine == 0 && n <= 2 && k >= 128;   // that route computes the column sums in its own statistics pass
+  if (centered && !auto_i8_pre && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
   // Engine 0 at n <= 2 (the CG / GBLUP iteration, HBM-bound): the exact int8 slicing is used WHEN IT IS EXACT -- every column of B
   // finite with an exponent span that fits its 32 (n = 1) / 16 (n = 2) digits, checked on the device per call (gemm_i8_device,
   // guard).  Then B is represented without any error, all dot products are exact integers and the only roundings are the S - 1
@@ -373,7 +374,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     // auto_i8: the verdict of the exactness check stays on the device (guard = 2) -- the int8 chain and the fp64 fallback are both enqueued and
     // test the flag themselves, so the product has no host round trip in its middle (44 us of a 1.2 ms product in the kernel timeline)
     const int rc8 = gemm_i8_device(G, trans, n, dB, ldb, dC, ldc, fill_rows, centered, d_sumB, d_sumfB, h->d_f, w, s, pe0, pe1,
-                                   &splits8, auto_i8 ? 2 : 0, &d_flag);
+                                   &splits8, auto_i8 ? 2 : 0, &d_flag, auto_i8 ? w.d_colpart : nullptr);
     if (rc8 == 0 || rc8 == 3) {
       if (rc8 == 3) {   // fp64 pair tables, run only if the flag is set
         const GemmPlan pl = plan_lut(m, G.k_pad, n);

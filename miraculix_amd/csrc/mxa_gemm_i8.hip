@@ -77,9 +77,76 @@ __device__ __forceinline__ unsigned int digit_of(const Digits9 &d, int S, int s)
   return i < 8 ? (unsigned int)(d.lo >> (8 * i)) & 0xffu : d.hi;
 }
 
+// One pass over B for everything the guarded n <= 2 route needs to know about its columns (round 3; was four launches): per chunk c of a column
+// the largest |entry| (inf if a non-finite one was seen), the smallest non-zero |entry|, and -- when centring -- sum b and sum f b.
+// part[j*64 + c] = max, part[(n + j)*64 + c] = min; sums[(j*64 + c)*2 + {0, 1}].  Fixed thread -> row assignment and fixed trees: deterministic.
+__global__ void __launch_bounds__(256) k_colstats_partial(const double *__restrict__ B, long ldb, long k, int n, const double *__restrict__ f, int want_sums,
+                                                          double *__restrict__ part, double *__restrict__ sums) {
+  const int j = blockIdx.y, c = blockIdx.x;
+  const long per = (k + 63) / 64;
+  const long c0 = c * per, c1 = c0 + per < k ? c0 + per : k;
+  const double inf = __longlong_as_double(0x7ff0000000000000ll);
+  double mx = 0.0, lo = inf, s1 = 0.0, s2 = 0.0;
+  for (long r = c0 + threadIdx.x; r < c1; r += 256) {
+    const double b = B[r + (long)j * ldb], a = fabs(b);
+    mx = (a <= 1.7976931348623157e308) ? fmax(mx, a) : inf;   // NaN counts as non-finite too (fmax would drop it)
+    if (a > 0.0) lo = fmin(lo, a);
+    if (want_sums) { s1 += b; if (f) s2 = fma(f[r], b, s2); }
+  }
+  __shared__ double sh[4][256];
+  sh[0][threadIdx.x] = mx; sh[1][threadIdx.x] = lo; sh[2][threadIdx.x] = s1; sh[3][threadIdx.x] = s2;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      sh[0][threadIdx.x] = fmax(sh[0][threadIdx.x], sh[0][threadIdx.x + w]); sh[1][threadIdx.x] = fmin(sh[1][threadIdx.x], sh[1][threadIdx.x + w]);
+      sh[2][threadIdx.x] += sh[2][threadIdx.x + w]; sh[3][threadIdx.x] += sh[3][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[(size_t)j * 64 + c] = sh[0][0]; part[((size_t)n + j) * 64 + c] = sh[1][0];
+    if (want_sums) { sums[((size_t)j * 64 + c) * 2] = sh[2][0]; sums[((size_t)j * 64 + c) * 2 + 1] = sh[3][0]; }
+  }
+}
+
+// fused-final mode of k_slice_B (guarded n <= 2 route): every block derives the column exponents and the verdict of the exactness guard from
+// the partials of k_colstats_partial itself (same data, same order: same answer in every block); block 0 also publishes them -- E, the flag,
+// and the column sums of the centring term -- for the kernels behind it.  The flag is WRITTEN (0 / 1), so nobody has to clear it first.
+struct SliceFused {
+  const double *part; const double *sums;     // part == nullptr: legacy mode (E and the flag come from launch_colexp)
+  int *E_out; int *flag_out; double *sumB, *sumfB;
+  int bias, max_span, min_emax, want_sums;
+};
+
 __global__ void __launch_bounds__(256) k_slice_B(const double *__restrict__ B, long ldb, long k, int n, const int *__restrict__ E, int S, int nc, int NT,
-                                                 long T_total, int ncols, uint32_t *__restrict__ Bs, long total, const int *__restrict__ skip_if_set) {
-  if (skip_if_set && *skip_if_set) return;   // guarded route: B is not exactly representable, the fp64 fallback does this product
+                                                 long T_total, int ncols, uint32_t *__restrict__ Bs, long total, const int *__restrict__ skip_if_set,
+                                                 SliceFused fu) {
+  __shared__ int sE[2], sflag;
+  if (fu.part) {   // n <= 2
+    if (threadIdx.x < 64) {
+      int bad = 0;
+      for (int j = 0; j < n; j++) {
+        double m = fu.part[(size_t)j * 64 + threadIdx.x], lo = fu.part[((size_t)n + j) * 64 + threadIdx.x];
+        double s1 = fu.want_sums ? fu.sums[((size_t)j * 64 + threadIdx.x) * 2] : 0.0, s2 = fu.want_sums ? fu.sums[((size_t)j * 64 + threadIdx.x) * 2 + 1] : 0.0;
+        for (int o = 32; o > 0; o >>= 1) { m = fmax(m, __shfl_xor(m, o)); lo = fmin(lo, __shfl_xor(lo, o)); }
+        if (fu.want_sums && blockIdx.x == 0) {   // chunk sums in ascending chunk order, like k_colsum_final
+          double t1 = 0.0, t2 = 0.0;
+          for (int c = 0; c < 64; c++) { t1 += __shfl(s1, c); t2 += __shfl(s2, c); }
+          if (threadIdx.x == 0) { fu.sumB[j] = t1; fu.sumfB[j] = t2; }
+        }
+        int e = 0;
+        if (m > 0.0 && isfinite(m)) (void)frexp(m, &e);
+        bool ok = isfinite(m);
+        if (ok && m > 0.0) { int el = 0; (void)frexp(lo, &el); ok = e >= fu.min_emax && el >= e - fu.max_span; }
+        if (!ok) bad = 1;
+        if (threadIdx.x == 0) { sE[j] = e + fu.bias; if (blockIdx.x == 0) fu.E_out[j] = e + fu.bias; }
+      }
+      if (threadIdx.x == 0) { sflag = bad; if (blockIdx.x == 0) *fu.flag_out = bad; }
+    }
+    __syncthreads();
+    if (sflag) return;
+    E = sE;
+  } else if (skip_if_set && *skip_if_set) return;   // guarded route: B is not exactly representable, the fp64 fallback does this product
   // one thread per (q, column cj = chunk*nc + jj, h, T): reads the 4 values k = 128(T/4) + 64h + 16(T%4) + 4i + q (i = 0..3), writes dword q of
   // lane (h, col) for each slice.  q runs fastest, then the column: 16-byte lane records and 128-byte runs of doubles.
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -367,56 +434,72 @@ __global__ void __launch_bounds__(256) k_finish_i8(const int *__restrict__ P, lo
 }
 
 
-// n <= 2 (one tile of 32 expanded columns, e = s * nc + jj, nc * S <= 32): 64 rows per workgroup, 32 lanes per row, 8 rows per half-wave
-// with all loads of the 8 rows issued before the first use (the kernel is pure HBM streaming: splits x 128 bytes per row).  Lane e adds its
-// digit's int32 partials of all K splits exactly (int64), scales (exact), and the lanes of a column are added in a fixed butterfly order
-// (log2(S) levels: at most 5 roundings per result, fewer than the S - 1 of a sequential sum).
-constexpr int kFinSmallRows = 8;   // rows per half-wave
+// n <= 2 (one tile of 32 expanded columns, e = s * nc + jj, nc * S <= 32, nc = 1 or 2).  Pure HBM streaming: splits x 128 bytes per row.  Eight
+// threads share a row, each with four digits (one 16-byte load per split -- a wave reads 1 KiB runs); four rows per thread, all their loads
+// issued before the first use.  A thread adds its digits' int32 partials of all K splits exactly (int64), scales them (exact) and adds its four
+// terms smallest scale first; the eight threads of a row are then added in a fixed butterfly (3 levels): at most 6 roundings per result.
+// (Round 2 read 4 bytes per lane: 2.7-3.3 TB/s; 35-47 us of a 1.1 ms product.)
+constexpr int kFinSmallRows = 4;       // rows per thread
+constexpr int kFinSmallBlockRows = 32 * kFinSmallRows;
 __global__ void __launch_bounds__(256) k_finish_i8_small(const int *__restrict__ P, long m_pad, int splits, long m, int n, int S, int nc, const int *__restrict__ E,
                                                          const double *__restrict__ colmax_part, double *__restrict__ Cout, long ldc, long fill_rows, int mode_trans,
                                                          int centered, const double *__restrict__ sumB, const double *__restrict__ sumfB, const double *__restrict__ f,
                                                          const int *__restrict__ skip_if_set) {
   if (skip_if_set && *skip_if_set) return;
-  const int e = threadIdx.x & 31;
-  const long r0 = ((long)blockIdx.x * 8 + (threadIdx.x >> 5)) * kFinSmallRows;
-  const int s = e / nc, jj = e - s * nc;
-  const bool live = e < nc * S;
-  const int sh = live ? E[jj] - 8 * (s + 1) : 0;
-  long long t[kFinSmallRows];
-#pragma unroll
-  for (int i = 0; i < kFinSmallRows; i++) t[i] = 0;
-  // unconditional loads (P has m_pad rows; row indices are clamped, rows >= m are masked below): all 8 x splits loads of a lane are in flight together
+  const int g = threadIdx.x & 7;                                       // digits 4g .. 4g+3 of the row
+  const long rbase = (long)blockIdx.x * kFinSmallBlockRows + (threadIdx.x >> 3);
+  long long t[kFinSmallRows][4];
   long rl[kFinSmallRows];
 #pragma unroll
-  for (int i = 0; i < kFinSmallRows; i++) rl[i] = r0 + i < m_pad ? r0 + i : m_pad - 1;
-  for (int sp = 0; sp < splits; sp++) {
-    const int *Ps = P + (size_t)sp * m_pad * 32 + e;
-    int x[kFinSmallRows];
+  for (int i = 0; i < kFinSmallRows; i++) {
+    const long r = rbase + 32 * i;
+    rl[i] = r < m_pad ? r : m_pad - 1;                                 // clamped loads; rows >= m are masked below
 #pragma unroll
-    for (int i = 0; i < kFinSmallRows; i++) x[i] = Ps[(size_t)rl[i] * 32];
-#pragma unroll
-    for (int i = 0; i < kFinSmallRows; i++) t[i] += x[i];
+    for (int d = 0; d < 4; d++) t[i][d] = 0;
   }
-  bool bad = false;
-  double cs = 0.0;
-  if (e < nc && e < n) {
+  const int4 *P4 = reinterpret_cast<const int4 *>(P);
+  for (int sp = 0; sp < splits; sp++) {
+    int4 x[kFinSmallRows];
+#pragma unroll
+    for (int i = 0; i < kFinSmallRows; i++) x[i] = P4[((size_t)sp * m_pad + rl[i]) * 8 + g];
+#pragma unroll
+    for (int i = 0; i < kFinSmallRows; i++) { t[i][0] += x[i].x; t[i][1] += x[i].y; t[i][2] += x[i].z; t[i][3] += x[i].w; }
+  }
+  // digit e = 4g + d belongs to column jj = e % nc, slice s = e / nc, weight 2^(E_jj - 8(s+1))
+  int sh[4]; bool live[4];
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    const int e = 4 * g + d, sl = e / nc, jj = e - sl * nc;
+    live[d] = e < nc * S;
+    sh[d] = live[d] ? E[jj] - 8 * (sl + 1) : 0;
+  }
+  bool bad[2] = {false, false};
+  double cs[2] = {0.0, 0.0};
+  for (int jj = 0; jj < nc && jj < n; jj++) {
     double cm = 0.0;
-    for (int c = 0; c < 64; c++) cm = fmax(cm, colmax_part[(size_t)e * 64 + c]);
-    bad = !(cm <= 1.7976931348623157e308);   // a column with inf / NaN: NaN, like 0 * inf in fp64
-    if (centered) cs = -2.0 * (mode_trans ? sumB[e] : sumfB[e]);
+    for (int c = 0; c < 64; c++) cm = fmax(cm, colmax_part[(size_t)jj * 64 + c]);
+    bad[jj] = !(cm <= 1.7976931348623157e308);                        // a column with inf / NaN: NaN, like 0 * inf in fp64
+    if (centered) cs[jj] = -2.0 * (mode_trans ? sumB[jj] : sumfB[jj]);
   }
 #pragma unroll
   for (int i = 0; i < kFinSmallRows; i++) {
-    const long r = r0 + i;
-    double v = (live && r < m) ? ldexp((double)t[i], sh) : 0.0;
-    // lanes of one column: e = jj, jj + nc, jj + 2 nc, ...  (nc = 1: all 32 lanes; nc = 2: lanes of equal parity)
-    for (int off = 16; off >= nc; off >>= 1) v += __shfl_xor(v, off, 32);
-    if (e < nc && e < n && r < fill_rows) {
+    const long r = rbase + 32 * i;
+    double v[2] = {0.0, 0.0};
+#pragma unroll
+    for (int d = 3; d >= 0; d--) {                                     // smallest scale first
+      const double term = (live[d] && r < m) ? ldexp((double)t[i][d], sh[d]) : 0.0;
+      if (nc == 1) v[0] += term; else v[d & 1] += term;
+    }
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++)
+      for (int off = 4; off >= 1; off >>= 1) v[jj] += __shfl_xor(v[jj], off, 8);
+    if (g < nc && g < n && r < fill_rows) {
+      double out = v[g];
       if (r < m) {
-        if (bad) v = __longlong_as_double(0x7ff8000000000000ll);
-        if (centered) v = mode_trans ? fma(cs, f[r], v) : v + cs;
-      } else v = 0.0;
-      Cout[r + (long)e * ldc] = v;
+        if (bad[g]) out = __longlong_as_double(0x7ff8000000000000ll);
+        if (centered) out = mode_trans ? fma(cs[g], f[r], out) : out + cs[g];
+      } else out = 0.0;
+      Cout[r + (long)g * ldc] = out;
     }
   }
 }
@@ -442,23 +525,27 @@ static I8Plan plan_i8(long m, long k_pad, int n) {
   p.stages_total = (int)(k_pad / kI8StageK);
   p.T_total = k_pad / 32;
   const long units = (long)p.rowblocks * p.nchunks;
-  long want = (2048 + units - 1) / units;                        // 256 resident workgroups -> >= 8 rounds
+  // K splits.  The kernel runs one workgroup per piece and the hardware keeps as many resident as the LDS allows (NT = 1: four per CU; the
+  // launch is HBM-bound there and more workgroups mean more bytes in flight).  Measured on the config-5 shard (n = 1): what matters is that the
+  // workgroup total fills whole rounds of the resident slots -- 391 row tiles x 5 splits = 1.91 rounds of 1024: 1.08 ms, x 6 = 2.29 rounds:
+  // 1.19 ms -- and, at equal fill, FEWER splits (less partial-sum traffic, fewer prologues): 977 tiles x 3: 1.05 ms, x 7: 1.16 ms.
+  const long lds_wg = 3L * (kI8ABytes + 4L * p.NT * 1024);
+  const long resident = 256L * (p.NT <= 4 ? std::max<long>(1, std::min<long>(4, 163840 / lds_wg)) : 1);
+  long want = (3 * resident / 2 + units - 1) / units;             // at least ~1.5 rounds
   long max_splits = std::max<long>(1, p.stages_total / 32);
   long splits = std::max<long>(1, std::min<long>(want, max_splits));
   {
-    // like plan_gemm: around the target pick the split count whose workgroup total fills whole rounds of the resident slots best (two
-    // workgroups per CU for NT <= 4, else one): 391 row blocks x 6 splits = 4.58 rounds of 512 wastes 8 % of the last round's HBM time
     static const long search = [] { const char *e = getenv("MXA_I8_SPLIT_SEARCH"); return e ? atol(e) : 1L; }();
-    const long resident = p.NT <= 4 ? 512 : 256;
     double best_eff = -1.0;
-    const long lo = splits, hi = std::min<long>(max_splits, splits + splits / 2 + 2);
+    const long lo = splits, hi = std::min<long>(max_splits, splits + 6);
     for (long cand = lo; search && cand <= hi; cand++) {
       const long per = (p.stages_total + cand - 1) / cand, actual = (p.stages_total + per - 1) / per;
       const long wgs = units * actual;
       const double eff = (double)wgs / (double)(resident * ((wgs + resident - 1) / resident));
-      if (eff > best_eff + 0.02) { best_eff = eff; splits = cand; }   // prefer fewer splits unless the fill improves by 2 %
+      if (eff > best_eff + 0.03) { best_eff = eff; splits = cand; }   // prefer fewer splits unless the fill improves by 3 %
     }
   }
+  if (const char *e = getenv("MXA_I8_SPLITS")) splits = std::max<long>(1, std::min<long>(max_splits, atol(e)));   // A/B measurement
   splits = std::max<long>(splits, (p.stages_total + 32767) / 32768);   // int32 accumulators: 2 * 128 * (K per split) < 2^31
   p.stages_per_split = (int)((p.stages_total + splits - 1) / splits);
   p.splits = (p.stages_total + p.stages_per_split - 1) / p.stages_per_split;
@@ -497,9 +584,9 @@ static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const 
 
 // Whole product on the device; B, C device pointers; asynchronous on s.  The workspace (exponents, slices, partials) lives with the
 // handle and only grows.
-int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool centered, const double *d_sumB,
-                   const double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out, int guard,
-                   const int **flag_out) {
+int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool centered, double *d_sumB,
+                   double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out, int guard,
+                   const int **flag_out, double *colsum_scratch) {
   const long m = G.rows, k = G.k;
   const I8Plan p = plan_i8(m, G.k_pad, n);
   if (p.m_pad > G.rows_pad) { set_error(4, "internal: packed matrix smaller than the i8 plan"); return 1; }
@@ -523,6 +610,8 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
 
   // E_j = e + 2: |b| * 2^-E_j < 1/4, inside the remainder range of the balanced digits
   const int *skip = nullptr;   // guard = 2: the kernels below test this device flag themselves
+  bool fused = false;
+  SliceFused fu{};
   if (!guard) {
     if (launch_colexp(dB, ldb, k, n, d_part, d_E, 2, s)) return 1;
   } else {
@@ -532,7 +621,11 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
     // the flag lives in the handle's small flag block (never reallocated while the handle lives: mxa_last_path() may read it later)
     if (!w.d_denflag) { set_error(4, "internal: flag block missing"); return 1; }
     int *d_flag = w.d_denflag + 1, h_flag = 1;
-    if (launch_colexp(dB, ldb, k, n, d_part, d_E, 2, s, d_flag, 8 * p.S - 55, 8 * p.S - 1023)) return 1;
+    fused = guard == 2 && colsum_scratch && n <= 2;
+    if (fused) {   // one statistics pass; exponents, verdict and column sums are finished inside k_slice_B
+      hipLaunchKernelGGL(k_colstats_partial, dim3(64, n), dim3(256), 0, s, dB, ldb, k, n, trans ? nullptr : d_f, centered ? 1 : 0, d_part, colsum_scratch);
+      fu = SliceFused{d_part, colsum_scratch, d_E, d_flag, d_sumB, d_sumfB, 2, 8 * p.S - 55, 8 * p.S - 1023, centered ? 1 : 0};
+    } else if (launch_colexp(dB, ldb, k, n, d_part, d_E, 2, s, d_flag, 8 * p.S - 55, 8 * p.S - 1023)) return 1;
     if (guard == 1) {
       MXA_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
       MXA_HIP(hipStreamSynchronize(s));
@@ -547,7 +640,7 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
     const int ncols = p.nchunks * p.nc;
     const long total = (long)p.T_total * 2 * ncols * 4;
     hipLaunchKernelGGL(k_slice_B, dim3((unsigned)std::min<long>((total + 255) / 256, 256L * 64)), dim3(256), 0, s, dB, ldb, k, n, d_E, p.S, p.nc, p.NT,
-                       p.T_total, ncols, reinterpret_cast<uint32_t *>(d_Bs), total, skip);
+                       p.T_total, ncols, reinterpret_cast<uint32_t *>(d_Bs), total, skip, fu);
   }
   MXA_HIP(hipGetLastError());
   if (ev0) MXA_HIP(hipEventRecord(ev0, s));
@@ -565,7 +658,7 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   if (rc) return rc;
   if (ev1) MXA_HIP(hipEventRecord(ev1, s));
   if (p.nchunks == 1 && p.NT == 1 && p.nc * p.S <= 32 && (p.nc == 1 || p.nc == 2)) {   // n <= 2: one tile, the fast finish
-    hipLaunchKernelGGL(k_finish_i8_small, dim3((unsigned)((fill_rows + 8 * kFinSmallRows - 1) / (8 * kFinSmallRows))), dim3(256), 0, s, d_P, p.m_pad, p.splits, m, n, p.S, p.nc, d_E, d_part, dC, ldc, fill_rows,
+    hipLaunchKernelGGL(k_finish_i8_small, dim3((unsigned)((fill_rows + kFinSmallBlockRows - 1) / kFinSmallBlockRows)), dim3(256), 0, s, d_P, p.m_pad, p.splits, m, n, p.S, p.nc, d_E, d_part, dC, ldc, fill_rows,
                        trans ? 1 : 0, centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip);
   } else {
     dim3 grid((unsigned)((fill_rows + 31) / 32), p.nchunks);

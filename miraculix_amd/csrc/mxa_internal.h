@@ -177,9 +177,12 @@ int launch_colsums(const double *dB, long ldb, long k, int n, const double *d_f 
                    double *d_sumB, double *d_sumfB, hipStream_t s);
 // p_rows: rows per tile of the partial-result array P[split][m_pad / p_rows][n_pad][p_rows] (k_gemm: the workgroup's row block, so a
 // workgroup writes one contiguous chunk; lookup kernel: m_pad, i.e. plain [split][n_pad][m_pad])
-// K splits: [0, s1) are l1 slabs long, [s1, splits) l2 (tapered tail of k_gemm; elsewhere s1 = splits); slabs_per_split = l1
-struct GemmPlan { int a, c, nchunks, n_pad, splits, slabs_per_split, slabs_total, rowblocks; long m_pad; long p_rows; int s1, l1, l2; };
-inline long plan_split_begin(const GemmPlan &p, int sp) { return sp < p.s1 ? (long)sp * p.l1 : (long)p.s1 * p.l1 + (long)(sp - p.s1) * p.l2; }
+// K splits (mxa_queue.h: KSplit): [0, s1) are l1 slabs long, the first r1 of them one more; [s1, splits) exactly l2 (tapered tail of
+// k_gemm; elsewhere s1 = splits, r1 = 0); slabs_per_split = l1
+struct GemmPlan { int a, c, nchunks, n_pad, splits, slabs_per_split, slabs_total, rowblocks; long m_pad; long p_rows; int s1, l1, l2, r1; };
+inline long plan_split_begin(const GemmPlan &p, int sp) {
+  return sp < p.s1 ? (long)sp * p.l1 + (sp < p.r1 ? sp : p.r1) : (long)p.s1 * p.l1 + p.r1 + (long)(sp - p.s1) * p.l2;
+}
 // ksplits_like: take the K pieces of another plan (row ranges of one product: identical sums)
 GemmPlan plan_gemm(long m, long k_pad, int n, const GemmPlan *ksplits_like = nullptr);
 // conversion variant of k_gemm for a tile of c column groups: 2 (v_bfe_u32) or 3 (v_and_b32 + B rows pre-scaled); MXA_GEMM_MODE overrides
@@ -214,8 +217,10 @@ int launch_sparse_times_plink(const uint8_t *dP, size_t pitch, long entries, int
 // and 2 is returned (the caller takes the fp64 path).  guard = 2: no host round trip -- the three kernels of the chain test the device
 // flag themselves and do nothing when it is set; 3 is returned with *flag_out = the device flag, and the caller enqueues the fp64
 // fallback with run_if_set = that flag.
-int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool centered, const double *d_sumB,
-                   const double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out, int guard = 0,
-                   const int **flag_out = nullptr);
+// colsum_scratch (guard = 2, n <= 2 only; 128 n doubles): the column sums of the centring term are computed HERE, in the same pass over B as
+// the exponents and the guard (k_colstats_partial; finished inside k_slice_B) -- the caller must not have launched launch_colsums for them
+int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool centered, double *d_sumB,
+                   double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out, int guard = 0,
+                   const int **flag_out = nullptr, double *colsum_scratch = nullptr);
 
 }  // namespace mxa

@@ -13,6 +13,7 @@
 //
 // gfx950 only; wave64; no CUDA compatibility layer.
 #include "mxa_internal.h"
+#include "mxa_queue.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -282,13 +283,6 @@ struct GemmCfg {
 // MODE 1 63.6 TFLOP/s, MODE 0 69.7 TFLOP/s; with the LDS-DMA addresses computed on the VALU instead of the scalar
 // unit MODE 0 drops to 65.5.  MODE 2 vs MODE 0 at 1M x 50k: n = 32 (C = 8) 17.1k vs 17.3k cycles per slab (+1 %),
 // n = 20 (C = 5) 72.0 vs 68.7 TFLOP/s, n = 10 (C = 3) 56.0 vs 52.0.
-// K splits of a launch plan: splits [0, s1) are l1 slabs long, the rest l2 (the TAPERED TAIL: the last workgroup-sized pieces of a launch are a
-// quarter as long, so that the resident slots run dry within a quarter of a long piece's duration -- measured on C2 with in-kernel stamps
-// (MXA_DIAG): 0.95-1.0 ms of idle slot time in the last 2 ms of a 44.6 ms launch with equal pieces, whatever their length)
-struct KSplit { int s1, l1, l2; };
-__host__ __device__ __forceinline__ int ksplit_begin(const KSplit &ks, int sp) { return sp < ks.s1 ? sp * ks.l1 : ks.s1 * ks.l1 + (sp - ks.s1) * ks.l2; }
-__host__ __device__ __forceinline__ int ksplit_len(const KSplit &ks, int sp) { return sp < ks.s1 ? ks.l1 : ks.l2; }
-
 // PERSISTENT workgroups.  The launch has one workgroup per resident slot (2 per CU); each pulls work pieces "unit" = (row block, column chunk,
 // K split) from queues in device memory until they are empty.  Why (MXA_DIAG stamps, C2): with one workgroup per piece the hardware needs
 // 8-14 us to replace a finished workgroup (0.36-0.42 ms of idle slot time per 44.6 ms launch) and every piece begins with an exposed first
@@ -313,27 +307,10 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // g8 (a multiple of 8, from the launcher): groups dealt to the XCDs whole -- LONG pieces only, the same number for every XCD, so that
-  // the XCD queues hold equal work; the remaining long groups and the short ones (the tapered tail) form the common queue
-  const int n1 = (g8 / 8) * rowblocks;               // pieces in every XCD queue
-  const int n2 = nunits - g8 * rowblocks;            // pieces in the common queue
-  int xcc;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-  xcc &= 7;
-  int phase = 0;                                      // 0 own XCD queue, 1 common queue, 2..8 the other XCDs' queues (only thread 0 uses it)
-  auto fetch = [&]() -> int {
-    while (phase <= 8) {
-      if (phase == 1) {
-        const int t = __hip_atomic_fetch_add(ctr + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t < n2) return g8 * rowblocks + t;
-      } else {
-        const int y = phase == 0 ? xcc : ((xcc + phase - 1) & 7);
-        const int sl = n1 > 0 ? __hip_atomic_fetch_add(ctr + y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : n1;
-        if (sl < n1) return sl * 8 + y;
-      }
-      phase++;
-    }
-    return -1;
-  };
+  // the XCD queues hold equal work; the remaining long groups and the short ones (the tapered tail) form the common queue (mxa_queue.h)
+  PieceQueue q;
+  q.init(ctr, rowblocks, g8, nunits);
+  auto fetch = [&]() -> int { return q.next(); };
 
   // ---- DMA issue for one slab into buffer `buf`.  Every source address is (wave-uniform 64-bit base) + (per-lane 32-bit
   // offset that never changes), so the per-slab address arithmetic is scalar: VALU instructions are expensive beside the
@@ -346,12 +323,11 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
   auto decode = [&](int bid) -> Unit {
     Unit u;
     int grp;
-    if (bid < g8 * rowblocks) { const int xcd = bid & 7, slot = bid >> 3; u.rb = slot % rowblocks; grp = xcd + 8 * (slot / rowblocks); }
-    else { const int t = bid - g8 * rowblocks; u.rb = t % rowblocks; grp = g8 + t / rowblocks; }
+    q.locate(bid, u.rb, grp);
     u.nc = grp % nchunks;
     u.sp = grp / nchunks + split0;                   // split0: first K split of this launch (host-operand pipeline: K ranges as B arrives)
     u.slab0 = ksplit_begin(ks, u.sp);
-    u.slab1 = min(u.slab0 + ksplit_len(ks, u.sp), slabs_total);
+    u.slab1 = u.slab0 + ksplit_len(ks, u.sp);
     const long row0 = (long)u.rb * Cfg::kRowsWG;
     // chunk-major B fragments: the column chunk nc is one contiguous array [S_total][C][64]
     u.Bp_u = reinterpret_cast<const char *>(Bp) + (size_t)u.nc * ((size_t)slabs_total * kSlabSteps * C * 512);
@@ -572,7 +548,7 @@ GemmPlan plan_gemm(long m, long k_pad, int n, const GemmPlan *ksplits_like) {
   p.p_rows = rows_wg;
   p.slabs_total = (int)(k_pad / kSlabK);
   if (ksplits_like) {   // the same K pieces as another plan (row-range launches of the host-operand pipeline: identical sums)
-    p.splits = ksplits_like->splits; p.s1 = ksplits_like->s1; p.l1 = ksplits_like->l1; p.l2 = ksplits_like->l2; p.slabs_per_split = ksplits_like->slabs_per_split;
+    p.splits = ksplits_like->splits; p.s1 = ksplits_like->s1; p.l1 = ksplits_like->l1; p.l2 = ksplits_like->l2; p.r1 = ksplits_like->r1; p.slabs_per_split = ksplits_like->slabs_per_split;
     return p;
   }
   // K pieces.  The persistent workgroups (launch_gemm_t) pull pieces = (row block, column chunk, K split) from queues, so what matters is
@@ -587,20 +563,13 @@ GemmPlan plan_gemm(long m, long k_pad, int n, const GemmPlan *ksplits_like) {
   const double slab_us = (double)kSlabSteps * p.a * p.c * 16.0 * gemm_wg_per_cu(p.c) / 2390.0;
   long l1 = std::max<long>(8, std::min<long>(p.slabs_total, (long)(piece_us / slab_us + 0.5)));
   while (l1 > 16 && units * ((p.slabs_total + l1 - 1) / l1) < 6 * resident) l1 = l1 * 3 / 4;   // at least ~6 rounds of pieces: the queues balance the slots
-  long s1 = (p.slabs_total + l1 - 1) / l1, l2 = l1;
-  l1 = (p.slabs_total + s1 - 1) / s1;                       // equal pieces
-  s1 = (p.slabs_total + l1 - 1) / l1;
-  p.splits = (int)s1;
-  const long lt = tail_us > 0 ? std::max<long>(8, (long)(tail_us / slab_us + 0.5)) : l1;
-  if (lt * 2 <= l1 && units * s1 >= 3 * resident) {
-    const long s2 = std::max<long>(1, (5 * resident / 2 + units - 1) / units);         // short splits: about 2.5 rounds of short pieces
-    const long tail = std::min<long>(s2 * lt, p.slabs_total / 2);
-    const long s1n = std::max<long>(1, (p.slabs_total - tail + l1 - 1) / l1);          // long splits cover the rest ...
-    const long l1n = (p.slabs_total - tail + s1n - 1) / s1n;                            // ... in equal pieces
-    const long rest = p.slabs_total - s1n * l1n;
-    if (rest > 0 && l1n >= 2 * lt) { s1 = s1n; l1 = l1n; l2 = lt; p.splits = (int)(s1 + (rest + lt - 1) / lt); }
-  }
-  p.s1 = (int)s1; p.l1 = (int)l1; p.l2 = (int)l2;
+  const long lt = tail_us > 0 ? std::max<long>(8, (long)(tail_us / slab_us + 0.5)) : 0;
+  const bool taper = lt > 0 && units * ((p.slabs_total + l1 - 1) / l1) >= 3 * resident;
+  const long tail = taper ? lt * std::max<long>(1, (5 * resident / 2 + units - 1) / units) : 0;   // short splits: about 2.5 rounds of short pieces
+  KSplit ks;
+  p.splits = ksplit_make(ks, p.slabs_total, l1, lt, tail);
+  p.s1 = ks.s1; p.l1 = ks.l1; p.r1 = ks.r1; p.l2 = ks.l2;
+  l1 = ks.l1;
   p.slabs_per_split = (int)l1;
   if (p.splits < 1) p.splits = 1;
   return p;
@@ -629,7 +598,7 @@ static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, c
   }
   const long grid = std::min<long>(nunits, per_cu[dev & 63]);
   static const int xcd_order = [] { const char *e = getenv("MXA_XCD_ORDER"); return e ? atoi(e) : 1; }();   // 0: one queue in plain order (A/B measurement)
-  const KSplit ks{p.s1, p.l1, p.l2};
+  const KSplit ks{p.s1, p.l1, p.r1, p.l2};
   const int long_groups = (std::min(split_end, p.s1) - std::min(split_begin, p.s1)) * p.nchunks;
   const int g8 = xcd_order ? (long_groups & ~7) : 0;
   MXA_HIP(hipMemsetAsync(d_ctr, 0, 9 * sizeof(int), s));
@@ -648,7 +617,7 @@ static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, c
     std::vector<double> ghz, cyc;
     for (long i = 0; i < nunits; i++) if (h[2 * i + 1]) {
       const int sp = (int)(i < (long)g8 * p.rowblocks ? ((i & 7) + 8 * ((i >> 3) / p.rowblocks)) / p.nchunks : (i / p.rowblocks) / p.nchunks);
-      const int len = sp < p.s1 ? p.l1 : p.l2;
+      const int len = ksplit_len(ks, sp);
       ghz.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1); cyc.push_back((double)h[2 * i] / len);
     }
     std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end());
@@ -892,7 +861,7 @@ GemmPlan plan_lut(long m, long k_pad, int n) {
   long splits = std::max<long>(1, std::min<long>(want, max_splits));
   p.slabs_per_split = (int)((p.slabs_total + splits - 1) / splits);
   p.splits = (p.slabs_total + p.slabs_per_split - 1) / p.slabs_per_split;
-  p.s1 = p.splits; p.l1 = p.l2 = p.slabs_per_split;
+  p.s1 = p.splits; p.l1 = p.l2 = p.slabs_per_split; p.r1 = 0;
   return p;
 }
 
