@@ -268,7 +268,7 @@ int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink
 // 100 MB download takes 1.8 ms this way and 7.7 ms as one 1-D copy per column).  Exception: strided DOWNLOADS issued by the shard worker
 // threads of a multi-device object go column by column.  hipMemcpy2DAsync to pageable host memory issued from several threads at the same
 // time leaves device memory behind on ROCm 7.2 (0.2-0.6 MiB per shard and object life cycle; not with HIP_LAUNCH_BLOCKING=1, not from a
-// single thread, not with 1-D copies: tools/leak_probe*.py, tools/soak_lifecycle.py), and a long-lived session must not creep.
+// single thread, not with 1-D copies: tools/soak_lifecycle.py), and a long-lived session must not creep.
 // MXA_COPY_COLUMNS=1 forces the per-column form everywhere, =2 a synchronous hipMemcpy2D (diagnosis).
 static thread_local bool tl_concurrent = false;
 void mark_thread_concurrent() { tl_concurrent = true; }

@@ -71,3 +71,38 @@ def test_fp4_engine_exact_next_to_its_limit():
     sub = Xd[:40].cpu().numpy()
     ref = o.crossprod_i32(sub, k, True).astype(np.float64)
     assert np.array_equal(M[:40, :40].cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("plink,k_below,k_above", [(True, 4_194_300, 4_194_304), (False, 1_864_132, 1_864_136)])
+def test_fp4_threshold_boundaries_bit_exact(plink, k_below, k_above):
+    """The exactness claim of the FP4 engine rests on the fp32 accumulator of v_mfma_scale_f32_32x32x64_f8f6f4 carrying every quarter unit
+    up to 2^24 of them.  Probed at the boundary itself: rows that are the largest value throughout (PLINK 11 = 2 without a 3 in the
+    matrix: limit 4 K < 2^24; raw 3s: limit 9 K < 2^24) except for a few 1s at the very END of K, so that single quarter units (1 x 1 / 4)
+    are added when the running sum already sits at the top of the 24-bit range; plus random rows.  Just below each limit the default
+    engine (FP4) must agree with the int8 engine and the closed form bit for bit; just above it the default must still be exact (it has
+    switched to int8)."""
+    rows = 256
+    big = 0xFF                                         # PLINK: four codes 11 (value 2); raw: four 3s
+    one = 0xAA if plink else 0x55                      # PLINK 10 -> 1; raw 01 -> 1
+    top, lo = (2, 1) if plink else (3, 1)
+    for k, below in ((k_below, True), (k_above, False)):
+        assert (top * top * k < 2 ** 24) == below
+        rng = np.random.default_rng(k)
+        X = rng.integers(0, 256, size=(rows, k // 4), dtype=np.uint8)
+        if plink:                                      # no missing code 01 anywhere: the staged matrix holds no 3
+            miss = (X & 0x55) & ~((X >> 1) & 0x55)
+            X ^= miss
+        X[:4] = big
+        X[1, -2:] = one                                # row 1: the last 8 values are 1
+        X[2, -1] = one                                 # row 2: the last 4
+        X[3, -3:] = one
+        got = _xprod(X, k, rows, plink)
+        ref8 = _xprod(X, k, rows, plink, env="i8")
+        assert np.array_equal(got, ref8), (k, "default engine vs int8 engine")
+        # closed forms of the top-left 4 x 4 block: (k - c) values `top`, c values `lo` at the end
+        ones = [0, 8, 4, 12]
+        for a in range(4):
+            for b in range(4):
+                both = min(ones[a], ones[b]); either = max(ones[a], ones[b])
+                want = top * top * (k - either) + top * lo * (either - both) + lo * lo * both
+                assert got[a, b] == float(want), (k, a, b)
