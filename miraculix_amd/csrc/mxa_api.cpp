@@ -466,6 +466,8 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
   if (!enabled || (engine != 0 && engine != 3) || n < 3 || getenv("MXA_DIAG")) return 2;
   const PackedMatrix &G = trans ? h->snp_major : h->ind_major;
   const long m = G.rows, k = G.k;
+  // b_host / c_host: the operand is not memory of this device -- host memory (PCIe) or memory of another GPU (peer copies over xGMI):
+  // either way its transfer is hidden behind the product
   const size_t b_bytes = b_host ? sizeof(double) * (size_t)k * n : 0, c_bytes = c_host ? sizeof(double) * (size_t)m * n : 0;
   if (std::max(b_bytes, c_bytes) < kPipeMinBytes) return 2;
   const bool kmode = b_bytes >= c_bytes;
@@ -606,8 +608,8 @@ int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, double *C,
   const bool b_local = ptr_location(B, &b_devno) == 1 && b_devno == h->device;
   const bool c_local = ptr_location(C, &c_devno) == 1 && c_devno == h->device;
   if (b_devno >= 0 && !b_local && sync_foreign_producer(b_devno)) return 1;   // B may still be being produced on the other device's default stream
-  if (sync && (b_devno < 0 || c_devno < 0)) {   // a host operand on a synchronous call: transfers hidden behind the product when they are large
-    const int rcp = gemm_host_pipelined(h, trans, n, B, ldb, b_devno < 0, b_local, C, ldc, c_devno < 0, c_local, fill_rows);
+  if (sync && (!b_local || !c_local)) {   // an operand in host memory or on another GPU, synchronous call: transfers hidden behind the product when they are large
+    const int rcp = gemm_host_pipelined(h, trans, n, B, ldb, !b_local, b_local, C, ldc, !c_local, c_local, fill_rows);
     if (rcp != 2) return rcp;
   }
   const double *dB = B; long dldb = ldb;

@@ -598,8 +598,11 @@ static int multi_product(Multi *m, bool trans, int n, const double *B, const dou
       const double *Bg = per_shard ? (Bs[g] ? Bs[g] : Bs[0]) : B;
       double *Cg = per_shard ? Cs[g] : C + S.begin;
       const long fill = per_shard ? rows : (g == G - 1 ? ldc - S.begin : rows);
-      const bool host_op = ptr_location(Bg, nullptr) == 0 || ptr_location(Cg, nullptr) == 0;
-      if (gemm_any(S.h, true, n, Bg, ldb, Cg, ldc, fill, sync || host_op, true)) return 1;
+      // an operand in host memory or on another GPU: synchronous inside the shard's own worker thread, so that a big one travels in row
+      // ranges behind the product (gemm_host_pipelined)
+      int bd = -1, cd = -1;
+      const bool remote_op = ptr_location(Bg, &bd) == 0 || bd != S.h->device || ptr_location(Cg, &cd) == 0 || cd != S.h->device;
+      if (gemm_any(S.h, true, n, Bg, ldb, Cg, ldc, fill, sync || remote_op, true)) return 1;
       return 0;
     });
   } else {
@@ -610,9 +613,11 @@ static int multi_product(Multi *m, bool trans, int n, const double *B, const dou
       // the previous reduction has read this shard's partial (and its landing buffer) before the product overwrites it
       if (m->red_recorded) MXA_HIP(hipStreamWaitEvent(S.h->stream, m->ev_red1, 0));
       const double *Bg = per_shard ? Bs[g] : B + S.begin;
-      // a host B: synchronous inside the shard's own worker thread, so that a big one is uploaded in K ranges behind the product (gemm_host_pipelined)
-      const bool host_op = ptr_location(Bg, nullptr) == 0;
-      if (gemm_any(S.h, false, n, Bg, ldb, S.d_part, indiv, indiv, host_op, true)) return 1;
+      // a B in host memory or on another GPU: synchronous inside the shard's own worker thread, so that a big one arrives in K ranges behind
+      // the product (gemm_host_pipelined)
+      int bd = -1;
+      const bool remote_op = ptr_location(Bg, &bd) == 0 || bd != S.h->device;
+      if (gemm_any(S.h, false, n, Bg, ldb, S.d_part, indiv, indiv, remote_op, true)) return 1;
       return publish_partial(m, g, indiv, n, !m->use_rccl);
     });
     if (!rc) rc = multi_reduce(m, indiv, n, per_shard ? Cs[0] : C, ldc, sync);

@@ -214,6 +214,14 @@ def test_two_physical_devices(mx):
             Bhub = (torch.from_numpy(BN).to(devs[1]) + x[0, 0] * 0).t()
         hub = dg.dgemm_compressed_main(False, obj, Bhub, snps, indiv)
         assert np.array_equal(hub.cpu().numpy(), plainN)
+        # a hub operand large enough for the K-range pipeline (> 32 MB): it streams from device 1 over xGMI behind the products of both shards
+        n_big = 128
+        BNb = make_B(snps, n_big, seed=5)
+        with torch.cuda.device(1):
+            Bbig = torch.from_numpy(BNb).to(devs[1]).t()
+        big_hub = dg.dgemm_compressed_main(False, obj, Bbig, snps, indiv)
+        big_host = dg.dgemm_compressed_main(False, obj, np.asfortranarray(BNb.T), snps, indiv)
+        assert np.array_equal(big_hub.cpu().numpy(), big_host)
         # RCCL with two ranks, cross-checked against the peer-to-peer reduction on its first product
         assert dg.multi_set_reduction(obj, "rccl") is True
         rc = dg.dgemm_compressed_main(False, obj, np.asfortranarray(BN.T), snps, indiv)
