@@ -562,6 +562,11 @@ GemmPlan plan_gemm(long m, long k_pad, int n, const GemmPlan *ksplits_like) {
   const long resident = gemm_wg_per_cu(p.c) * device_cus();
   const double slab_us = (double)kSlabSteps * p.a * p.c * 16.0 * gemm_wg_per_cu(p.c) / 2390.0;
   long l1 = std::max<long>(8, std::min<long>(p.slabs_total, (long)(piece_us / slab_us + 0.5)));
+  // ... and no longer than the K range whose B slabs (C x 4 KiB per slab, streamed by every piece of a group) stay in one XCD's 4 MiB L2 next to
+  // the packed rows passing through: 3 MiB.  Measured at C2 (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE per launch): pieces of 1.5 ms (214 / 181 slabs,
+  // 6.8 / 5.8 MB of B) 25.3 GB, pieces of 0.66 ms (96 slabs, 3 MB) 18.9 GB against 12.8 GB algorithmic, for 0.3 % of the time.
+  static const long b_l2_bytes = [] { const char *e = getenv("MXA_GEMM_B_L2_BYTES"); return e ? atol(e) : 3L << 20; }();
+  if (b_l2_bytes > 0) l1 = std::max<long>(8, std::min<long>(l1, b_l2_bytes / ((long)p.c * 4096)));
   while (l1 > 16 && units * ((p.slabs_total + l1 - 1) / l1) < 6 * resident) l1 = l1 * 3 / 4;   // at least ~6 rounds of pieces: the queues balance the slots
   const long lt = tail_us > 0 ? std::max<long>(8, (long)(tail_us / slab_us + 0.5)) : 0;
   const bool taper = lt > 0 && units * ((p.slabs_total + l1 - 1) / l1) >= 3 * resident;
