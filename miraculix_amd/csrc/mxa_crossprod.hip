@@ -10,7 +10,7 @@
 //                   instruction runs at twice the int8 rate (tools/mfma_f4_probe.hip: exact, 32.8 cycles, 8.3 Pop/s bare loop).
 //                   Products are multiples of 1/4; the fp32 accumulator is exact while sum z z' < 2^24, i.e. for K < 1 864 135 with
 //                   values up to 3 and K < 4 194 304 when the staged matrix holds no 3 (checked while staging).
-//   k_crossprod2    (longer K)  v_mfma_i32_32x32x32_i8, 7 VALU per 16 values, exact int32 for K < 2.3e8.
+//   k_crossprod_i8  (longer K)  v_mfma_i32_32x32x32_i8, 7 VALU per 16 values, exact int32 for K < 2.3e8; the same K-step pipeline.
 #include "../../include/miraculix_amd.h"
 #include "mxa_internal.h"
 #include <atomic>
@@ -121,131 +121,16 @@ __device__ __forceinline__ void xprod_store(const AccT (&acc)[4][4], char *smem,
     }
 }
 
-// 4 waves, one per SIMD, wave tile 128 x 128 (16 accumulator tiles = 256 registers), 3-deep LDS-DMA ring with a counted vmcnt.
-// Per K-step of 32 genotypes a wave unpacks 8 fragments (56 VALU) for 16 MFMAs (512 MFMA cycles).  (The first version used 8
-// waves with 128 x 64 wave tiles -- 6 fragments per 8 MFMAs -- and stalled at 43-54 % of the int8 peak on that VALU density.)
-constexpr int kX2Bufs = 3;
-constexpr int kX2Lds = kX2Bufs * kXBufBytes;      // 48 KiB
-
+// Both engines: 4 waves, one per SIMD, wave tile 128 x 128 (16 accumulator tiles = 256 registers), one workgroup per CU.  (History: 8 waves with
+// 128 x 64 wave tiles stalled at 43-54 % of the int8 peak on their unpack VALU density; the round-1/2 int8 kernel k_crossprod2 -- 3-deep ring, the
+// packed words of a whole stage prefetched mid-stage -- ran 2704 cycles per stage of 2048 ideal at 2.38 GHz, issue-bound; round 3 moved the int8
+// engine onto the FP4 kernel's K-step pipeline below: 2272 cycles at 2.19 GHz, now power-bound like the FP4 engine.)
 __device__ __forceinline__ void xdma16_s(const void *sbase, uint32_t voff, uint32_t lds_addr) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
 }
 
-template <bool DIAG>
-__global__ void __launch_bounds__(256, 1)
-k_crossprod2(const uint8_t *__restrict__ X, long nslabs, int stages, const int4 *__restrict__ tiles, long n, double *__restrict__ ans,
-             long ld, long c0, unsigned long long *__restrict__ diag) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wi = wave >> 1, wj = wave & 1;      // wave tile: rows [128*wi, +128) of the I block x rows [128*wj, +128) of the J block
-  const int4 t = tiles[blockIdx.x];             // (I tile, J tile, images to store: 1 = M[gj, gi] "direct", 2 = M[gi, gj] "mirror")
-  if (t.z == 0) return;                         // padding entry of the XCD-aware tile order (whole workgroup, before any barrier)
-  const long i0 = (long)t.x * kXT, j0 = (long)t.y * kXT;
-  const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
-  const uint32_t v_lane = (uint32_t)lane * 16;
-  // tiled layout: the 256 rows of operand block t at stage s are the contiguous 8 KiB tile (t, s): lane-linear 1 KiB DMA units
-  const char *XI = reinterpret_cast<const char *>(X) + (size_t)t.x * nslabs * kTileBytes;
-  const char *XJ = reinterpret_cast<const char *>(X) + (size_t)t.y * nslabs * kTileBytes;
-
-  // 16 units of 1 KiB per stage (8 per operand), 4 per wave: unit u = wave + 4*i
-  auto issue = [&](int stage, int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int u = wave + 4 * i;
-      const int op = u >> 3, uu = u & 7;
-      xdma16_s((op ? XJ : XI) + (size_t)stage * kTileBytes + uu * 1024, v_lane, lds0 + buf * kXBufBytes + op * kXOpBytes + uu * 1024);
-    }
-  };
-
-  v16i acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; a++)
-#pragma unroll
-    for (int b = 0; b < 4; b++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[a][b][r] = 0;
-
-  const int a_off = (wi * 128 + (lane & 31)) * kXStageBytes + (lane >> 5) * 16;
-  const int b_off = kXOpBytes + (wj * 128 + (lane & 31)) * kXStageBytes + (lane >> 5) * 16;
-
-  // Software pipeline over stages (ring of 3 LDS buffers, packed words of the NEXT stage prefetched into registers):
-  //   mid-stage s:  wait until stage s+1 has landed (vmcnt leaves only the 4 DMAs of stage s+2 in flight) -> barrier ->
-  //                 issue stage s+3 into buffer s%3 (its words are already in registers) -> ds_read the words of stage s+1
-  //   so neither the DMA latency nor the LDS read latency nor the first unpack is exposed at a stage boundary.
-  issue(0, 0);
-  if (stages > 1) issue(1, 1);
-  if (stages > 2) issue(2, 2);
-  if (stages > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (stages > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  unsigned long long t0 = 0, r0 = 0;   // DIAG instantiation only: shader-clock / 100 MHz stamps around the K loop
-  if (DIAG) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
-  uint4 aw[4], bw[4], awn[4], bwn[4];
-#pragma unroll
-  for (int a = 0; a < 4; a++) aw[a] = *reinterpret_cast<const uint4 *>(smem + a_off + a * 32 * kXStageBytes);
-#pragma unroll
-  for (int b = 0; b < 4; b++) bw[b] = *reinterpret_cast<const uint4 *>(smem + b_off + b * 32 * kXStageBytes);
-#pragma unroll
-  for (int a = 0; a < 4; a++) { awn[a] = aw[a]; bwn[a] = bw[a]; }
-  int buf = 0;   // buffer of stage s
-  auto comp = [](const uint4 &w, int c) -> uint32_t { return c == 0 ? w.x : c == 1 ? w.y : c == 2 ? w.z : w.w; };
-  // The unpack VALU (7 per fragment, 56 per K-step of 16 MFMAs) are software-pipelined one fragment ahead and spread into the
-  // MFMA gaps: measured with one wave per SIMD (tools/mfma_i8_probe2.hip) 3-4 VALU placed after each MFMA cost ~15 %, the same
-  // VALU clustered in front of a group of 4 MFMAs cost 70 %.
-  v4i af_cur = unpack16(aw[0].x), bf_cur[4], bf_nxt[4];
-#pragma unroll
-  for (int b = 0; b < 4; b++) bf_cur[b] = unpack16(bw[b].x);
-  for (int s = 0; s < stages; s++) {
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-      if (ks == 2 && s + 1 < stages) {
-        // mid-stage: stage s+1 must have landed; the 4 DMAs of stage s+2 (if issued) may stay in flight
-        if (s + 2 < stages) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (s + 3 < stages) issue(s + 3, buf);
-        const int nb = buf == 2 ? 0 : buf + 1;
-        const char *base = smem + nb * kXBufBytes;
-#pragma unroll
-        for (int a = 0; a < 4; a++) awn[a] = *reinterpret_cast<const uint4 *>(base + a_off + a * 32 * kXStageBytes);
-#pragma unroll
-        for (int b = 0; b < 4; b++) bwn[b] = *reinterpret_cast<const uint4 *>(base + b_off + b * 32 * kXStageBytes);
-        buf = nb;
-      }
-#pragma unroll
-      for (int a = 0; a < 4; a++) {
-        // fragments needed next: A of (ks, a+1) or of (ks+1, 0); B fragment a of K-step ks+1 (next stage's first K-step after ks = 3)
-        const uint32_t wa = a < 3 ? comp(aw[a + 1], ks) : (ks < 3 ? comp(aw[0], ks + 1) : awn[0].x);
-        const uint32_t wb = ks < 3 ? comp(bw[a], ks + 1) : bwn[a].x;
-        const v4i af_nxt = unpack16(wa);
-        bf_nxt[a] = unpack16(wb);
-#pragma unroll
-        for (int b = 0; b < 4; b++) acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af_cur, bf_cur[b], acc[a][b], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        af_cur = af_nxt;
-      }
-#pragma unroll
-      for (int b = 0; b < 4; b++) bf_cur[b] = bf_nxt[b];
-    }
-#pragma unroll
-    for (int a = 0; a < 4; a++) { aw[a] = awn[a]; bw[a] = bwn[a]; }
-  }
-  __syncthreads();   // all waves are done with the ring before it is reused as the epilogue scratch
-  if (DIAG) {
-    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0 && diag) { diag[2 * (size_t)blockIdx.x] = t1 - t0; diag[2 * (size_t)blockIdx.x + 1] = r1 - r0; }
-  }
-
-  xprod_store<v16i>(acc, smem, wave, lane, wi, wj, i0, j0, t.z, n, ans, ld, c0);
-}
-
 // ---- FP4 engine ----------------------------------------------------------------------------------------------------------------
-// Same tiling, ring and pipeline as k_crossprod2; per stage of 128 genotypes TWO K-steps of 64 (v_mfma_scale_f32_32x32x64_f8f6f4, FP4
+// Per stage of 128 genotypes TWO K-steps of 64 (v_mfma_scale_f32_32x32x64_f8f6f4, FP4
 // operands, unit scales).  Lane (row r = lane&31, K half h = lane>>5) reads 16 bytes = 64 genotypes of its row per stage; K-step ks uses
 // dwords 2ks, 2ks+1 of them.  A dword of 16 two-bit values z becomes two dwords of 8 nibbles 00zz -- the e2m1 numbers z/2 -- by
 // (w & 0x33333333) and ((w >> 2) & 0x33333333): 6 VALU per fragment of 32 values, 48 per K-step of 16 MFMAs (the int8 engine: 56 VALU per
@@ -268,10 +153,19 @@ __device__ __forceinline__ v16f mfma_f4(const v4i &a, const v4i &b, const v16f &
 
 // EXP (diagnostic instantiations only, results are wrong): 1 = no unpack VALU; 2 = no DMA / barrier / LDS reads inside the loop;
 // 3 = barrier only; 4 = DMA + LDS reads without the barrier; 5 = barrier + DMA, no LDS reads; 6 = barrier + LDS reads, no DMA
-template <bool DIAG, int EXP = 0>
-__global__ void __launch_bounds__(256, 1)
-k_crossprod_f4(const uint8_t *__restrict__ X, long nslabs, int stages, const int4 *__restrict__ tiles, long n, double *__restrict__ ans,
-               long ld, long c0, unsigned long long *__restrict__ diag) {
+// The same pipeline serves the int8 engine (I8, round 3): a "K-step of 64" is then two v_mfma_i32_32x32x32_i8 sub-steps -- the lane's two dwords of
+// a K-step unpack into two int8 fragments (14 VALU per sub-block instead of 6), 8 MFMAs per sub-block row instead of 4, exact int32 sums.  It replaced
+// k_crossprod2 (3-deep ring, words of a whole stage prefetched mid-stage: 2704 cycles per stage of 2048 ideal at 2.38 GHz -- issue-bound, not
+// power-bound).
+struct FragI8 { v4i lo, hi; };
+template <bool I8> struct XFrag { using type = v4i; using acc = v16f; };
+template <> struct XFrag<true> { using type = FragI8; using acc = v16i; };
+
+template <bool DIAG, int EXP, bool I8>
+__device__ __forceinline__ void xprod_pipeline(const uint8_t *__restrict__ X, long nslabs, int stages, const int4 *__restrict__ tiles, long n, double *__restrict__ ans,
+                                               long ld, long c0, unsigned long long *__restrict__ diag) {
+  using FragT = typename XFrag<I8>::type;
+  using AccT = typename XFrag<I8>::acc;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -292,13 +186,13 @@ k_crossprod_f4(const uint8_t *__restrict__ X, long nslabs, int stages, const int
     }
   };
 
-  v16f acc[4][4];
+  AccT acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; a++)
 #pragma unroll
     for (int b = 0; b < 4; b++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0;
 
   const int a_off = (wi * 128 + (lane & 31)) * kXStageBytes + (lane >> 5) * 16;
   const int b_off = kXOpBytes + (wj * 128 + (lane & 31)) * kXStageBytes + (lane >> 5) * 16;
@@ -322,10 +216,17 @@ k_crossprod_f4(const uint8_t *__restrict__ X, long nslabs, int stages, const int
   //   must have landed (its words are read during this stage); stages s+2 .. s+NB-1 stay in flight.
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
   u32x2 wa0[4], wb0[4], wa1[4], wb1[4];      // W[0] / W[1]: words of an even / odd K-step, 4 A and 4 B sub-blocks of 32 rows
-  v4i fa0[4], fb0[4], fa1[4], fb1[4];        // F[0] / F[1]
-  auto unpack = [](const u32x2 &w) -> v4i {
-    if (EXP == 1) { v4i r = {(int)w.x, (int)w.y, (int)w.x, (int)w.y}; return r; }
-    return unpack_f4(w.x, w.y);
+  FragT fa0[4], fb0[4], fa1[4], fb1[4];      // F[0] / F[1]
+  auto unpack = [](const u32x2 &w) -> FragT {
+    if constexpr (I8) { FragI8 r; r.lo = unpack16(w.x); r.hi = unpack16(w.y); return r; }
+    else {
+      if (EXP == 1) { v4i r = {(int)w.x, (int)w.y, (int)w.x, (int)w.y}; return r; }
+      return unpack_f4(w.x, w.y);
+    }
+  };
+  auto mma = [](const FragT &fa, const FragT &fb, const AccT &c) -> AccT {
+    if constexpr (I8) return __builtin_amdgcn_mfma_i32_32x32x32_i8(fa.hi, fb.hi, __builtin_amdgcn_mfma_i32_32x32x32_i8(fa.lo, fb.lo, c, 0, 0, 0), 0, 0, 0);
+    else return mfma_f4(fa, fb, c);
   };
 #pragma unroll
   for (int a = 0; a < 4; a++) {
@@ -355,11 +256,22 @@ k_crossprod_f4(const uint8_t *__restrict__ X, long nslabs, int stages, const int
       }                                                                                                                                    \
       FAN[a] = unpack(WAU[a]);                                                                                                             \
       FBN[a] = unpack(WBU[a]);                                                                                                             \
-      _Pragma("unroll") for (int b = 0; b < 4; b++) acc[a][b] = mfma_f4(FA[a], FB[b], acc[a][b]);                                          \
+      _Pragma("unroll") for (int b = 0; b < 4; b++) acc[a][b] = mma(FA[a], FB[b], acc[a][b]);                                              \
+      if constexpr (I8) {   /* 8 MFMAs, 28 unpack VALU, one DMA unit, two LDS reads */                                                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                              \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                              \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                              \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                              \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                              \
+      } else {                                                                                                                             \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                \
+      }                                                                                                                                    \
       __builtin_amdgcn_sched_barrier(0);                                                                                                   \
     }                                                                                                                                      \
   }
@@ -386,7 +298,20 @@ k_crossprod_f4(const uint8_t *__restrict__ X, long nslabs, int stages, const int
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0 && diag) { diag[2 * (size_t)blockIdx.x] = t1 - t0; diag[2 * (size_t)blockIdx.x + 1] = r1 - r0; }
   }
-  xprod_store<v16f>(acc, smem, wave, lane, wi, wj, i0, j0, t.z, n, ans, ld, c0);
+  xprod_store<AccT>(acc, smem, wave, lane, wi, wj, i0, j0, t.z, n, ans, ld, c0);
+}
+
+template <bool DIAG, int EXP = 0>
+__global__ void __launch_bounds__(256, 1)
+k_crossprod_f4(const uint8_t *__restrict__ X, long nslabs, int stages, const int4 *__restrict__ tiles, long n, double *__restrict__ ans,
+               long ld, long c0, unsigned long long *__restrict__ diag) {
+  xprod_pipeline<DIAG, EXP, false>(X, nslabs, stages, tiles, n, ans, ld, c0, diag);
+}
+template <bool DIAG>
+__global__ void __launch_bounds__(256, 1)
+k_crossprod_i8(const uint8_t *__restrict__ X, long nslabs, int stages, const int4 *__restrict__ tiles, long n, double *__restrict__ ans,
+               long ld, long c0, unsigned long long *__restrict__ diag) {
+  xprod_pipeline<DIAG, 0, true>(X, nslabs, stages, tiles, n, ans, ld, c0, diag);
 }
 
 int launch_plink_lut(uint8_t *d, size_t nbytes, hipStream_t s) {
@@ -449,9 +374,8 @@ struct XBuf {
 // one launch over a tile list with either engine (f4: FP4 MFMA, else int8 MFMA); diag_out: in-kernel clocks of the DIAG instantiation
 static int launch_tiles(bool f4, size_t ntiles, hipStream_t s, const uint8_t *d_X, long nslabs, int stages, const int4 *d_tiles, long rows, double *d_ans, long ld,
                         long c0, unsigned long long *d_diag) {
-  static unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;   // per-device function attributes
-  if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod2<false>), kX2Lds, &m0) || ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod2<true>), kX2Lds, &m1) ||
-      ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<false>), kF4Lds, &m2) || ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true>), kF4Lds, &m3)) return 1;
+  static unsigned long long m2 = 0, m3 = 0;   // per-device function attributes
+  if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<false>), kF4Lds, &m2) || ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true>), kF4Lds, &m3)) return 1;
   const dim3 grid((unsigned)ntiles), block(256);
   if (f4) {
     static const int exp = [] { const char *e = getenv("MXA_XPROD_EXP"); return e ? atoi(e) : 0; }();
@@ -482,8 +406,10 @@ static int launch_tiles(bool f4, size_t ntiles, hipStream_t s, const uint8_t *d_
     } else if (d_diag) hipLaunchKernelGGL(k_crossprod_f4<true>, grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
     else hipLaunchKernelGGL(k_crossprod_f4<false>, grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
   } else {
-    if (d_diag) hipLaunchKernelGGL(k_crossprod2<true>, grid, block, kX2Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
-    else hipLaunchKernelGGL(k_crossprod2<false>, grid, block, kX2Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
+    static unsigned long long i0 = 0, i1 = 0;
+    if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_i8<false>), kF4Lds, &i0) || ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_i8<true>), kF4Lds, &i1)) return 1;
+    if (d_diag) hipLaunchKernelGGL(k_crossprod_i8<true>, grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
+    else hipLaunchKernelGGL(k_crossprod_i8<false>, grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
   }
   MXA_HIP(hipGetLastError());
   return 0;
@@ -533,7 +459,7 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
     for (size_t i = 0; i < tiles.size(); i++) if (tiles[i].z && hd[2 * i + 1]) { ghz.push_back((double)hd[2 * i] / (double)hd[2 * i + 1] * 0.1); cyc.push_back((double)hd[2 * i] / stages); }
     std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end());
     if (!ghz.empty()) printf("MXA_DIAG %s: %zu tiles, in-kernel clock median %.3f GHz (min %.3f max %.3f); shader cycles per stage median %.0f (ideal %d)\n",
-                             f4 ? "k_crossprod_f4" : "k_crossprod2", tiles.size(), ghz[ghz.size() / 2], ghz.front(), ghz.back(), cyc[cyc.size() / 2], f4 ? 1024 : 2048);
+                             f4 ? "k_crossprod_f4" : "k_crossprod_i8", tiles.size(), ghz[ghz.size() / 2], ghz.front(), ghz.back(), cyc[cyc.size() / 2], f4 ? 1024 : 2048);
   }
   float ms = 0.f;
   MXA_HIP(hipEventElapsedTime(&ms, e0.e, e1.e));

@@ -59,7 +59,7 @@ def test_bench_single_gpu_line_is_complete():
     for t in ("N", "T"):
         assert c4[t]["k_gemm_ms"] > 0 and 0 < c4[t]["frac_of_fp64_mfma_peak_kernel"] < 1
     assert c4["check"]["N_16_sampled_rows_vs_dense_oracle_max_rel_err"] <= 1e-11 and c4["check"]["T_16_sampled_rows_vs_dense_oracle_max_rel_err"] <= 1e-11
-    for eng in ("k_crossprod_f4 (FP4 MFMA, default)", "k_crossprod2 (int8 MFMA)"):
+    for eng in ("k_crossprod_f4 (FP4 MFMA, default)", "k_crossprod_i8 (int8 MFMA)"):
         assert c3[eng]["kernel_ms"] > 0 and c3[eng]["check"]["four_256x256_tiles_and_mirrors_bit_exact_vs_int32_oracle"] is True
 
 
