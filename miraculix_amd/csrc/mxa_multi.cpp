@@ -478,7 +478,8 @@ static int reduce_rccl(Multi *m, long rows, int n, double *dC, long ldc, long fi
   if (!rc) {
     for (int g = 0; g < G && !rc && he == hipSuccess; g++) {
       he = hipSetDevice(m->sh[g].h->device);
-      if (he == hipSuccess) rc = r.Reduce(m->sh[g].d_part, g == 0 ? S0.d_land : nullptr, (size_t)rows * n, kNcclFloat64, kNcclSum, 0, m->comm[g], m->sh[g].cs);
+      // the receive buffer is read on the root rank only; the other ranks pass a valid pointer all the same (their own partial)
+      if (he == hipSuccess) rc = r.Reduce(m->sh[g].d_part, g == 0 ? S0.d_land : m->sh[g].d_part, (size_t)rows * n, kNcclFloat64, kNcclSum, 0, m->comm[g], m->sh[g].cs);
     }
     const int rc_end = r.GroupEnd();   // always
     if (!rc) rc = rc_end;
