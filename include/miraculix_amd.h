@@ -140,6 +140,11 @@ int mxa_dgemm_compressed_device(char trans, void *compressed, int n, const doubl
  * out (indiv x n, ld ldo) = Zc * (Zc^T * V), V indiv x n (ld ldv); the snps x n intermediate stays in HBM.  Centring as set by
  * setOptions_compressed.  V / out host or device.  On a SNP shard the result is that shard's partial sum.  Returns 0 / 1. */
 int mxa_gram_matvec(void *compressed, int n, const double *V, long ldv, double *out, long ldo);
+/* the same with device-resident V / out (memory of the object's device) and optional asynchrony: sync == 0 returns when both products are
+ * enqueued on the object's stream -- a blocking stream, so work the caller enqueues afterwards on the device's default stream (PyTorch, hipBLAS
+ * on stream 0) is ordered behind it and a CG / GBLUP loop on device-resident vectors never waits on the host: the ~40 us between two
+ * synchronous calls (return, caller, next launch) disappear from every iteration.  Single-device objects only.  Returns 0 / 1. */
+int mxa_gram_matvec_device(void *compressed, int n, const double *dV, long ldv, double *dOut, long ldo, int sync);
 
 /* on-device .bed staging helpers (reference counterparts live in the bindings:
  * transpose_genotype_matrix src/bindings/Julia/compressed_operations.jl:45-66, popcount frequencies

@@ -776,6 +776,19 @@ int mxa_gram_matvec(void *compressed, int n, const double *V, long ldv, double *
   return gram_any(h, n, V, ldv, out, ldo, true);
 }
 
+int mxa_gram_matvec_device(void *compressed, int n, const double *dV, long ldv, double *dOut, long ldo, int sync) {
+  clear_error();
+  if (is_multi(compressed)) { set_error(16, "mxa_gram_matvec_device: not available on a multi-device object; use mxa_gram_matvec"); return 1; }
+  Handle *h = as_handle(compressed, "mxa_gram_matvec_device");
+  if (!h) return 1;
+  int vd = -1, od = -1;
+  if (ptr_location(dV, &vd) != 1 || ptr_location(dOut, &od) != 1 || vd != h->device || od != h->device) {
+    set_error(1, "mxa_gram_matvec_device: V and out must be memory of the object's device (%d)", h->device);
+    return 1;
+  }
+  return gram_any(h, n, dV, ldv, dOut, ldo, sync != 0);
+}
+
 void free_compressed(void **compressed) {
   if (!compressed || !*compressed) return;
   if (is_multi(*compressed)) { multi_destroy(*compressed); *compressed = nullptr; return; }

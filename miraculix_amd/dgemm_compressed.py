@@ -262,9 +262,11 @@ def sparse_times_plink(transcompressed, plink, plink_transposed, snps, indiv, ro
     return C[:nidx, :] if out is None else C
 
 
-def gram_matvec(obj_ref, V, snps, indiv, out=None):
+def gram_matvec(obj_ref, V, snps, indiv, out=None, sync=True):
     """Additive: out (indiv x n) = Zc (Zc^T V) in one call (the 'T' + 'N' pair of a CG / GBLUP step,
-    examples/iterative_solver/grm_solve_cg.jl:74-84) with the snps x n intermediate kept on the device."""
+    examples/iterative_solver/grm_solve_cg.jl:74-84) with the snps x n intermediate kept on the device.
+    sync=False (torch tensors on the object's device, single-device object): returns when the products are enqueued on the object's blocking
+    stream; later work on the device's default stream -- the torch ops of the loop -- is ordered behind them (mxa_gram_matvec_device)."""
     check_storage_object(obj_ref)
     if V.shape[0] != indiv:
         raise ValueError(f"Matrix V must have {indiv} rows")
@@ -281,6 +283,10 @@ def gram_matvec(obj_ref, V, snps, indiv, out=None):
     if Cc is not C:
         raise ValueError("out must be column-major")
     L = _lib.check_library_handle()
+    if not sync and _lib.is_torch_tensor(V) and V.is_cuda and L.mxa_num_shards(obj_ref) == 1:
+        if L.mxa_gram_matvec_device(obj_ref, int(n), _lib.ptr(Vc), int(ldv), _lib.ptr(C), int(ldo), 0):
+            raise RuntimeError("mxa_gram_matvec_device failed: " + _lib.last_error()[1])
+        return C
     if L.mxa_gram_matvec(obj_ref, int(n), _lib.ptr(Vc), int(ldv), _lib.ptr(C), int(ldo)):
         raise RuntimeError("mxa_gram_matvec failed: " + _lib.last_error()[1])
     return C

@@ -37,9 +37,9 @@ class HipLocalEngine:
     def multiply(self, transpose, B, out=None):
         return self.dg.dgemm_compressed_main(transpose, self.obj, B, self.snps, self.indiv, out=out)
 
-    def gram(self, V, out=None):
-        """Zc_local (Zc_local^T V) in one library call (mxa_gram_matvec)"""
-        return self.dg.gram_matvec(self.obj, V, self.snps, self.indiv, out=out)
+    def gram(self, V, out=None, sync=True):
+        """Zc_local (Zc_local^T V) in one library call (mxa_gram_matvec; sync=False: mxa_gram_matvec_device, no host wait)"""
+        return self.dg.gram_matvec(self.obj, V, self.snps, self.indiv, out=out, sync=sync)
 
     def close(self):
         if self.obj is not None and self.obj.value:
@@ -73,7 +73,9 @@ class ShardedGenotypeOperator:
         """G V = Zc Zc^T V for V (indiv x n, identical on all ranks): every rank applies its SNP block (one fused 'T' + 'N' call when
         the local engine has one), then the same fp64 sum all-reduce as matmul_N.  Returns the full result on every rank."""
         if hasattr(self.engine, "gram"):
-            C = self.engine.gram(V, out=out)
+            # one rank: no collective follows, so the step need not wait on the host (the torch ops of the caller's loop run on the default
+            # stream, which the object's blocking stream orders itself with)
+            C = self.engine.gram(V, out=out, sync=False) if (self.world == 1 and not self.force_collective and getattr(self.engine, "obj", None) is not None) else self.engine.gram(V, out=out)
         else:
             C = self.engine.multiply(False, self.engine.multiply(True, V), out=out)
         if self.world > 1 or (dist.is_initialized() and self.force_collective):

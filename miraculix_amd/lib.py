@@ -88,6 +88,8 @@ def load_shared_library():
     L.sparse_times_plink.restype = None
     L.mxa_gram_matvec.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_long]
     L.mxa_gram_matvec.restype = ctypes.c_int
+    L.mxa_gram_matvec_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_long, ctypes.c_int]
+    L.mxa_gram_matvec_device.restype = ctypes.c_int
     L.mxa_snp_multiply_panel.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_int]
     L.mxa_snp_multiply_panel.restype = ctypes.c_int
     L.potrs_solve_gpu.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]

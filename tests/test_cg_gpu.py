@@ -95,3 +95,38 @@ def test_randomized_snp_pca_finds_the_population_structure():
     cosines = np.linalg.svd(Qa.T @ Ud[:, :n], compute_uv=False)
     assert cosines.min() >= 1.0 - 1e-9
     assert sd[n - 1] > 1.5 * sd[n]                                         # the structure is real: a gap after the second component
+
+
+def test_gram_matvec_device_async_equals_sync():
+    """mxa_gram_matvec_device with sync = 0: the step is only enqueued (on the object's blocking stream); torch ops issued right after it on
+    the default stream see its result, and a chain of 20 dependent steps with torch arithmetic in between -- no host wait anywhere -- gives the
+    same bits as the same chain through the synchronous entry.  Host pointers and multi-device objects are refused."""
+    import ctypes
+    import torch
+    import miraculix_amd as mx
+    from _util import make_problem
+    L = mx.load_shared_library()
+    dg = mx.dgemm_compressed
+    dev = torch.device("cuda", 0)
+    snps, indiv = 20_004, 3_001
+    prob = make_problem(snps, indiv, 1, seed=21)
+    dg.set_options(use_gpu=True, not_center=False, verbose=0)
+    obj = dg.init_compressed(torch.from_numpy(prob["plink"]).to(dev), torch.from_numpy(prob["plink_t"]).to(dev), snps, indiv, torch.from_numpy(prob["f"]).to(dev), 1)
+    try:
+        g = torch.Generator(device=dev); g.manual_seed(5)
+        v0 = torch.randn((1, indiv), dtype=torch.float64, device=dev, generator=g).t()
+
+        def chain(sync):
+            v = v0.clone()
+            for _ in range(20):
+                w = dg.gram_matvec(obj, v, snps, indiv, sync=sync)
+                v = w / torch.linalg.vector_norm(w) + 0.25 * v          # torch ops on the default stream, dependent on the step
+            torch.cuda.synchronize()
+            return v
+        a, b = chain(True), chain(False)
+        assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+        hv = np.zeros((indiv, 1), order="F"); ho = np.zeros((indiv, 1), order="F")
+        assert L.mxa_gram_matvec_device(obj, 1, hv.ctypes.data_as(ctypes.c_void_p), indiv, ho.ctypes.data_as(ctypes.c_void_p), indiv, 0) == 1
+        assert L.mxa_last_error() != 0
+    finally:
+        dg.free_compressed(obj)
