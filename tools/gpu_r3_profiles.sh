@@ -11,8 +11,12 @@ stats() {  # name, command...
   [ -n "$f" ] && cp "$f" "$O/${name}_kernel_stats.csv"
   rm -rf "$O/tmp_$name"
 }
-stats bench_n1 python3 "$R/bench.py" --no-pmc --no-abi --steps 10 --warmup 2
+# headline only (k_gemm<8,8,2> = the C2 launches and nothing else: the config-4 leg launches the same instantiation at another size, the ABI leg over K / row ranges)
+stats bench_n1 python3 "$R/bench.py" --no-pmc --no-abi --no-configs --steps 10 --warmup 2
 grep '^{' "$O/bench_n1_run.log" > "$O/bench_n1_profiled.json"
+# the same with the legs for configs 3, 4 (shard), 5 (shard)
+stats bench_n1_with_config_legs python3 "$R/bench.py" --no-pmc --no-abi --steps 5 --warmup 1
+grep '^{' "$O/bench_n1_with_config_legs_run.log" > "$O/bench_n1_with_config_legs_profiled.json"
 PMC="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE"
 timeout -k 10 600 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d "$O/pmc1" -- python3 "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-alt-engine --no-pmc --no-abi --no-configs > "$O/pmc1_run.log" 2>&1
 cd "$R"
