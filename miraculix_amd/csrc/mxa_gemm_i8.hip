@@ -206,10 +206,21 @@ struct SchedIter {
 // columns with MT * (4/WC) = 8 so that a workgroup covers one 256-row tile of the packed layout.
 //   <NT, 2, 1>: every wave reads all NT B fragments per K-step (LDS read traffic 4 x NT KiB per K-step of 512 MFMA cycles)
 //   <NT, 4, 2>: wave tile 128 x (NT/2 x 32): half the B-fragment LDS traffic, twice the unpack VALU (28 per 16 MFMAs)
+// Direct finish (n <= 2, ONE K split, round 3): the workgroup holds the complete integer sums of its 256 rows, so it scales them, adds the digits
+// of a column across the lanes in a fixed butterfly, applies the centring term and stores C itself -- no partial sums through HBM, no finish launch
+// (the 'T' product of a CG step: 128 MB of int32 partials and ~25 us).  Same arithmetic as k_finish_i8_small up to the (fixed) order of the additions.
+struct I8Direct {
+  int on;                                   // 0: partial sums to P (finish kernel follows)
+  const int *E; const double *colmax_part; double *C; long ldc; long m; long fill_rows;
+  int n, S, nc, mode_trans, centered;
+  const double *sumB, *sumfB, *f;
+};
+
 template <int NT, int MT, int WC, bool DIAG>
 __global__ void __launch_bounds__(256, 1)
 k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict__ Bs, long T_total, int *__restrict__ P, long m_pad, int e_pad,
-          int rowblocks, int nchunks, int stages_total, int stages_per_split, unsigned long long *__restrict__ diag, const int *__restrict__ skip_if_set) {
+          int rowblocks, int nchunks, int stages_total, int stages_per_split, unsigned long long *__restrict__ diag, const int *__restrict__ skip_if_set,
+          I8Direct dir) {
   using Cfg = I8Cfg<NT>;
   if (skip_if_set && *skip_if_set) return;
   constexpr int NTW = NT / WC;
@@ -330,6 +341,38 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
   // epilogue: P[split][row][e] int32, e contiguous: lanes (col) write 128-byte runs.  C/D map: col = lane&31,
   // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const int col = lane & 31, rq = 4 * (lane >> 5);
+  if (NT == 1 && WC == 1 && dir.on) {
+    // lane = digit e = s * nc + jj of the rows it holds; weight 2^(E_jj - 8 (s + 1))
+    const int sl = col / dir.nc, jj = col - sl * dir.nc;
+    const bool live = col < dir.nc * dir.S;
+    const int sh = live ? dir.E[jj] - 8 * (sl + 1) : 0;
+    bool bad = false;
+    double cs = 0.0;
+    if (col < dir.nc && col < dir.n) {
+      double cm = 0.0;
+      for (int c = 0; c < 64; c++) cm = fmax(cm, dir.colmax_part[(size_t)col * 64 + c]);
+      bad = !(cm <= 1.7976931348623157e308);   // a column with inf / NaN: NaN, like 0 * inf in fp64
+      if (dir.centered) cs = -2.0 * (dir.mode_trans ? dir.sumB[col] : dir.sumfB[col]);
+    }
+#pragma unroll
+    for (int a = 0; a < MT; a++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const long row = (long)rb * kTileRows + wr * (MT * 32) + a * 32 + (r & 3) + 8 * (r >> 2) + rq;
+        double v = live ? ldexp((double)acc[a][0][r], sh) : 0.0;
+        // the 32 lanes of a half-wave hold the digits of one row; lanes of one column: e = jj, jj + nc, ...  (nc = 1: all 32; nc = 2: equal parity)
+        for (int off = 16; off >= dir.nc; off >>= 1) v += __shfl_xor(v, off, 32);
+        if (col < dir.nc && col < dir.n && row < dir.m) {
+          if (bad) v = __longlong_as_double(0x7ff8000000000000ll);
+          if (dir.centered) v = dir.mode_trans ? fma(cs, dir.f[row], v) : v + cs;
+          dir.C[row + (long)col * dir.ldc] = v;
+        }
+      }
+    if (rb == rowblocks - 1)   // rows [m, fill_rows) of every column are zero (ld padding of the plain ABI), whatever the tile padding
+      for (long r = dir.m + threadIdx.x; r < dir.fill_rows; r += 256)
+        for (int c = 0; c < dir.n; c++) dir.C[r + (long)c * dir.ldc] = 0.0;
+    return;
+  }
   int *Pb = P + (size_t)sp * m_pad * e_pad;
 #pragma unroll
   for (int a = 0; a < MT; a++)
@@ -537,7 +580,9 @@ static I8Plan plan_i8(long m, long k_pad, int n) {
   {
     static const long search = [] { const char *e = getenv("MXA_I8_SPLIT_SEARCH"); return e ? atol(e) : 1L; }();
     double best_eff = -1.0;
-    const long lo = splits, hi = std::min<long>(max_splits, splits + 6);
+    // from ONE split on: with at least ~0.85 rounds of row tiles a single K piece per tile fills the slots, and the n <= 2 product then
+    // finishes inside the kernel (I8Direct)
+    const long lo = units * 20 >= resident * 17 ? 1 : splits, hi = std::min<long>(max_splits, splits + 6);
     for (long cand = lo; search && cand <= hi; cand++) {
       const long per = (p.stages_total + cand - 1) / cand, actual = (p.stages_total + per - 1) / per;
       const long wgs = units * actual;
@@ -553,7 +598,7 @@ static I8Plan plan_i8(long m, long k_pad, int n) {
 }
 
 template <int NT, int MT, int WC>
-static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const I8Plan &p, hipStream_t s, const int *skip_if_set) {
+static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const I8Plan &p, hipStream_t s, const int *skip_if_set, const I8Direct &dir) {
   using Cfg = I8Cfg<NT>;
   static unsigned long long attr_a = 0, attr_b = 0;   // function attributes are per device
   if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8<NT, MT, WC, false>), Cfg::kLds, &attr_a) ||
@@ -564,7 +609,7 @@ static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const 
     unsigned long long *d_diag = nullptr;
     MXA_HIP(hipMalloc((void **)&d_diag, sizeof(unsigned long long) * 2 * grid));
     hipLaunchKernelGGL((k_gemm_i8<NT, MT, WC, true>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBs, p.T_total, dP, p.m_pad, p.e_pad,
-                       p.rowblocks, p.nchunks, p.stages_total, p.stages_per_split, d_diag, skip_if_set);
+                       p.rowblocks, p.nchunks, p.stages_total, p.stages_per_split, d_diag, skip_if_set, dir);
     std::vector<unsigned long long> h(2 * grid);
     MXA_HIP(hipStreamSynchronize(s));
     MXA_HIP(hipMemcpy(h.data(), d_diag, sizeof(unsigned long long) * 2 * grid, hipMemcpyDeviceToHost));
@@ -577,7 +622,7 @@ static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const 
     return 0;
   }
   hipLaunchKernelGGL((k_gemm_i8<NT, MT, WC, false>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBs, p.T_total, dP, p.m_pad, p.e_pad,
-                     p.rowblocks, p.nchunks, p.stages_total, p.stages_per_split, (unsigned long long *)nullptr, skip_if_set);
+                     p.rowblocks, p.nchunks, p.stages_total, p.stages_per_split, (unsigned long long *)nullptr, skip_if_set, dir);
   MXA_HIP(hipGetLastError());
   return 0;
 }
@@ -645,19 +690,26 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   MXA_HIP(hipGetLastError());
   if (ev0) MXA_HIP(hipEventRecord(ev0, s));
   int rc = 0;
+  const bool small_tile = p.nchunks == 1 && p.NT == 1 && p.nc * p.S <= 32 && (p.nc == 1 || p.nc == 2);   // n <= 2: one tile
+  static const bool direct_on = [] { const char *e = getenv("MXA_I8_DIRECT"); return !e || atoi(e) != 0; }();
+  I8Direct dir{};
+  if (direct_on && small_tile && p.splits == 1)
+    dir = I8Direct{1, d_E, d_part, dC, ldc, m, fill_rows, n, p.S, p.nc, trans ? 1 : 0, centered ? 1 : 0, d_sumB, d_sumfB, d_f};
   switch (p.NT) {
-    case 1: rc = launch_i8_t<1, 2, 1>(G, d_Bs, d_P, p, s, skip); break;
-    case 2: rc = launch_i8_t<2, 2, 1>(G, d_Bs, d_P, p, s, skip); break;
-    case 3: rc = launch_i8_t<3, 2, 1>(G, d_Bs, d_P, p, s, skip); break;
-    case 4: rc = launch_i8_t<4, 2, 1>(G, d_Bs, d_P, p, s, skip); break;
-    case 5: rc = launch_i8_t<5, 2, 1>(G, d_Bs, d_P, p, s, skip); break;
-    case 6: rc = launch_i8_t<6, 2, 1>(G, d_Bs, d_P, p, s, skip); break;
-    case 7: rc = launch_i8_t<7, 2, 1>(G, d_Bs, d_P, p, s, skip); break;
-    default: rc = launch_i8_t<8, 4, 2>(G, d_Bs, d_P, p, s, skip); break;
+    case 1: rc = launch_i8_t<1, 2, 1>(G, d_Bs, d_P, p, s, skip, dir); break;
+    case 2: rc = launch_i8_t<2, 2, 1>(G, d_Bs, d_P, p, s, skip, dir); break;
+    case 3: rc = launch_i8_t<3, 2, 1>(G, d_Bs, d_P, p, s, skip, dir); break;
+    case 4: rc = launch_i8_t<4, 2, 1>(G, d_Bs, d_P, p, s, skip, dir); break;
+    case 5: rc = launch_i8_t<5, 2, 1>(G, d_Bs, d_P, p, s, skip, dir); break;
+    case 6: rc = launch_i8_t<6, 2, 1>(G, d_Bs, d_P, p, s, skip, dir); break;
+    case 7: rc = launch_i8_t<7, 2, 1>(G, d_Bs, d_P, p, s, skip, dir); break;
+    default: rc = launch_i8_t<8, 4, 2>(G, d_Bs, d_P, p, s, skip, dir); break;
   }
   if (rc) return rc;
   if (ev1) MXA_HIP(hipEventRecord(ev1, s));
-  if (p.nchunks == 1 && p.NT == 1 && p.nc * p.S <= 32 && (p.nc == 1 || p.nc == 2)) {   // n <= 2: one tile, the fast finish
+  if (dir.on) {
+    // finished inside k_gemm_i8
+  } else if (small_tile) {   // n <= 2: one tile, the fast finish
     hipLaunchKernelGGL(k_finish_i8_small, dim3((unsigned)((fill_rows + kFinSmallBlockRows - 1) / kFinSmallBlockRows)), dim3(256), 0, s, d_P, p.m_pad, p.splits, m, n, p.S, p.nc, d_E, d_part, dC, ldc, fill_rows,
                        trans ? 1 : 0, centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip);
   } else {

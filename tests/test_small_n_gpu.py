@@ -206,3 +206,33 @@ def test_column_peel_exact_route_and_fallback(mx, n):
                 assert np.all(err <= tol + 1e-300)
     finally:
         dg.free_compressed(obj)
+
+
+@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("trans", [0, 1])
+@pytest.mark.parametrize("centered", [False, True])
+def test_result_does_not_depend_on_ldc_or_operand_residence(mx, n, trans, centered):
+    """single-split products finish inside k_gemm_i8, multi-split ones through P + k_finish_i8_small; which of the two runs must
+    depend on the shape only: the same product into a padded device C (ldc = m + 7; for n > 1 the padding rows come back zero like on the reference's CPU path) and from host
+    operands is bit-identical"""
+    import torch
+    dg = mx.dgemm_compressed
+    dg.set_options(use_gpu=True, not_center=not centered, verbose=0)
+    snps, indiv = 2050, 1301
+    prob = make_problem(snps, indiv, n, seed=11)
+    obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], 2)
+    try:
+        k, m = (indiv, snps) if trans else (snps, indiv)
+        B = np.asfortranarray(np.random.default_rng(12).standard_normal((k, n)))
+        C_host = dg.dgemm_compressed_main(bool(trans), obj, B, snps, indiv)
+        assert dg.last_path() == "k_gemm_i8"
+        Bd = torch.from_numpy(np.ascontiguousarray(B.T)).cuda().t()               # column-major on the device
+        buf = torch.full((n, m + 7), 7.0, dtype=torch.float64, device="cuda")
+        Cd = dg.dgemm_compressed_main(bool(trans), obj, Bd, snps, indiv, out=buf.t()[:m])
+        torch.cuda.synchronize()
+        assert dg.last_path() == "k_gemm_i8"
+        assert np.array_equal(Cd.cpu().numpy(), C_host)
+        if n > 1:
+            assert np.all(buf[:, m:].cpu().numpy() == 0.0)
+    finally:
+        dg.free_compressed(obj)
