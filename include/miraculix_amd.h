@@ -270,6 +270,12 @@ int mxa_ld(const unsigned char *plink, int snps, int indiv, double *R, int is_pl
  *    results agree with engine 0 to ~1e-14 of each result column's largest entry on the test problems, at ~4x the throughput.
  * 2 (MXA_ENGINE=small-n-i8): engine 1 for n <= 4 only, engine 0's fp64 path otherwise.
  * 3 (MXA_ENGINE=f64-strict): fp64 arithmetic for every n (n <= 2: the pair-table kernel, never the int8 route).
+ * 4 (opt-in, MXA_ENGINE=i8-exact): the int8 slicing for EVERY n, but only when it is exact, with the digit count chosen per call: one
+ *    pass over B measures the binary-exponent span of the non-zero entries of every column; S = max(7, ceil((span + 55) / 8)) digits
+ *    represent every entry of B without error (the condition of engine 0's n <= 2 check), so the error bound above holds with S - 1
+ *    additions: |error| <= 3.02 * (S - 1) * 2^-53 * sum_k |z_k b_k|, S <= 24.  Wider spans (> 137 binades), inf / NaN, columns whose largest
+ *    entry lies below 2^(8S - 1023), or K < 128: engine 0's path.  Typical data (spans of 15-30 binades) need 9-11 digits; the product is
+ *    then 2-3 times faster than the fp64 matrix cores allow.  n <= 2: as engine 0.  One host synchronisation per call.
  * mxa_set_engine returns the previous value (an invalid argument leaves the engine unchanged).  mxa_last_path: kernel family of
  * the most recent product: 0 = fp64 MFMA (k_gemm), 1 = fp64 pair tables (k_lut), 2 = int8 slicing (k_gemm_i8). */
 int mxa_set_engine(int engine);

@@ -33,6 +33,7 @@ static std::atomic<int> g_engine{[] {
   if (e && std::string(e) == "i8") return 1;
   if (e && std::string(e) == "small-n-i8") return 2;
   if (e && std::string(e) == "f64-strict") return 3;
+  if (e && std::string(e) == "i8-exact") return 4;
   return 0;
 }()};
 
@@ -360,14 +361,34 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     h->prof_slot = slot ^ 1;
   }
   hipEvent_t pe0 = prof ? h->ev0[slot] : nullptr, pe1 = prof ? h->ev1[slot] : nullptr;
-  const bool auto_i8_pre = engine == 0 && n <= 2 && k >= 128;   // that route computes the column sums in its own statistics pass
+  const bool auto_i8_pre = (engine == 0 || engine == 4) && n <= 2 && k >= 128;   // that route computes the column sums in its own statistics pass
   if (centered && !auto_i8_pre && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
   // Engine 0 at n <= 2 (the CG / GBLUP iteration, HBM-bound): the exact int8 slicing is used WHEN IT IS EXACT -- every column of B
   // finite with an exponent span that fits its 32 (n = 1) / 16 (n = 2) digits, checked on the device per call (gemm_i8_device,
   // guard).  Then B is represented without any error, all dot products are exact integers and the only roundings are the S - 1
   // additions of the recombination: |error| <= 3.02 (S - 1) 2^-53 sum_k |z_k b_k|, below the K 2^-53 sum |z b| of
   // an fp64 chain for K >= 128.  Otherwise (and always with engine 3) the fp64 pair-table kernel k_lut runs.
-  const bool auto_i8 = engine == 0 && n <= 2 && k >= 128;
+  const bool auto_i8 = (engine == 0 || engine == 4) && n <= 2 && k >= 128;
+  // Engine 4 (i8-exact, opt-in) at n >= 3: the same exact slicing with the digit count chosen PER CALL from the measured exponent span of B's
+  // columns -- S = ceil((span + 55) / 8), at least 7 -- so that B is represented without error (the condition of the n <= 2 guard); the host reads
+  // three integers (one short sync, irrelevant beside a multi-millisecond product).  Beyond 24 digits (span > 137 binades), for non-finite
+  // entries, values near the underflow threshold or K < 128, the fp64 MFMA path below runs.  Error bound as for n <= 2 with S <= 24.
+  if (engine == 4 && n >= 3 && k >= 128) {
+    int hs[3] = {0, 0, 1};
+    if (launch_colspan(dB, ldb, k, n, w.d_colpart, w.d_denflag + 4, s)) return 1;
+    MXA_HIP(hipMemcpyAsync(hs, w.d_denflag + 4, sizeof(hs), hipMemcpyDeviceToHost, s));
+    MXA_HIP(hipStreamSynchronize(s));
+    const int S = std::max(7, (hs[0] + 55 + 7) / 8);
+    if (!hs[2] && S <= kI8ExactMaxDigits && hs[1] >= 8 * S - 1023) {
+      int splits8 = 1;
+      if (gemm_i8_device(G, trans, n, dB, ldb, dC, ldc, fill_rows, centered, d_sumB, d_sumfB, h->d_f, w, s, pe0, pe1, &splits8, 0, nullptr, nullptr, S)) return 1;
+      std::lock_guard<std::mutex> lk(g_prof_mutex);
+      Geometry &geo = last_geometry();
+      geo.m = m; geo.k = k; geo.n = n; geo.splits = splits8; geo.a = S; geo.c = 0; geo.path = 2; geo.d_flag = nullptr; geo.flag_dev = h->device;
+      h->prof_pending[slot] = prof;
+      return 0;
+    }
+  }
   if (engine == 1 || (engine == 2 && n <= 4) || auto_i8) {   // exact int8 slicing of B on the int8 matrix cores (mxa_gemm_i8.hip)
     int splits8 = 1;
     const int *d_flag = nullptr;
@@ -907,7 +928,7 @@ int mxa_device_count(void) {
 }
 
 int mxa_set_engine(int engine) {
-  if (engine < 0 || engine > 3) return g_engine.load();
+  if (engine < 0 || engine > 4) return g_engine.load();
   return g_engine.exchange(engine);
 }
 int mxa_get_engine(void) { return g_engine.load(); }

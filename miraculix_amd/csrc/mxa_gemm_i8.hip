@@ -549,14 +549,15 @@ __global__ void __launch_bounds__(256) k_finish_i8_small(const int *__restrict__
 
 struct I8Plan { int S, nc, nchunks, NT, e_pad, rowblocks, stages_total, stages_per_split, splits; long m_pad, T_total; };
 
-static I8Plan plan_i8(long m, long k_pad, int n) {
+static I8Plan plan_i8(long m, long k_pad, int n, int S_override) {
   I8Plan p{};
-  static const int S_env = [] { const char *e = getenv("MXA_I8_SLICES"); return e ? std::min(32, std::max(3, atoi(e))) : 0; }();
+  static const int S_env0 = [] { const char *e = getenv("MXA_I8_SLICES"); return e ? std::min(32, std::max(3, atoi(e))) : 0; }();
+  const int S_env = S_override > 0 ? std::min(32, std::max(3, S_override)) : S_env0;
   int S = S_env ? S_env : 7;                                     // 8 bits per digit: 7 digits = 56 bits below 2^E_j
   // a tile of 32 expanded columns is the unit of work: for n <= 4 the kernel is HBM-bound with one tile, so the digits that fit the
   // tile are free -- n = 1: 32 digits (256 bits: any entry down to 2^-200 of the column maximum keeps its whole mantissa), n = 2: 16
   if (!S_env && n * S <= 32) S = std::min(32, 32 / n);
-  if (n * S > 32 && S > 8) S = 8;
+  if (!S_override && n * S > 32 && S > 8) S = 8;
   p.S = S;
   const int max_nc = std::min(32, 256 / S);                     // <= 8 tiles of 32 expanded columns per pass; k_finish_i8 handles <= 32 columns per chunk
   p.nchunks = (n + max_nc - 1) / max_nc;
@@ -574,20 +575,25 @@ static I8Plan plan_i8(long m, long k_pad, int n) {
   // 1.19 ms -- and, at equal fill, FEWER splits (less partial-sum traffic, fewer prologues): 977 tiles x 3: 1.05 ms, x 7: 1.16 ms.
   const long lds_wg = 3L * (kI8ABytes + 4L * p.NT * 1024);
   const long resident = 256L * (p.NT <= 4 ? std::max<long>(1, std::min<long>(4, 163840 / lds_wg)) : 1);
-  long want = (3 * resident / 2 + units - 1) / units;             // at least ~1.5 rounds
   long max_splits = std::max<long>(1, p.stages_total / 32);
-  long splits = std::max<long>(1, std::min<long>(want, max_splits));
+  long splits = 1;
   {
+    // Cost model (round 3; replaces "fill the rounds to 3 %"): main kernel = the larger of the packed-matrix stream at ~6 TB/s and the int8
+    // work at the ~2.4 Pop/s the power limit allows, stretched by the unfilled part of the last round of resident slots and by a per-piece
+    // prologue worth ~6 stages; plus the partial sums, written once and read once by the finish (none when the single split of an n <= 2
+    // product finishes inside the kernel).  Fewest splits within 1 % of the best.
     static const long search = [] { const char *e = getenv("MXA_I8_SPLIT_SEARCH"); return e ? atol(e) : 1L; }();
-    double best_eff = -1.0;
-    // from ONE split on: with at least ~0.85 rounds of row tiles a single K piece per tile fills the slots, and the n <= 2 product then
-    // finishes inside the kernel (I8Direct)
-    const long lo = units * 20 >= resident * 17 ? 1 : splits, hi = std::min<long>(max_splits, splits + 6);
-    for (long cand = lo; search && cand <= hi; cand++) {
+    const double t_main = std::max((double)p.m_pad * (double)k_pad / 4.0 * p.nchunks / 6.0e12, 2.0 * (double)p.m_pad * (double)k_pad * p.e_pad / 2.4e15);
+    const bool direct_possible = p.nchunks == 1 && p.NT == 1 && p.nc <= 2;
+    double best = 1e300;
+    for (long cand = 1; search && cand <= std::min<long>(max_splits, 64); cand++) {
       const long per = (p.stages_total + cand - 1) / cand, actual = (p.stages_total + per - 1) / per;
-      const long wgs = units * actual;
-      const double eff = (double)wgs / (double)(resident * ((wgs + resident - 1) / resident));
-      if (eff > best_eff + 0.03) { best_eff = eff; splits = cand; }   // prefer fewer splits unless the fill improves by 3 %
+      if (actual != cand) continue;
+      const long wgs = units * actual, rounds = (wgs + resident - 1) / resident;
+      const double quant = (double)(rounds * resident) / (double)wgs;
+      const double t_p = (actual == 1 && direct_possible) ? 0.0 : 2.0 * (double)actual * (double)p.m_pad * p.e_pad * 4.0 / 5.0e12;
+      const double t = t_main * quant * (double)(per + 6) / (double)per + t_p;
+      if (t < best * 0.99) { best = t; splits = cand; }
     }
   }
   if (const char *e = getenv("MXA_I8_SPLITS")) splits = std::max<long>(1, std::min<long>(max_splits, atol(e)));   // A/B measurement
@@ -631,9 +637,9 @@ static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const 
 // handle and only grows.
 int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool centered, double *d_sumB,
                    double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out, int guard,
-                   const int **flag_out, double *colsum_scratch) {
+                   const int **flag_out, double *colsum_scratch, int S_override) {
   const long m = G.rows, k = G.k;
-  const I8Plan p = plan_i8(m, G.k_pad, n);
+  const I8Plan p = plan_i8(m, G.k_pad, n, S_override);
   if (p.m_pad > G.rows_pad) { set_error(4, "internal: packed matrix smaller than the i8 plan"); return 1; }
   if (splits_out) *splits_out = p.splits;
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };

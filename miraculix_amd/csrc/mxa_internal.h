@@ -166,6 +166,8 @@ constexpr int kDenUp = 900;
 constexpr int kDenMaxSpan = 800;
 // E[j] = binary exponent of the largest |entry| of column j (frexp convention) + bias; d_part: 64 * n doubles of scratch
 // d_flag (nullable, device int): range guard of the exact int8 slicing, see k_colexp_final; then d_part needs 128 * n doubles
+constexpr int kI8ExactMaxDigits = 24;   // engine 4: more digits than this cost more than the fp64 MFMA path
+int launch_colspan(const double *dB, long ldb, long k, int n, double *d_part, int *d_out3, hipStream_t s);   // engine 4: span / e_max / non-finite verdict for the host
 int launch_colexp(const double *dB, long ldb, long k, int n, double *d_part, int *d_E, int bias, hipStream_t s, int *d_flag = nullptr, int max_span = 0,
                   int min_emax = 0, bool reset_flag = true);
 // d_E (nullable): per-column exponents for the denormal-operand mode
@@ -217,10 +219,11 @@ int launch_sparse_times_plink(const uint8_t *dP, size_t pitch, long entries, int
 // and 2 is returned (the caller takes the fp64 path).  guard = 2: no host round trip -- the three kernels of the chain test the device
 // flag themselves and do nothing when it is set; 3 is returned with *flag_out = the device flag, and the caller enqueues the fp64
 // fallback with run_if_set = that flag.
+// S_override > 0 (engine 4): that many digits per column for every n (the caller has already proved them sufficient: guard = 0).
 // colsum_scratch (guard = 2, n <= 2 only; 128 n doubles): the column sums of the centring term are computed HERE, in the same pass over B as
 // the exponents and the guard (k_colstats_partial; finished inside k_slice_B) -- the caller must not have launched launch_colsums for them
 int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool centered, double *d_sumB,
                    double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out, int guard = 0,
-                   const int **flag_out = nullptr, double *colsum_scratch = nullptr);
+                   const int **flag_out = nullptr, double *colsum_scratch = nullptr, int S_override = 0);
 
 }  // namespace mxa

@@ -167,6 +167,41 @@ int launch_colexp(const double *dB, long ldb, long k, int n, double *d_part, int
   return 0;
 }
 
+// engine 4 (i8-exact): what the host needs to choose the digit count: out[0] = largest exponent span e_max - e_min over the columns (non-zero
+// entries only), out[1] = smallest e_max over the non-zero columns (0 if there is none), out[2] = 1 if any entry is inf / NaN.  One workgroup.
+__global__ void __launch_bounds__(256) k_colspan_final(const double *__restrict__ part, int n, int *__restrict__ out) {
+  __shared__ int s_span[256], s_emax[256], s_bad[256];
+  int span = 0, emin_max = 1 << 20, bad = 0;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    double m = 0.0;
+    for (int c = 0; c < 64; c++) m = fmax(m, part[(size_t)j * 64 + c]);
+    if (!isfinite(m)) { bad = 1; continue; }
+    if (m > 0.0) {
+      double lo = m;
+      for (int c = 0; c < 64; c++) lo = fmin(lo, part[((size_t)n + j) * 64 + c]);
+      int e = 0, el = 0;
+      (void)frexp(m, &e); (void)frexp(lo, &el);
+      span = max(span, e - el); emin_max = min(emin_max, e);
+    }
+  }
+  s_span[threadIdx.x] = span; s_emax[threadIdx.x] = emin_max; s_bad[threadIdx.x] = bad;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      s_span[threadIdx.x] = max(s_span[threadIdx.x], s_span[threadIdx.x + w]); s_emax[threadIdx.x] = min(s_emax[threadIdx.x], s_emax[threadIdx.x + w]);
+      s_bad[threadIdx.x] |= s_bad[threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = s_span[0]; out[1] = s_emax[0] == (1 << 20) ? 0 : s_emax[0]; out[2] = s_bad[0]; }
+}
+int launch_colspan(const double *dB, long ldb, long k, int n, double *d_part, int *d_out3, hipStream_t s) {
+  hipLaunchKernelGGL(k_colmax_partial, dim3(64, n), dim3(256), 0, s, dB, ldb, k, d_part, n, 1);
+  hipLaunchKernelGGL(k_colspan_final, dim3(1), dim3(256), 0, s, d_part, n, d_out3);
+  MXA_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k_pad, int n_pad, int c, hipStream_t s, const int *d_E, long S0, long S_cnt,
                   const int *run_if_set, bool rowscale) {
   const long S_total = k_pad / 16;
