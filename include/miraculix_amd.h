@@ -83,7 +83,7 @@ int snp_multiply_gpu(unsigned char *snp_matrix, int snps, int indiv, double *ans
 /* ---- solver twin (not on the compressed-genotype hot path) behind the reference's solver exports
  * src/cuda/solve_cuda.cu:927-951 (prototypes src/cuda/solve_cuda.h:61-88; Julia binding src/bindings/Julia/solve.jl:45-180;
  * Fortran binding src/bindings/Fortran/modmiraculix_gpu.f90:23-80).  Blocked Cholesky and a synchronisation-free sparse
- * triangular solve written here; rocBLAS (dlopen()ed on first use) does the Level-3 updates.  All matrices column-major fp64;
+ * triangular solve written here, Level-3 updates on the fp64 matrix cores included (no vendor library is loaded).  All matrices column-major fp64;
  * pointers may be host or device. */
 
 /* replaces solve_cuda.cu:947-951 -> dense_solve (:70-280): X = A^-1 B by Cholesky (lower triangle of the symmetric positive

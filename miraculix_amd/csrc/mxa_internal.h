@@ -226,4 +226,9 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
                    double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out, int guard = 0,
                    const int **flag_out = nullptr, double *colsum_scratch = nullptr, int S_override = 0);
 
+// mxa_dense.hip: dense fp64 MFMA building blocks of the solver twin
+int launch_dgemm(bool ta, bool tb, long M, long N, long K, double alpha, const double *A, long lda, const double *B, long ldb, double beta, double *C, long ldc,
+                 bool lower_only, hipStream_t s);
+int launch_potrf_inv_block(double *A, long ld, int nb, long offset, int *info, double *inv_out, hipStream_t s);
+
 }  // namespace mxa

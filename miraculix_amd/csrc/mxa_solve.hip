@@ -5,19 +5,16 @@
 // The reference calls cuSOLVER Xpotrf/Xpotrs and cuSPARSE SpSM.  Their ROCm counterparts cannot be used the same way here:
 // measured on MI355X / ROCm 7.2, dlopen() of librocsolver.so or librocsparse.so in a process whose HIP runtime is already
 // initialised (the normal case: plink2compressed has run) takes 130 s to > 4 min (their thousands of code objects are loaded
-// eagerly), while librocblas.so takes 2.4 s.  So only rocBLAS is used (dlopen()ed on first use: libmiraculix_amd.so itself
-// carries no dependency on it), for the Level-3 updates, and the rest is written here:
-//   dense   two-level blocked right-looking Cholesky: k_potrf_block (64 x 64 diagonal block in LDS) + rocblas_dtrsm / rocblas_dgemm
-//           inside a 512-column panel, one rocblas_dsyrk per panel; the two triangular solves by rocblas_dtrsm; k_logdet (the
-//           reference's trace_kernel, :884-909)
+// eagerly), and even librocblas.so takes 2.4 s.  Round 3: no vendor library at all -- everything is written here / in mxa_dense.hip:
+//   dense   two-level blocked right-looking Cholesky: k_potrf_block (64 x 64 diagonal block in LDS), k_trtri_blocks (its inverse), and
+//           k_dgemm (fp64 MFMA) for the block column below it (A L^-T as a product with the inverted block), for the rest of the 512-column
+//           panel, and once per panel -- lower tiles only -- for the trailing matrix; the two triangular solves block by block as
+//           products with the inverted diagonal blocks; k_logdet (the reference's trace_kernel, :884-909)
 //   sparse  k_sptrsm: synchronisation-free triangular solve, one wave per row, rows in dependency order, a flag per row
 //           (host side: COO -> sorted CSR of A and of A^T, diagonal check)
 #include "../../include/miraculix_amd.h"
 #include "mxa_internal.h"
 
-#include <rocblas/rocblas.h>
-
-#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -28,41 +25,6 @@
 #include <vector>
 
 namespace mxa {
-
-// ------------------------------------------------------------------------------------------------ lazy library binding
-static void *open_rocm_lib(const char *name) {
-  void *h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-  if (h) return h;
-  Dl_info info;   // next to the HIP runtime this library is already linked against
-  if (dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &info) && info.dli_fname) {
-    std::string dir(info.dli_fname);
-    const size_t slash = dir.rfind('/');
-    if (slash != std::string::npos) {
-      const std::string path = dir.substr(0, slash + 1) + name;
-      h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
-    }
-  }
-  return h;
-}
-
-#define MXA_SYM(lib, name) name = reinterpret_cast<decltype(&::name)>(dlsym(lib, #name)); if (!name) { set_error(20, "symbol %s not found", #name); return false; }
-
-struct BlasLib {
-  decltype(&::rocblas_create_handle) rocblas_create_handle = nullptr;
-  decltype(&::rocblas_destroy_handle) rocblas_destroy_handle = nullptr;
-  decltype(&::rocblas_dtrsm) rocblas_dtrsm = nullptr;
-  decltype(&::rocblas_dsyrk) rocblas_dsyrk = nullptr;
-  decltype(&::rocblas_dgemm) rocblas_dgemm = nullptr;
-  bool ok = false;
-  bool load() {
-    if (ok) return true;
-    void *blas = open_rocm_lib("librocblas.so");
-    if (!blas) { set_error(20, "potrs_solve_gpu: cannot load rocBLAS (%s)", dlerror()); return false; }
-    MXA_SYM(blas, rocblas_create_handle) MXA_SYM(blas, rocblas_destroy_handle) MXA_SYM(blas, rocblas_dtrsm) MXA_SYM(blas, rocblas_dsyrk) MXA_SYM(blas, rocblas_dgemm)
-    return ok = true;
-  }
-};
-static BlasLib &blas_lib() { static BlasLib l; return l; }
 
 static bool solve_is_device_ptr(const void *p) {
   if (!p) return false;
@@ -82,33 +44,6 @@ static int solve_select_device(const char *who) {
 // ------------------------------------------------------------------------------------------------ dense: Cholesky solve + logdet
 constexpr int kPotrfNB = 64;        // diagonal block factored in LDS
 constexpr int kPotrfPanel = 512;    // columns per outer panel
-
-// Cholesky of one NB x NB diagonal block (lower triangle, column-major, ld) in LDS, right-looking, one workgroup.
-// *info = (1-based global index of the first non-positive pivot) if the block is not positive definite, untouched otherwise.
-__global__ void __launch_bounds__(256) k_potrf_block(double *__restrict__ A, long ld, int nb, long offset, int *__restrict__ info) {
-  __shared__ double a[kPotrfNB][kPotrfNB + 1];
-  __shared__ int bad;
-  for (int idx = threadIdx.x; idx < nb * nb; idx += 256) { const int i = idx % nb, j = idx / nb; a[i][j] = i >= j ? A[i + (long)j * ld] : 0.0; }
-  if (threadIdx.x == 0) bad = 0;
-  __syncthreads();
-  for (int j = 0; j < nb; j++) {
-    const double d = a[j][j];
-    if (!(d > 0.0)) { if (threadIdx.x == 0) { bad = 1; atomicCAS(info, 0, (int)(offset + j + 1)); } }
-    __syncthreads();
-    if (bad) return;
-    const double l = sqrt(d);
-    for (int i = j + threadIdx.x; i < nb; i += 256) a[i][j] = i == j ? l : a[i][j] / l;
-    __syncthreads();
-    // trailing update of the lower triangle: a[i][k] -= a[i][j] * a[k][j], j < k <= i
-    const int t = nb - j - 1;
-    for (int idx = threadIdx.x; idx < t * t; idx += 256) {
-      const int i = j + 1 + idx % t, k = j + 1 + idx / t;
-      if (k <= i) a[i][k] -= a[i][j] * a[k][j];
-    }
-    __syncthreads();
-  }
-  for (int idx = threadIdx.x; idx < nb * nb; idx += 256) { const int i = idx % nb, j = idx / nb; if (i >= j) A[i + (long)j * ld] = a[i][j]; }
-}
 
 // logdet(A) = sum_i 2 log L_ii of the Cholesky factor (reference trace_kernel, solve_cuda.cu:884-909, which adds with atomics);
 // here one workgroup, fixed-order tree: bitwise reproducible
@@ -133,16 +68,15 @@ static int dense_solve_impl(const double *A, unsigned int input_size, const doub
                             int oversubscribe) {
   if (!A || !B || !X || input_size == 0 || rhs_cols == 0) { set_error(1, "potrs_solve_gpu: invalid argument"); return 1; }
   if (oversubscribe != 0 && oversubscribe != 1) { set_error(1, "potrs_solve_gpu: oversubscribe must be 0 or 1"); return 1; }
-  if (input_size > 0x7fffffffu) { set_error(1, "potrs_solve_gpu: matrix dimension exceeds the 32-bit rocBLAS interface"); return 1; }
   if (solve_select_device("potrs_solve_gpu")) return 1;
-  BlasLib &L = blas_lib();
-  if (!L.load()) return 1;
   const size_t n = input_size, nrhs = rhs_cols;
-  Dev dA, dB, dInfo, dLog;
+  const long nblk = (long)((n + kPotrfNB - 1) / kPotrfNB);
+  Dev dA, dB, dInfo, dLog, dInv;
   if (oversubscribe) MXA_HIP(hipMallocManaged(&dA.p, sizeof(double) * n * n));
   else MXA_HIP(hipMalloc(&dA.p, sizeof(double) * n * n));
   MXA_HIP(hipMalloc(&dB.p, sizeof(double) * n * nrhs));
   MXA_HIP(hipMalloc(&dInfo.p, sizeof(int)));
+  MXA_HIP(hipMalloc(&dInv.p, sizeof(double) * kPotrfNB * kPotrfNB * (size_t)nblk));   // inverted diagonal blocks
   MXA_HIP(hipMemset(dInfo.p, 0, sizeof(int)));
   MXA_HIP(hipMemcpy(dA.p, A, sizeof(double) * n * n, solve_is_device_ptr(A) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
   MXA_HIP(hipMemcpy(dB.p, B, sizeof(double) * n * nrhs, solve_is_device_ptr(B) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
@@ -150,36 +84,34 @@ static int dense_solve_impl(const double *A, unsigned int input_size, const doub
   const auto secs = [](std::chrono::steady_clock::time_point a0, std::chrono::steady_clock::time_point a1) { return std::chrono::duration<double>(a1 - a0).count(); };
   const bool verbose = env_print_level() > 0;   // timings like the reference's debug_info lines (solve_cuda.cu:157-259)
   auto t_start = verbose ? tick() : std::chrono::steady_clock::time_point();
-  rocblas_handle h = nullptr;
-  if (L.rocblas_create_handle(&h) != rocblas_status_success) { set_error(21, "potrs_solve_gpu: rocblas_create_handle failed"); return 1; }
-  double *a = static_cast<double *>(dA.p), *b = static_cast<double *>(dB.p);
-  const double one = 1.0, minus_one = -1.0;
-  const rocblas_int N = (rocblas_int)n;
+  double *a = static_cast<double *>(dA.p), *b = static_cast<double *>(dB.p), *inv = static_cast<double *>(dInv.p);
+  const long N = (long)n;
+  hipStream_t st = nullptr;
   int rc = 0;
   do {
     // lower triangle of the column-major image, as the reference (CUBLAS_FILL_MODE_LOWER, solve_cuda.cu:84); A is symmetric.
     // Two-level right-looking Cholesky.  Outer panels of kPotrfPanel columns; inside a panel, per 64-column step: factor the
-    // diagonal block, solve the block column below it (full height), update only the REST OF THE PANEL with a gemm; after the
-    // panel one syrk with k = kPotrfPanel updates the whole trailing matrix (a syrk per 64 columns re-reads it 8x as often and
-    // is memory-bound).
+    // diagonal block, invert it, solve the block column below it (full height) as A21 <- A21 L11^-T = A21 (L11^-1)^T -- a product, in
+    // place: a workgroup reads only the rows it writes --, update only the REST OF THE PANEL; after the panel one rank-512 update
+    // of the lower tiles of the whole trailing matrix (an update per 64 columns re-reads it 8x as often and is memory-bound).
     for (size_t K = 0; K < n && !rc; K += kPotrfPanel) {
       const size_t pw = std::min<size_t>(kPotrfPanel, n - K);          // panel width
       for (size_t k = K; k < K + pw && !rc; k += kPotrfNB) {
         const int nb = (int)std::min<size_t>(kPotrfNB, K + pw - k);
-        hipLaunchKernelGGL(k_potrf_block, dim3(1), dim3(256), 0, nullptr, a + k + k * n, (long)n, nb, (long)k, static_cast<int *>(dInfo.p));
-        const rocblas_int below = (rocblas_int)(n - k - nb);           // rows under the diagonal block
+        double *inv_k = inv + (k / kPotrfNB) * (size_t)(kPotrfNB * kPotrfNB);   // kept: the solves of the right-hand sides use it again
+        if (launch_potrf_inv_block(a + k + k * n, N, nb, (long)k, static_cast<int *>(dInfo.p), inv_k, st)) { rc = 1; break; }
+        const long below = (long)(n - k - nb);                         // rows under the diagonal block
         if (below <= 0) continue;
-        if (L.rocblas_dtrsm(h, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, below, nb, &one, a + k + k * n, N,
-                            a + (k + nb) + k * n, N) != rocblas_status_success) { set_error(21, "potrs_solve_gpu: rocBLAS trsm failed"); rc = 1; break; }
-        const rocblas_int rest = (rocblas_int)(K + pw - k - nb);       // columns of the panel still to the right
-        if (rest > 0 &&
-            L.rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_transpose, below, rest, nb, &minus_one, a + (k + nb) + k * n, N, a + (k + nb) + k * n, N, &one,
-                            a + (k + nb) + (k + nb) * n, N) != rocblas_status_success) { set_error(21, "potrs_solve_gpu: rocBLAS gemm failed"); rc = 1; break; }
+        double *a21 = a + (k + nb) + k * n;
+        if (launch_dgemm(false, true, below, nb, nb, 1.0, a21, N, inv_k, kPotrfNB, 0.0, a21, N, false, st)) { rc = 1; break; }
+        const long rest = (long)(K + pw - k - nb);                     // columns of the panel still to the right
+        if (rest > 0 && launch_dgemm(false, true, below, rest, nb, -1.0, a21, N, a21, N, 1.0, a + (k + nb) + (k + nb) * n, N, false, st)) { rc = 1; break; }
       }
-      const rocblas_int trailing = (rocblas_int)(n - K - pw);
-      if (!rc && trailing > 0 &&
-          L.rocblas_dsyrk(h, rocblas_fill_lower, rocblas_operation_none, trailing, (rocblas_int)pw, &minus_one, a + (K + pw) + K * n, N, &one,
-                          a + (K + pw) + (K + pw) * n, N) != rocblas_status_success) { set_error(21, "potrs_solve_gpu: rocBLAS syrk failed"); rc = 1; }
+      const long trailing = (long)(n - K - pw);
+      if (!rc && trailing > 0) {
+        const double *p21 = a + (K + pw) + K * n;
+        if (launch_dgemm(false, true, trailing, trailing, (long)pw, -1.0, p21, N, p21, N, 1.0, a + (K + pw) + (K + pw) * n, N, true, st)) rc = 1;
+      }
     }
     if (rc) break;
     if (verbose) { const auto t1 = tick(); debug_info("Time for potrf: %.3fs", secs(t_start, t1)); t_start = t1; }
@@ -188,11 +120,18 @@ static int dense_solve_impl(const double *A, unsigned int input_size, const doub
     if (info != 0) {   // wording of the reference (solve_cuda.cu:196-199); no device reset here
       set_error(22, "Error: Cholesky factorization failed at minor %d", info); rc = 1; break;
     }
-    // A X = B:  L Y = B, then L^T X = Y
-    if (L.rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N, (rocblas_int)nrhs, &one, a, N, b, N) != rocblas_status_success ||
-        L.rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, N, (rocblas_int)nrhs, &one, a, N, b, N) != rocblas_status_success) {
-      set_error(21, "potrs_solve_gpu: rocBLAS trsm failed"); rc = 1; break;
+    // A X = B:  L Y = B, then L^T X = Y, block by block with the inverted diagonal blocks (L is read once per solve)
+    for (long kb = 0; kb < nblk && !rc; kb++) {
+      const long off = kb * kPotrfNB, nb = std::min<long>(kPotrfNB, N - off), rest = N - off - nb;
+      if (launch_dgemm(false, false, nb, (long)nrhs, nb, 1.0, inv + kb * kPotrfNB * kPotrfNB, kPotrfNB, b + off, N, 0.0, b + off, N, false, st)) rc = 1;
+      if (!rc && rest > 0 && launch_dgemm(false, false, rest, (long)nrhs, nb, -1.0, a + (off + nb) + off * n, N, b + off, N, 1.0, b + off + nb, N, false, st)) rc = 1;
     }
+    for (long kb = nblk - 1; kb >= 0 && !rc; kb--) {
+      const long off = kb * kPotrfNB, nb = std::min<long>(kPotrfNB, N - off);
+      if (launch_dgemm(true, false, nb, (long)nrhs, nb, 1.0, inv + kb * kPotrfNB * kPotrfNB, kPotrfNB, b + off, N, 0.0, b + off, N, false, st)) rc = 1;
+      if (!rc && off > 0 && launch_dgemm(true, false, off, (long)nrhs, nb, -1.0, a + off, N, b + off, N, 1.0, b, N, false, st)) rc = 1;
+    }
+    if (rc) break;
     if (verbose) { const auto t1 = tick(); debug_info("Time for potrs: %.3fs", secs(t_start, t1)); t_start = t1; }
     if (logdet) {
       if (!check_hip(hipMalloc(&dLog.p, sizeof(double)), __func__, __LINE__)) { rc = 1; break; }
@@ -203,7 +142,6 @@ static int dense_solve_impl(const double *A, unsigned int input_size, const doub
     if (!check_hip(hipMemcpy(X, dB.p, sizeof(double) * n * nrhs, solve_is_device_ptr(X) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost), __func__, __LINE__)) { rc = 1; break; }
   } while (0);
   (void)hipDeviceSynchronize();
-  (void)L.rocblas_destroy_handle(h);
   return rc;
 }
 
