@@ -265,6 +265,10 @@ int mxa_ld(const unsigned char *plink, int snps, int indiv, double *R, int is_pl
  *    the only roundings are the <= 31 additions of the recombination, and |error| <= 3.02 * 31 * 2^-53 * sum_k |z_k b_k| per
  *    output -- tighter than the K * 2^-53 * sum_k |z_k b_k| of any fp64 FMA chain of length K >= 128.  If the check fails (or
  *    K < 128) the fp64 pair-table kernel runs instead; results then and with engine 3 are fp64 lookup-add sums.
+ *    3 <= n <= 6 (the products that would run on the narrowest MFMA tile, which the genotype extraction holds at 0.80 of the fp64 MFMA
+ *    rate): the same exact route with the digit count chosen per call as engine 4 does -- taken only when B is represented without
+ *    error (same bound with S <= 24), else the fp64 MFMA path; 1.2-1.7 ms instead of 3.2-4.4 ms on 500k x 50k.  n >= 7: fp64 MFMA, the
+ *    one or two odd columns of n = 4q + 1, 4q + 2 through the exact route when it is exact.  MXA_AUTO_EXACT_MAX_N=0 keeps n >= 3 on fp64.
  * 1 (opt-in, also MXA_ENGINE=i8 in the environment): the int8 slicing for every n with 7 digits (32 / 16 for n = 1 / 2) and NO
  *    exactness check: B is represented to 2^-54 of each column's largest |entry| (fixed point per column, not per element);
  *    results agree with engine 0 to ~1e-14 of each result column's largest entry on the test problems, at ~4x the throughput.

@@ -373,7 +373,11 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   // columns -- S = ceil((span + 55) / 8), at least 7 -- so that B is represented without error (the condition of the n <= 2 guard); the host reads
   // three integers (one short sync, irrelevant beside a multi-millisecond product).  Beyond 24 digits (span > 137 binades), for non-finite
   // entries, values near the underflow threshold or K < 128, the fp64 MFMA path below runs.  Error bound as for n <= 2 with S <= 24.
-  if (engine == 4 && n >= 3 && k >= 128) {
+  // Engine 0 takes the same route for 3 <= n <= 6 -- the products that would run on the single-group MFMA tile (4 columns per extraction: the
+  // tile the extraction VALU hurts most, MFMA pipe busy 0.82 at best; n = 5, 6 need a peel pass on top).  There the int8 route is bound by the
+  // packed-matrix stream like n <= 2 (1.3-1.9 ms against 3.2-4.4 ms on 500k x 50k), and it is taken only when it is exact.
+  static const int auto_exact_max_n = [] { const char *e = getenv("MXA_AUTO_EXACT_MAX_N"); return e ? atoi(e) : 6; }();
+  if ((engine == 4 || ((engine == 0 || (engine == 2 && n > 4)) && n <= auto_exact_max_n)) && n >= 3 && k >= 128) {   // engine 2 = engine 0 for n > 4
     int hs[3] = {0, 0, 1};
     if (launch_colspan(dB, ldb, k, n, w.d_colpart, w.d_denflag + 4, s)) return 1;
     MXA_HIP(hipMemcpyAsync(hs, w.d_denflag + 4, sizeof(hs), hipMemcpyDeviceToHost, s));
@@ -381,6 +385,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     const int S = std::max(7, (hs[0] + 55 + 7) / 8);
     if (!hs[2] && S <= kI8ExactMaxDigits && hs[1] >= 8 * S - 1023) {
       int splits8 = 1;
+      MXA_HIP(hipMemsetAsync(w.d_denflag, 0, sizeof(int), s));   // mxa_last_range_fallback: this product does not use the denormal-operand mode
       if (gemm_i8_device(G, trans, n, dB, ldb, dC, ldc, fill_rows, centered, d_sumB, d_sumfB, h->d_f, w, s, pe0, pe1, &splits8, 0, nullptr, nullptr, S)) return 1;
       std::lock_guard<std::mutex> lk(g_prof_mutex);
       Geometry &geo = last_geometry();
@@ -485,6 +490,10 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
   static const bool enabled = [] { const char *e = getenv("MXA_HOST_PIPELINE"); return !e || atoi(e) != 0; }();
   const int engine = g_engine.load();
   if (!enabled || (engine != 0 && engine != 3) || n < 3 || getenv("MXA_DIAG")) return 2;
+  {   // engine 0 sends 3 <= n <= 6 through the exact int8 route of gemm_device (plain upload; B is at most 6 columns)
+    static const int auto_exact_max_n = [] { const char *e = getenv("MXA_AUTO_EXACT_MAX_N"); return e ? atoi(e) : 6; }();
+    if (engine == 0 && n <= auto_exact_max_n) return 2;
+  }
   const PackedMatrix &G = trans ? h->snp_major : h->ind_major;
   const long m = G.rows, k = G.k;
   // b_host / c_host: the operand is not memory of this device -- host memory (PCIe) or memory of another GPU (peer copies over xGMI):

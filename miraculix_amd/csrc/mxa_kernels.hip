@@ -643,7 +643,7 @@ static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, c
   const int g8 = xcd_order ? (long_groups & ~7) : 0;
   MXA_HIP(hipMemsetAsync(d_ctr, 0, 9 * sizeof(int), s));
   static const bool diag_on = getenv("MXA_DIAG") != nullptr;
-  if (diag_on && A == 8 && C == 8 && split_begin == 0 && split_end == p.splits && !run_if_set) {   // diagnostic instantiation: in-kernel clock + cycles per slab
+  if (diag_on && ((A == 8 && C == 8) || (A == 16 && C == 1)) && split_begin == 0 && split_end == p.splits && !run_if_set) {   // diagnostic instantiation: in-kernel clock + cycles per slab
     static unsigned long long attr2 = 0;
     if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm<A, C, MODE, true>), Cfg::kLds, &attr2)) return 1;
     unsigned long long *d_diag = nullptr;

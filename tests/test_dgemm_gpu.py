@@ -49,6 +49,29 @@ def test_dgemm_vs_oracle(mx, snps, indiv, n, trans, centered):
     assert err <= RTOL, err
 
 
+@pytest.mark.parametrize("snps,indiv,n", [(1000, 500, 1), (2047, 771, 3), (5000, 1203, 4), (1003, 501, 5), (2600, 900, 6), (777, 1301, 10)])
+@pytest.mark.parametrize("trans", [0, 1])
+@pytest.mark.parametrize("centered", [0, 1])
+def test_dgemm_vs_oracle_fp64_arithmetic_only(mx, snps, indiv, n, trans, centered):
+    """engine 'f64-strict': fp64 arithmetic for every n -- the pair tables for n <= 2, the single-group MFMA tile for 3 <= n <= 6 (which the
+    default engine only uses when the exact int8 route declines), no column peel"""
+    o = Oracle()
+    dg = mx.dgemm_compressed
+    prob = make_problem(snps, indiv, n, seed=42 + snps)
+    k = indiv if trans else snps
+    m = snps if trans else indiv
+    B = make_B(k, n, seed=43)
+    ref = o.dgemm_dense(trans, prob, B, centered)[:, :m]
+    prev = dg.set_engine("f64-strict")
+    try:
+        C = _run(mx, prob, trans, B, centered)
+        assert dg.last_path() == ("k_lut" if n <= 2 else "k_gemm")
+    finally:
+        dg.set_engine(prev)
+    err = np.abs(C.T - ref).max() / np.abs(ref).max()
+    assert err <= RTOL, err
+
+
 def test_missing_codes_are_zero_then_centred(mx):
     o = Oracle()
     prob = make_problem(1203, 610, 8, seed=7, missing_frac=0.1)

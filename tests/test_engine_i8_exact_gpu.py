@@ -118,10 +118,10 @@ def test_integer_B_is_exact_and_matches_default_engine_closely(mx):
         assert np.array_equal(C.T, (prob["Z"].astype(np.int64) @ B.T.astype(np.int64)).astype(np.float64))
         B = make_B(3000, 6, seed=2)[:, :3000]
         C8 = _run(mx, obj, prob, 0, B)
-        assert dg.set_engine("f64") == "i8-exact"
+        assert dg.set_engine("f64-strict") == "i8-exact"
         C64 = _run(mx, obj, prob, 0, B)
         assert dg.last_path() == "k_gemm"
-        assert dg.set_engine("i8-exact") == "f64"
+        assert dg.set_engine("i8-exact") == "f64-strict"
         assert np.abs(C8 - C64).max() <= 1e-12 * np.abs(C64).max()
     finally:
         dg.free_compressed(obj)

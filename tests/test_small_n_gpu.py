@@ -178,8 +178,9 @@ def _last_n(mx):
 
 @pytest.mark.parametrize("n", [5, 6, 10, 33])
 def test_column_peel_exact_route_and_fallback(mx, n):
-    """n = 4q + 1 / 4q + 2: the odd columns take the guarded exact int8 route, the MFMA tile multiplies 4q columns without padding (the
-    reference harness's n = 10 becomes 8 + 2); a peeled column whose entries span too many binades sends all n columns to the MFMA"""
+    """n = 4q + 1 / 4q + 2, n > 6: the odd columns take the guarded exact int8 route, the MFMA tile multiplies 4q columns without padding (the
+    reference harness's n = 10 becomes 8 + 2); a peeled column whose entries span too many binades sends all n columns to the MFMA.
+    n = 5, 6 (3 <= n <= 6 in general): all columns take the exact int8 route when it is exact, the MFMA tile otherwise"""
     o = Oracle()
     snps, indiv = 2050, 777
     prob = _adversarial_problem(snps, indiv, seed=5)
@@ -193,7 +194,10 @@ def test_column_peel_exact_route_and_fallback(mx, n):
                 m = snps if trans else indiv
                 B = np.random.default_rng(n + trans).standard_normal((n, k))
                 C = _run(mx, obj, prob, trans, B)
-                assert _last_n(mx)[0] == n - n % 4                       # the MFMA launch saw the multiple of 4 only
+                if n <= 6:                                               # round 3: the whole product takes the exact int8 route
+                    assert dg.last_path() == "k_gemm_i8" and _last_n(mx)[0] == n
+                else:
+                    assert _last_n(mx)[0] == n - n % 4                   # the MFMA launch saw the multiple of 4 only
                 ref = o.dgemm_dense(trans, prob, B, centered)[:, :m]
                 assert np.abs(C - ref).max() <= 1e-11 * np.abs(ref).max()
                 B[n - 1] = _wide_B(k, 1, 70, seed=2, big_every=5)[0]     # 230 binades in the last column: guard declines

@@ -25,7 +25,14 @@ for trans in (False, True):
     m = snps if trans else indiv
     B = torch.randn((n, k), dtype=torch.float64, device=dev, generator=g).t()
     C = torch.zeros((n, m), dtype=torch.float64, device=dev).t()
-    dg.dgemm_compressed_main(trans, obj, B, snps, indiv, out=C)
+    # warm-up by time, not by count: the clock of an idle GPU ramps over the first ~0.3 s of work (rocprofv3 GRBM_GUI_ACTIVE: 2.07 -> 2.26 GHz over
+    # six 3 ms launches), which used to be charged to whichever product ran first
+    t_w = time.perf_counter()
+    while True:
+        dg.dgemm_compressed_main(trans, obj, B, snps, indiv, out=C)
+        torch.cuda.synchronize()
+        if time.perf_counter() - t_w > float(os.environ.get("WARM_S", "0.5")):
+            break
     L.mxa_profile_reset()
     t0 = time.perf_counter()
     for _ in range(reps):
