@@ -377,16 +377,25 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   // tile the extraction VALU hurts most, MFMA pipe busy 0.82 at best; n = 5, 6 need a peel pass on top).  There the int8 route is bound by the
   // packed-matrix stream like n <= 2 (1.3-1.9 ms against 3.2-4.4 ms on 500k x 50k), and it is taken only when it is exact.
   static const int auto_exact_max_n = [] { const char *e = getenv("MXA_AUTO_EXACT_MAX_N"); return e ? atoi(e) : 6; }();
-  if ((engine == 4 || ((engine == 0 || (engine == 2 && n > 4)) && n <= auto_exact_max_n)) && n >= 3 && k >= 128) {   // engine 2 = engine 0 for n > 4
+  // columns [c0, c0 + nc) of this product through the exact int8 route with per-call digits: 0 done, 2 declined (not exact within 24 digits), 1 error
+  auto exact_adaptive = [&](int c0, int nc, hipEvent_t e0, hipEvent_t e1, int *splits_out, int *digits_out) -> int {
     int hs[3] = {0, 0, 1};
-    if (launch_colspan(dB, ldb, k, n, w.d_colpart, w.d_denflag + 4, s)) return 1;
+    const double *dBc = dB + (size_t)c0 * ldb;
+    if (launch_colspan(dBc, ldb, k, nc, w.d_colpart, w.d_denflag + 4, s)) return 1;
     MXA_HIP(hipMemcpyAsync(hs, w.d_denflag + 4, sizeof(hs), hipMemcpyDeviceToHost, s));
     MXA_HIP(hipStreamSynchronize(s));
     const int S = std::max(7, (hs[0] + 55 + 7) / 8);
-    if (!hs[2] && S <= kI8ExactMaxDigits && hs[1] >= 8 * S - 1023) {
-      int splits8 = 1;
+    if (hs[2] || S > kI8ExactMaxDigits || hs[1] < 8 * S - 1023) return 2;
+    if (digits_out) *digits_out = S;
+    return gemm_i8_device(G, trans, nc, dBc, ldb, dC + (size_t)c0 * ldc, ldc, fill_rows, centered, d_sumB + c0, d_sumfB + c0, h->d_f, w, s, e0, e1, splits_out, 0,
+                          nullptr, nullptr, S) ? 1 : 0;
+  };
+  if ((engine == 4 || ((engine == 0 || (engine == 2 && n > 4)) && n <= auto_exact_max_n)) && n >= 3 && k >= 128) {   // engine 2 = engine 0 for n > 4
+    int splits8 = 1, S = 0;
+    const int rcx = exact_adaptive(0, n, pe0, pe1, &splits8, &S);
+    if (rcx == 1) return 1;
+    if (rcx == 0) {
       MXA_HIP(hipMemsetAsync(w.d_denflag, 0, sizeof(int), s));   // mxa_last_range_fallback: this product does not use the denormal-operand mode
-      if (gemm_i8_device(G, trans, n, dB, ldb, dC, ldc, fill_rows, centered, d_sumB, d_sumfB, h->d_f, w, s, pe0, pe1, &splits8, 0, nullptr, nullptr, S)) return 1;
       std::lock_guard<std::mutex> lk(g_prof_mutex);
       Geometry &geo = last_geometry();
       geo.m = m; geo.k = k; geo.n = n; geo.splits = splits8; geo.a = S; geo.c = 0; geo.path = 2; geo.d_flag = nullptr; geo.flag_dev = h->device;
@@ -427,6 +436,13 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
                                    nullptr, nullptr, nullptr, true);
     if (rc8 == 0) n = n4;            // the rest of this function multiplies the first n4 columns
     else if (rc8 != 2) return 1;
+  }
+  // n = 4q + 3, q >= 1 (round 3): the three odd columns through the exact route with per-call digits (1.2 ms on 500k x 50k) instead of a
+  // quarter-full MFMA group (2.7-2.9 ms)
+  if (peel_on && (engine == 0 || engine == 2) && n > 6 && n_odd == 3 && k >= 128 && auto_exact_max_n >= 3) {
+    const int rcx = exact_adaptive(n - 3, 3, nullptr, nullptr, nullptr, nullptr);
+    if (rcx == 1) return 1;
+    if (rcx == 0) n -= 3;
   }
   static const int lut_max_n = [] { const char *e = getenv("MXA_LUT_MAX_N"); return e ? atoi(e) : 2; }();
   const bool use_lut = n <= lut_max_n && n <= 4;

@@ -176,11 +176,12 @@ def _last_n(mx):
     return gn.value, ga.value, gc.value
 
 
-@pytest.mark.parametrize("n", [5, 6, 10, 33])
+@pytest.mark.parametrize("n", [5, 6, 7, 10, 15, 33])
 def test_column_peel_exact_route_and_fallback(mx, n):
     """n = 4q + 1 / 4q + 2, n > 6: the odd columns take the guarded exact int8 route, the MFMA tile multiplies 4q columns without padding (the
     reference harness's n = 10 becomes 8 + 2); a peeled column whose entries span too many binades sends all n columns to the MFMA.
-    n = 5, 6 (3 <= n <= 6 in general): all columns take the exact int8 route when it is exact, the MFMA tile otherwise"""
+    n = 5, 6 (3 <= n <= 6 in general): all columns take the exact int8 route when it is exact, the MFMA tile otherwise.
+    n = 4q + 3 > 6: the three odd columns take the exact route with per-call digits"""
     o = Oracle()
     snps, indiv = 2050, 777
     prob = _adversarial_problem(snps, indiv, seed=5)
