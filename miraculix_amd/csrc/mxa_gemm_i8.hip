@@ -225,6 +225,12 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
   if (skip_if_set && *skip_if_set) return;
   constexpr int NTW = NT / WC;
   static_assert(NT % WC == 0 && MT * (4 / WC) == 8 && MT * NTW <= 16, "wave tiling");
+  // Operand roles (round 3).  The matrix cores draw less power when the FULL-entropy operand (the radix-256 digits) is the instruction's A and the
+  // low-entropy one (genotype bytes 0..2) its B: a bare MFMA loop runs 4.17 Pop/s at 2.11 GHz that way round against 3.60 at 1.84 GHz the other
+  // (tools/mfma_i8_probe3.hip), and from two tiles on this kernel is power-bound.  The fragments are symmetric (a lane holds 16 consecutive k of one
+  // row / column), so swapping them just transposes the accumulator tile: lane & 31 = genotype row, registers = expanded column; the partial sums
+  // then go to P TRANSPOSED, P[split][e][row] (rows along the lanes: 128-byte runs), and k_finish_i8_t reads them that way.
+  constexpr bool kSwap = NT >= 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -321,7 +327,9 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
         for (int b = 0; b < NTW; b++)
           if (b >= lo && b < hi) bf_nxt[b] = *reinterpret_cast<const v4i *>(bsrc + b * 1024);
 #pragma unroll
-        for (int b = 0; b < NTW; b++) acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af_cur, bf_cur[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < NTW; b++)
+          acc[a][b] = kSwap ? __builtin_amdgcn_mfma_i32_32x32x32_i8(bf_cur[b], af_cur, acc[a][b], 0, 0, 0)
+                            : __builtin_amdgcn_mfma_i32_32x32x32_i8(af_cur, bf_cur[b], acc[a][b], 0, 0, 0);
         SchedIter<0, NTW, (NTW + MT - 1) / MT>::run();
         __builtin_amdgcn_sched_barrier(0);
         af_cur = af_nxt;
@@ -374,6 +382,19 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
     return;
   }
   int *Pb = P + (size_t)sp * m_pad * e_pad;
+  if (kSwap) {
+#pragma unroll
+    for (int a = 0; a < MT; a++)
+#pragma unroll
+      for (int b = 0; b < NTW; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const long row = (long)rb * kTileRows + wr * (MT * 32) + a * 32 + col;
+          const int e = nc * (NT * 32) + (wc * NTW + b) * 32 + (r & 3) + 8 * (r >> 2) + rq;
+          Pb[(size_t)e * m_pad + row] = acc[a][b][r];
+        }
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < MT; a++)
 #pragma unroll
@@ -476,6 +497,44 @@ __global__ void __launch_bounds__(256) k_finish_i8(const int *__restrict__ P, lo
   }
 }
 
+
+// finish for the TRANSPOSED partial sums of the operand-swapped instantiations (NT >= 2): P[split][e][row], e = chunk * NT * 32 + s * nc + jj.
+// One thread per (row, column): every load is a 1 KiB run along the rows, C is written along the rows.  Same arithmetic, in the same order, as
+// k_finish_i8: exact int64 sums over the splits, digits added smallest scale first.
+__global__ void __launch_bounds__(256) k_finish_i8_t(const int *__restrict__ P, long m_pad, int e_pad, int splits, long m, int n, int S, int nc, int NT,
+                                                     const int *__restrict__ E, const double *__restrict__ colmax_part, double *__restrict__ Cout, long ldc,
+                                                     long fill_rows, int mode_trans, int centered, const double *__restrict__ sumB, const double *__restrict__ sumfB,
+                                                     const double *__restrict__ f, const int *__restrict__ skip_if_set) {
+  if (skip_if_set && *skip_if_set) return;
+  const int j = blockIdx.y, chunk = j / nc, jj = j - chunk * nc;
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  __shared__ int bad;
+  if (threadIdx.x == 0) {
+    double cm = 0.0;
+    for (int c = 0; c < 64; c++) cm = fmax(cm, colmax_part[(size_t)j * 64 + c]);
+    bad = !(cm <= 1.7976931348623157e308);      // column holds an inf or a NaN: the result column is NaN, like 0 * inf in fp64
+  }
+  __syncthreads();
+  if (r >= fill_rows) return;
+  double v = 0.0;
+  if (r < m) {
+    if (bad) v = __longlong_as_double(0x7ff8000000000000ll);
+    else {
+      const int Ej = E[j];
+      const int *p0 = P + (size_t)(chunk * (NT * 32) + jj) * m_pad + r;
+      for (int s = S - 1; s >= 0; s--) {
+        long long t = 0;
+        for (int sp = 0; sp < splits; sp++) t += p0[((size_t)sp * e_pad + (size_t)s * nc) * m_pad];
+        v += ldexp((double)t, Ej - 8 * (s + 1));
+      }
+    }
+    if (centered) {
+      if (mode_trans) v = fma(-2.0 * sumB[j], f[r], v);
+      else v += -2.0 * sumfB[j];
+    }
+  }
+  Cout[r + (long)j * ldc] = v;
+}
 
 // n <= 2 (one tile of 32 expanded columns, e = s * nc + jj, nc * S <= 32, nc = 1 or 2).  Pure HBM streaming: splits x 128 bytes per row.  Eight
 // threads share a row, each with four digits (one 16-byte load per split -- a wave reads 1 KiB runs); four rows per thread, all their loads
@@ -718,6 +777,10 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   } else if (small_tile) {   // n <= 2: one tile, the fast finish
     hipLaunchKernelGGL(k_finish_i8_small, dim3((unsigned)((fill_rows + kFinSmallBlockRows - 1) / kFinSmallBlockRows)), dim3(256), 0, s, d_P, p.m_pad, p.splits, m, n, p.S, p.nc, d_E, d_part, dC, ldc, fill_rows,
                        trans ? 1 : 0, centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip);
+  } else if (p.NT >= 2) {   // operand-swapped instantiations: transposed partial sums
+    dim3 grid((unsigned)((fill_rows + 255) / 256), (unsigned)n);
+    hipLaunchKernelGGL(k_finish_i8_t, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, d_part, dC, ldc, fill_rows, trans ? 1 : 0,
+                       centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip);
   } else {
     dim3 grid((unsigned)((fill_rows + 31) / 32), p.nchunks);
     hipLaunchKernelGGL(k_finish_i8, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, d_part, dC, ldc, fill_rows, trans ? 1 : 0,
