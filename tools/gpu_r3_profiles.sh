@@ -22,7 +22,10 @@ timeout -k 10 600 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d "$O
 cd "$R"
 python3 tools/pmc_mfma_util.py "$O/pmc1" "k_gemm<8, 8, 2" "$O/pmc_mfma_util.json" > "$O/pmc_util.txt" 2>&1
 rm -rf "$O/pmc1"
-{ for n in 3 4 5 8 10 12 16 20 32 33 64 128; do python3 tools/perf_gemm.py 500000 50000 $n 5 2>&1 | grep tile; done; } > "$O/gemm_by_n_500k_x_50k.txt"
+bash tools/gpu_r3_gemm_by_n.sh > /dev/null 2>&1; cp gpurun_out/r03/gemm_by_n_warm.txt "$O/gemm_by_n_500k_x_50k.txt"
+bash tools/gpu_r3_pmc_narrow.sh > "$O/pmc_narrow.txt" 2>&1
+(cd /tmp && stats solve_dense python3 "$R/tools/perf_solve_dense.py")
+PRINT_LEVEL=1 python3 tools/perf_solve.py > "$O/solve_perf.txt" 2>&1
 { for n in 1 2; do CENTERED=1 python3 tools/perf_gemm.py 250000 100000 $n 20 2>&1 | grep tile; done; python3 tools/perf_gram.py 250000 100000 1 2>&1 | grep "G\*v"; } > "$O/small_n_config5_shard.txt"
 sed -i 's|gpurun_out/r03"|gpurun_out/r03p"|' tools/trace_gram.sh; bash tools/trace_gram.sh > "$O/gram_step_kernel_timeline.txt" 2>&1
 python3 bench.py --steps 20 --warmup 5 > "$O/bench_n1.json" 2> "$O/bench_n1.err"
