@@ -125,3 +125,47 @@ def test_integer_B_is_exact_and_matches_default_engine_closely(mx):
         assert np.abs(C8 - C64).max() <= 1e-12 * np.abs(C64).max()
     finally:
         dg.free_compressed(obj)
+
+
+def test_sharded_object_and_fused_gram_step(mx):
+    """the engine behind a multi-shard object (every shard chooses its own digit count for its rows of B) and through the fused CG step
+    mxa_gram_matvec at n = 12: against the oracle, and the fused step bit-identical to its two products"""
+    import os
+    o = Oracle()
+    snps, indiv, n = 4100, 901, 12
+    prob = make_problem(snps, indiv, n, seed=21)
+    dg = mx.dgemm_compressed
+    dg.set_options(use_gpu=True, not_center=False, verbose=0)
+    old = os.environ.get("MIRACULIX_NUM_GPUS")
+    os.environ["MIRACULIX_NUM_GPUS"] = "3"
+    try:
+        obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], n)
+    finally:
+        if old is None:
+            os.environ.pop("MIRACULIX_NUM_GPUS", None)
+        else:
+            os.environ["MIRACULIX_NUM_GPUS"] = old
+    try:
+        assert dg.num_shards(obj) == 3
+        for trans in (0, 1):
+            k, m = (indiv, snps) if trans else (snps, indiv)
+            B = make_B(k, n, seed=5 + trans)[:, :k]
+            B[3] *= 1e-7
+            C = _run(mx, obj, prob, trans, B)
+            ref = o.dgemm_dense(trans, prob, B, 1)[:, :m]
+            assert (np.abs(C - ref).max(axis=1) / np.abs(ref).max(axis=1)).max() <= 1e-11
+    finally:
+        dg.free_compressed(obj)
+    obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], n)
+    try:
+        V = np.asfortranarray(make_B(indiv, n, seed=9)[:, :indiv].T)
+        G = dg.gram_matvec(obj, V, snps, indiv)
+        assert dg.last_path() == "k_gemm_i8"
+        T = dg.dgemm_compressed_main(True, obj, V, snps, indiv)
+        N = dg.dgemm_compressed_main(False, obj, np.asfortranarray(T), snps, indiv)
+        assert np.array_equal(G, N)
+        refT = o.dgemm_dense(1, prob, np.ascontiguousarray(V.T), 1)[:, :snps]
+        refG = o.dgemm_dense(0, prob, refT, 1)[:, :indiv]
+        assert np.abs(G.T - refG).max() <= 1e-10 * np.abs(refG).max()
+    finally:
+        dg.free_compressed(obj)
