@@ -91,3 +91,42 @@ def test_sampled_rows_vs_dense_oracle(big):
     ref = o.dgemm_dense(1, prob, np.ascontiguousarray(X.t().cpu().numpy()), 0)
     got = ZtX[torch.from_numpy(ss).to(big["dev"])].t().cpu().numpy()
     assert np.abs(got - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+def test_exact_int8_engine_at_full_size(big):
+    """engine i8-exact at 1M x 50k x 32: taken (standard-normal B needs 10-11 digits), adjoint identity, agreement with the fp64 engine, and the stated
+    element-wise bound |error| <= 3.02 (S - 1) 2^-53 sum_k |z_k b_k| on 32 sampled individuals against the long-double dense oracle"""
+    torch, dg, mx = big["torch"], big["dg"], big["mx"]
+    o = Oracle()
+    g = torch.Generator(device=big["dev"]); g.manual_seed(11)
+    Y = torch.randn((N, SNPS), dtype=torch.float64, device=big["dev"], generator=g).t()
+    X = torch.randn((N, INDIV), dtype=torch.float64, device=big["dev"], generator=g).t()
+    ZY64 = dg.dgemm_compressed_main(False, big["obj"], Y, SNPS, INDIV)
+    assert dg.last_path() == "k_gemm"
+    prev = dg.set_engine("i8-exact")
+    try:
+        ZY = dg.dgemm_compressed_main(False, big["obj"], Y, SNPS, INDIV)
+        assert dg.last_path() == "k_gemm_i8"
+        L = mx.check_library_handle()
+        gm, gk, gn, gs, ga, gc = ctypes.c_long(), ctypes.c_long(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        L.mxa_last_geometry(ctypes.byref(gm), ctypes.byref(gk), ctypes.byref(gn), ctypes.byref(gs), ctypes.byref(ga), ctypes.byref(gc))
+        S = ga.value
+        assert 9 <= S <= 13
+        ZtX = dg.dgemm_compressed_main(True, big["obj"], X, SNPS, INDIV)
+        assert dg.last_path() == "k_gemm_i8"
+        assert torch.equal(ZY, dg.dgemm_compressed_main(False, big["obj"], Y, SNPS, INDIV))      # bitwise repeatable
+    finally:
+        dg.set_engine(prev)
+    lhs, rhs = (X * ZY).sum(dim=0), (ZtX * Y).sum(dim=0)
+    assert float(((lhs - rhs).abs() / lhs.abs().clamp_min(1.0)).max()) <= 1e-10
+    assert float(((ZY - ZY64).abs().amax(dim=0) / ZY64.abs().amax(dim=0)).max()) <= 1e-13
+    rng = np.random.default_rng(2)
+    ii = np.sort(rng.choice(INDIV, 32, replace=False))
+    rows = big["plink_t"][torch.from_numpy(ii).to(big["dev"])].cpu().numpy()
+    sub_plink = o.transpose_2bit(np.ascontiguousarray(rows), 32, SNPS)
+    prob = dict(snps=SNPS, indiv=32, plink=sub_plink, plink_t=rows, f=np.zeros(SNPS))
+    Bh = np.ascontiguousarray(Y.t().cpu().numpy())
+    ref = o.dgemm_dense(0, prob, Bh, 0)                                                          # 32 x 32
+    abssum = o.dgemm_dense(0, prob, np.abs(Bh), 0)
+    got = ZY[torch.from_numpy(ii).to(big["dev"])].t().cpu().numpy()
+    assert np.all(np.abs(got - ref) <= 3.02 * (S - 1) * 2.0 ** -53 * abssum)
