@@ -21,6 +21,9 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL, CUDA-tensor sharing): keep the setting if the launcher's environment lost it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
