@@ -143,7 +143,9 @@ int mxa_gram_matvec(void *compressed, int n, const double *V, long ldv, double *
 /* the same with device-resident V / out (memory of the object's device) and optional asynchrony: sync == 0 returns when both products are
  * enqueued on the object's stream -- a blocking stream, so work the caller enqueues afterwards on the device's default stream (PyTorch, hipBLAS
  * on stream 0) is ordered behind it and a CG / GBLUP loop on device-resident vectors never waits on the host: the ~40 us between two
- * synchronous calls (return, caller, next launch) disappear from every iteration.  Single-device objects only.  Returns 0 / 1. */
+ * synchronous calls (return, caller, next launch) disappear from every iteration.  Single-device objects only.  Returns 0 / 1.
+ * (n <= 2 -- the CG / GBLUP case -- never waits on the host.  For n >= 3 a product that takes the exact int8 route with per-call digits (engine 0:
+ * 3 <= n <= 6 and peeled columns; engine 4: every n) reads three integers back first, i.e. the call blocks for the work enqueued before it.) */
 int mxa_gram_matvec_device(void *compressed, int n, const double *dV, long ldv, double *dOut, long ldo, int sync);
 
 /* on-device .bed staging helpers (reference counterparts live in the bindings:
