@@ -94,9 +94,28 @@ static int dense_solve_impl(const double *A, unsigned int input_size, const doub
     // diagonal block, invert it, solve the block column below it (full height) as A21 <- A21 L11^-T = A21 (L11^-1)^T -- a product, in
     // place: a workgroup reads only the rows it writes --, update only the REST OF THE PANEL; after the panel one rank-512 update
     // of the lower tiles of the whole trailing matrix (an update per 64 columns re-reads it 8x as often and is memory-bound).
-    for (size_t K = 0; K < n && !rc; K += kPotrfPanel) {
+    // LOOKAHEAD (round 3): the in-panel steps are a chain of ~32 small dependent launches (~1 ms per panel, 29 ms of a 66 ms factorisation at
+    // n = 15 000) during which the chip idles.  Panel p's update is therefore split: its part for the columns of panel p + 1 (L(p)) stays on the
+    // factorisation stream, the rest (B(p): columns from panel p + 2 on) goes to a second stream, and panel p + 1 is factored while B(p) runs.
+    // Ordering: B(p) after F(p) (event) and after B(p - 1) (same stream); L(p) after B(p - 1) (both update panel p + 1's columns: event);
+    // F(p + 1) after L(p) (same stream).  The second stream then runs the big updates back to back.
+    const size_t npanels = (n + kPotrfPanel - 1) / kPotrfPanel;
+    struct Ev { std::vector<hipEvent_t> v; ~Ev() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); } } evF, evB;
+    struct St { hipStream_t s = nullptr; ~St() { if (s) (void)hipStreamDestroy(s); } } sA, sB;
+    evF.v.assign(npanels, nullptr); evB.v.assign(npanels, nullptr);
+    // the factorisation chain gets the higher priority: its one-workgroup launches must not queue behind the thousands of workgroups of an update
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (!check_hip(hipStreamCreateWithPriority(&sA.s, hipStreamNonBlocking, prio_hi), __func__, __LINE__) ||
+        !check_hip(hipStreamCreateWithPriority(&sB.s, hipStreamNonBlocking, prio_lo), __func__, __LINE__)) { rc = 1; break; }
+    st = sA.s;
+    for (size_t q = 0; q < npanels && !rc; q++)
+      if (!check_hip(hipEventCreateWithFlags(&evF.v[q], hipEventDisableTiming), __func__, __LINE__) ||
+          !check_hip(hipEventCreateWithFlags(&evB.v[q], hipEventDisableTiming), __func__, __LINE__)) rc = 1;
+    if (rc) break;
+    for (size_t K = 0, pi = 0; K < n && !rc; K += kPotrfPanel, pi++) {
       const size_t pw = std::min<size_t>(kPotrfPanel, n - K);          // panel width
-      for (size_t k = K; k < K + pw && !rc; k += kPotrfNB) {
+      for (size_t k = K; k < K + pw && !rc; k += kPotrfNB) {           // F(pi)
         const int nb = (int)std::min<size_t>(kPotrfNB, K + pw - k);
         double *inv_k = inv + (k / kPotrfNB) * (size_t)(kPotrfNB * kPotrfNB);   // kept: the solves of the right-hand sides use it again
         if (launch_potrf_inv_block(a + k + k * n, N, nb, (long)k, static_cast<int *>(dInfo.p), inv_k, st)) { rc = 1; break; }
@@ -107,12 +126,26 @@ static int dense_solve_impl(const double *A, unsigned int input_size, const doub
         const long rest = (long)(K + pw - k - nb);                     // columns of the panel still to the right
         if (rest > 0 && launch_dgemm(false, true, below, rest, nb, -1.0, a21, N, a21, N, 1.0, a + (k + nb) + (k + nb) * n, N, false, st)) { rc = 1; break; }
       }
+      if (rc) break;
       const long trailing = (long)(n - K - pw);
-      if (!rc && trailing > 0) {
-        const double *p21 = a + (K + pw) + K * n;
-        if (launch_dgemm(false, true, trailing, trailing, (long)pw, -1.0, p21, N, p21, N, 1.0, a + (K + pw) + (K + pw) * n, N, true, st)) rc = 1;
+      if (trailing <= 0) break;
+      if (!check_hip(hipEventRecord(evF.v[pi], st), __func__, __LINE__)) { rc = 1; break; }
+      const long pw1 = std::min<long>(kPotrfPanel, trailing);          // width of the next panel
+      const double *p21 = a + (K + pw) + K * n;                        // panel pi below its own diagonal blocks: trailing x pw
+      // L(pi): the next panel's columns, all trailing rows
+      if (pi > 0 && !check_hip(hipStreamWaitEvent(st, evB.v[pi - 1], 0), __func__, __LINE__)) { rc = 1; break; }
+      if (launch_dgemm(false, true, trailing, pw1, (long)pw, -1.0, p21, N, p21, N, 1.0, a + (K + pw) + (K + pw) * n, N, false, st)) { rc = 1; break; }
+      // B(pi): everything to the right of the next panel, lower tiles only
+      const long far = trailing - pw1;
+      if (far > 0) {
+        const double *p31 = p21 + pw1;
+        if (!check_hip(hipStreamWaitEvent(sB.s, evF.v[pi], 0), __func__, __LINE__)) { rc = 1; break; }
+        if (launch_dgemm(false, true, far, far, (long)pw, -1.0, p31, N, p31, N, 1.0, a + (K + pw + pw1) + (K + pw + pw1) * n, N, true, sB.s)) { rc = 1; break; }
       }
+      if (!check_hip(hipEventRecord(evB.v[pi], sB.s), __func__, __LINE__)) { rc = 1; break; }
     }
+    if (!check_hip(hipStreamSynchronize(sB.s), __func__, __LINE__) || !check_hip(hipStreamSynchronize(sA.s), __func__, __LINE__)) rc = 1;
+    st = nullptr;   // the solves below: legacy default stream (both streams are idle and are destroyed at the end of this scope)
     if (rc) break;
     if (verbose) { const auto t1 = tick(); debug_info("Time for potrf: %.3fs", secs(t_start, t1)); t_start = t1; }
     int info = 0;
