@@ -42,6 +42,18 @@ int env_print_level() {  // reference: cuda_utils.cu:44-52, env PRINT_LEVEL
   return e ? atoi(e) : 0;
 }
 
+// Banner of the reference (cuda_utils.cu:64-81: name, compile date, git commit), once per process; printed under PRINT_LEVEL > 0 /
+// print_details only -- the reference prints it by default, this library is quiet unless asked.
+#ifndef MXA_COMMIT_ID
+#define MXA_COMMIT_ID "unknown"
+#endif
+void print_compile_info(const char *what) {
+  static std::atomic<bool> done{false};
+  if (done.exchange(true)) return;
+  printf("------------------------------------------------------------\n\tmiraculix_amd (MI355X / gfx950) - %s\nCompiled on %s %s, git commit %s\n"
+         "------------------------------------------------------------\n", what, __DATE__, __TIME__, MXA_COMMIT_ID);
+}
+
 // The status is per process, like the reference's (its entries return void and print).  Worker threads of a multi-device object
 // report through the same state: the mutex keeps the message intact, the first error of a call wins.
 static std::mutex g_prof_mutex;   // profile() / last_geometry() are written by the worker threads of multi-device objects too
@@ -229,6 +241,7 @@ int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink
   if (dev < 0) return 1;
   if (env_print_level() > 0 || o.print_level > 0) {
     hipDeviceProp_t prop;
+    print_compile_info("dgemm_compressed");
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) printf("miraculix_amd - dgemm_compressed: using device %s (device no %d).\n", prop.name, dev);
   }
   // memory pre-flight like checkDevMemory (cuda_utils.cu:162-185)

@@ -21,3 +21,9 @@ def test_c_driver(tmp_path):
     r = subprocess.run([exe, "1000", "500"], capture_output=True, text=True, timeout=300, env=dict(os.environ, MIRACULIX_NUM_GPUS="3"))
     assert r.returncode == 0, r.stdout + r.stderr
     assert "c_driver ok" in r.stdout
+    # PRINT_LEVEL > 0 (reference: cuda_utils.cu:44-81): the compile banner once per process, the device line, the timings of debug_info
+    r = subprocess.run([exe, "1000", "500"], capture_output=True, text=True, timeout=300, env=dict(os.environ, PRINT_LEVEL="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("Compiled on") == 1 and "git commit" in r.stdout and "using device" in r.stdout
+    quiet = subprocess.run([exe, "1000", "500"], capture_output=True, text=True, timeout=300, env={k: v for k, v in os.environ.items() if k != "PRINT_LEVEL"})
+    assert "Compiled on" not in quiet.stdout
