@@ -151,6 +151,7 @@ struct Shard {
   hipEvent_t ev_pushed = nullptr;            // copy stream: the partial has landed on the root
   hipEvent_t ev_push0 = nullptr, ev_push1 = nullptr;   // timing of the push (or of ncclReduce on shard 0's copy stream)
   bool push_pending = false;
+  bool pushed_recorded = false;              // ev_pushed has been recorded at least once (the next 'N' product of this shard waits for it)
   int pushes = 0; double push_ms = 0.0;
   int peer_to_root = -1, peer_from_root = -1;
 };
@@ -437,7 +438,7 @@ static int publish_partial(Multi *m, int g, long rows, int n, bool push) {
     MXA_HIP(hipMemcpyPeerAsync(S.d_land, m->root, S.d_part, h->device, sizeof(double) * (size_t)rows * n, S.cs));
     MXA_HIP(hipEventRecord(S.ev_push1, S.cs));
     MXA_HIP(hipEventRecord(S.ev_pushed, S.cs));
-    S.push_pending = true;
+    S.push_pending = true; S.pushed_recorded = true;
   }
   return 0;
 }
@@ -486,10 +487,17 @@ static int reduce_rccl(Multi *m, long rows, int n, double *dC, long ldc, long fi
   }
   if (rc) { set_error(17, "ncclReduce failed: %s", r.GetErrorString ? r.GetErrorString(rc) : "?"); return 1; }
   MXA_HIP(he);
+  // every rank's ncclReduce reads its own partial on its own copy stream: the shard's next 'N' product waits for THAT (the root's completion
+  // alone does not order the other ranks' kernels)
+  for (int g = 1; g < G; g++) {
+    MXA_HIP(hipSetDevice(m->sh[g].h->device));
+    MXA_HIP(hipEventRecord(m->sh[g].ev_pushed, m->sh[g].cs));
+    m->sh[g].pushed_recorded = true;
+  }
   MXA_HIP(hipSetDevice(m->root));
   MXA_HIP(hipEventRecord(S0.ev_push1, S0.cs));
   MXA_HIP(hipEventRecord(S0.ev_pushed, S0.cs));
-  S0.push_pending = true;
+  S0.push_pending = true; S0.pushed_recorded = true;
   MXA_HIP(hipStreamWaitEvent(m->root_stream, S0.ev_pushed, 0));
   harvest_reduce(m);
   MXA_HIP(hipEventRecord(m->ev_red0, m->root_stream));
@@ -512,6 +520,7 @@ static int rccl_cross_check(Multi *m, long rows, int n) {
     MXA_HIP(hipSetDevice(S.h->device));
     MXA_HIP(hipMemcpyPeerAsync(S.d_land, m->root, S.d_part, S.h->device, sizeof(double) * (size_t)rows * n, S.cs));
     MXA_HIP(hipEventRecord(S.ev_pushed, S.cs));
+    S.pushed_recorded = true;
   }
   if (reduce_p2p(m, rows, n, m->d_chk, rows, rows, false)) return 1;
   MXA_HIP(hipStreamSynchronize(m->root_stream));
@@ -613,6 +622,7 @@ static int multi_product(Multi *m, bool trans, int n, const double *B, const dou
       MXA_HIP(hipSetDevice(S.h->device));
       // the previous reduction has read this shard's partial (and its landing buffer) before the product overwrites it
       if (m->red_recorded) MXA_HIP(hipStreamWaitEvent(S.h->stream, m->ev_red1, 0));
+      if (S.pushed_recorded) MXA_HIP(hipStreamWaitEvent(S.h->stream, S.ev_pushed, 0));   // ... and this shard's own push / ncclReduce has read it
       const double *Bg = per_shard ? Bs[g] : B + S.begin;
       // a B in host memory or on another GPU: synchronous inside the shard's own worker thread, so that a big one arrives in K ranges behind
       // the product (gemm_host_pipelined)
@@ -662,6 +672,7 @@ int multi_gram(void *obj, int n, const double *V, long ldv, double *out, long ld
     Shard &S = m->sh[g];
     MXA_HIP(hipSetDevice(S.h->device));
     if (m->red_recorded) MXA_HIP(hipStreamWaitEvent(S.h->stream, m->ev_red1, 0));
+    if (S.pushed_recorded) MXA_HIP(hipStreamWaitEvent(S.h->stream, S.ev_pushed, 0));
     if (gram_any(S.h, n, V, ldv, S.d_part, indiv, false)) return 1;
     return publish_partial(m, g, indiv, n, !m->use_rccl);
   });
