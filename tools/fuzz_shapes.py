@@ -51,5 +51,7 @@ for c in range(cases):
                 sys.exit(1)
     finally:
         dg.free_compressed(obj)
+    if (c + 1) % 50 == 0:
+        print(f"fuzz: {c + 1} / {cases} cases, worst so far {worst:.2e}", flush=True)   # a silent run is taken for a hung one on the GPU box
 dg.set_engine("f64")
 print(f"fuzz: {cases} cases x 2 products ok, worst column-wise relative error {worst:.2e}, paths {paths}")
