@@ -84,41 +84,101 @@ __device__ __forceinline__ v4i unpack16(uint32_t w) {
   return r;
 }
 
+// Element-wise map applied by the epilogue (round 3: the GRM / LD post-processing of the reference's binding, crossproduct.jl:83-152, FUSED into
+// the crossproduct -- SURVEY.md 8f-3 -- instead of three more passes over the 8 n^2-byte result).  Everything the map needs is known BEFORE the
+// product: the column sums of M = X X^T are X (X^T 1) and its diagonal is the row-wise sum of squares, both exact integers computed from the staged
+// 2-bit matrix (k_x_colsum, k_x_rowstats).  The same two functions serve the unfused kernels (k_grm_update, k_ld_center / k_ld_scale: kept for
+// MXA_XPROD_FUSED_POST=0 and as the bit-identity check of the tests): i = row index, j = column index of the element as stored.
+struct XPost {
+  const double *u = nullptr;      // GRM: column sums cs of M;  LD: allele frequencies f
+  const double *w = nullptr;      // LD: 1 / sigma
+  const double *scal = nullptr;   // GRM: scal[0] = sum(cs), scal[1] = 2 sum f (1 - f)
+  double a = 0.0;                 // GRM: 1 / n;  LD: 4 * indiv
+  int do_scale = 0;
+};
+// The two divisions of the reference (by the scalar c, by sigma_i and sigma_j) are multiplications by reciprocals formed once (<= 1 ulp from the
+// quotient; the stated tolerance of this path is 1e-12): an fp64 division is ~15 instructions on the pipe the epilogue shares with nothing else.
+__device__ __forceinline__ double grm_map(double v, double cs_i, double cs_j, double inv_n, double tot_nn, double inv_c, int do_scale) {
+  v = fma(-cs_i, inv_n, v);       // BLAS.ger!(-1/indiv, col_sum, one_vector, M)
+  v = fma(-cs_j, inv_n, v);       // BLAS.ger!(-1/indiv, one_vector, col_sum, M)
+  v = v + tot_nn;                 // M .+= sum(col_sum) / indiv^2
+  if (do_scale) v *= inv_c;       // M ./= 2 sum f (1 - f)
+  return v;
+}
+__device__ __forceinline__ double ld_center_map(double v, double f_i, double f_j, double four_indiv) { return fma(-four_indiv * f_i, f_j, v); }   // syr!('U', -4 indiv, f, M)
+__device__ __forceinline__ double ld_scale_map(double v, double is_i, double is_j) { return v * is_i * is_j; }                                    // M ./= sigma; M ./= sigma' (is = 1 / sigma)
+
 // Epilogue shared by both engines.  32x32 C/D map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); element (gi, gj) = M[gi][gj].
 // The output holds columns [c0, ..) of M with leading dimension ld (whole matrix: c0 = 0, ld = n).
 // Direct image: M[gj, gi] at ans[gj + (gi-c0)*ld], lanes run along gj (256-byte segments).  Mirror image M[gi, gj] at
 // ans[gi + (gj-c0)*ld]: the tile is transposed through a per-wave LDS scratch (row stride 33 doubles: conflict-free both ways)
 // so its lanes run along gi as well.  AccT = v16i: exact int32 sums; v16f: sums of z z' / 4 (FP4 engine), exact, times 4.
 typedef float v16f __attribute__((ext_vector_type(16)));
-template <typename AccT>
+// POST: 0 plain crossproduct, 1 GRM map, 2 LD map (XPost above); each stored element is mapped with ITS OWN (row, column), so both images equal what
+// the unfused element-wise kernels produce.  With a map the 32 x 32 block goes to the LDS scratch first (static accumulator indices, unrolled) and both
+// images are written by ROLLED loops over it: the fp64 divisions of the maps, unrolled 512 times, exceed the compiler's full-unroll budget, and a
+// rolled loop over the accumulators themselves would index them dynamically, i.e. move them to scratch memory for the whole kernel (measured: 10x).
+template <typename AccT, int POST>
 __device__ __forceinline__ void xprod_store(const AccT (&acc)[4][4], char *smem, int wave, int lane, int wi, int wj, long i0, long j0, int images, long n,
-                                            double *__restrict__ ans, long ld, long c0) {
+                                            double *__restrict__ ans, long ld, long c0, const XPost &post) {
   double *scratch = reinterpret_cast<double *>(smem) + wave * (32 * 33);   // the DMA ring is dead after the last barrier
   const int col = lane & 31, hh = lane >> 5, rq = 4 * hh;
   constexpr double scale = __is_same(AccT, v16f) ? 4.0 : 1.0;
+  if constexpr (POST == 0) {
 #pragma unroll
-  for (int a = 0; a < 4; a++)
+    for (int a = 0; a < 4; a++)
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-      const long gi_base = i0 + wi * 128 + a * 32, gj_base = j0 + wj * 128 + b * 32;
-      const long gj = gj_base + col;
+      for (int b = 0; b < 4; b++) {
+        const long gi_base = i0 + wi * 128 + a * 32, gj_base = j0 + wj * 128 + b * 32;
+        const long gj = gj_base + col;
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int row = (r & 3) + 8 * (r >> 2) + rq;
-        const double v = (double)acc[a][b][r] * scale;
-        if ((images & 1) && gi_base + row < n && gj < n) ans[(size_t)gj + (size_t)(gi_base + row - c0) * ld] = v;
-        scratch[row * 33 + col] = v;
-      }
-      if (images & 2) {
+        for (int r = 0; r < 16; r++) {
+          const int row = (r & 3) + 8 * (r >> 2) + rq;
+          const double v = (double)acc[a][b][r] * scale;
+          if ((images & 1) && gi_base + row < n && gj < n) ans[(size_t)gj + (size_t)(gi_base + row - c0) * ld] = v;
+          scratch[row * 33 + col] = v;
+        }
+        if (images & 2) {
 #pragma unroll
-        for (int it = 0; it < 16; it++) {
-          const int cc = 2 * it + hh;                       // column of the tile = gj offset; lanes (lane&31) run along gi
-          const double v = scratch[col * 33 + cc];
-          const long gi = gi_base + col, gjj = gj_base + cc;
-          if (gi < n && gjj < n) ans[(size_t)gi + (size_t)(gjj - c0) * ld] = v;
+          for (int it = 0; it < 16; it++) {
+            const int cc = 2 * it + hh;                       // column of the tile = gj offset; lanes (lane&31) run along gi
+            const double v = scratch[col * 33 + cc];
+            const long gi = gi_base + col, gjj = gj_base + cc;
+            if (gi < n && gjj < n) ans[(size_t)gi + (size_t)(gjj - c0) * ld] = v;
+          }
         }
       }
-    }
+  } else {
+    double tot_nn = 0.0, cc_scale = 1.0;
+    if (POST == 1) { tot_nn = post.scal[0] / ((double)n * (double)n); cc_scale = post.do_scale ? 1.0 / post.scal[1] : 1.0; }
+    auto map = [&](double v, long i, long j) -> double {       // element M[i][j] (i, j < n)
+      if (POST == 1) return grm_map(v, post.u[i], post.u[j], post.a, tot_nn, cc_scale, post.do_scale);
+      return ld_scale_map(ld_center_map(v, post.u[i], post.u[j], post.a), post.w[i], post.w[j]);
+    };
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const long gi_base = i0 + wi * 128 + a * 32, gj_base = j0 + wj * 128 + b * 32;
+        const long gj = gj_base + col, gi = gi_base + col;
+#pragma unroll
+        for (int r = 0; r < 16; r++) scratch[((r & 3) + 8 * (r >> 2) + rq) * 33 + col] = (double)acc[a][b][r] * scale;
+        if ((images & 1) && gj < n) {                          // direct image: row index gj, column index gi_base + row
+#pragma unroll 4
+          for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + rq;
+            if (gi_base + row < n) ans[(size_t)gj + (size_t)(gi_base + row - c0) * ld] = map(scratch[row * 33 + col], gj, gi_base + row);
+          }
+        }
+        if ((images & 2) && gi < n) {                          // mirror image: row index gi, column index gj_base + cc
+#pragma unroll 4
+          for (int it = 0; it < 16; it++) {
+            const int cc = 2 * it + hh;
+            if (gj_base + cc < n) ans[(size_t)gi + (size_t)(gj_base + cc - c0) * ld] = map(scratch[col * 33 + cc], gi, gj_base + cc);
+          }
+        }
+      }
+  }
 }
 
 // Both engines: 4 waves, one per SIMD, wave tile 128 x 128 (16 accumulator tiles = 256 registers), one workgroup per CU.  (History: 8 waves with
@@ -161,9 +221,9 @@ struct FragI8 { v4i lo, hi; };
 template <bool I8> struct XFrag { using type = v4i; using acc = v16f; };
 template <> struct XFrag<true> { using type = FragI8; using acc = v16i; };
 
-template <bool DIAG, int EXP, bool I8>
+template <bool DIAG, int EXP, bool I8, int POST>
 __device__ __forceinline__ void xprod_pipeline(const uint8_t *__restrict__ X, long nslabs, int stages, const int4 *__restrict__ tiles, long n, double *__restrict__ ans,
-                                               long ld, long c0, unsigned long long *__restrict__ diag) {
+                                               long ld, long c0, unsigned long long *__restrict__ diag, const XPost &post) {
   using FragT = typename XFrag<I8>::type;
   using AccT = typename XFrag<I8>::acc;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -298,20 +358,20 @@ __device__ __forceinline__ void xprod_pipeline(const uint8_t *__restrict__ X, lo
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0 && diag) { diag[2 * (size_t)blockIdx.x] = t1 - t0; diag[2 * (size_t)blockIdx.x + 1] = r1 - r0; }
   }
-  xprod_store<AccT>(acc, smem, wave, lane, wi, wj, i0, j0, t.z, n, ans, ld, c0);
+  xprod_store<AccT, POST>(acc, smem, wave, lane, wi, wj, i0, j0, t.z, n, ans, ld, c0, post);
 }
 
-template <bool DIAG, int EXP = 0>
+template <bool DIAG, int EXP = 0, int POST = 0>
 __global__ void __launch_bounds__(256, 1)
 k_crossprod_f4(const uint8_t *__restrict__ X, long nslabs, int stages, const int4 *__restrict__ tiles, long n, double *__restrict__ ans,
-               long ld, long c0, unsigned long long *__restrict__ diag) {
-  xprod_pipeline<DIAG, EXP, false>(X, nslabs, stages, tiles, n, ans, ld, c0, diag);
+               long ld, long c0, unsigned long long *__restrict__ diag, XPost post) {
+  xprod_pipeline<DIAG, EXP, false, POST>(X, nslabs, stages, tiles, n, ans, ld, c0, diag, post);
 }
-template <bool DIAG>
+template <bool DIAG, int POST = 0>
 __global__ void __launch_bounds__(256, 1)
 k_crossprod_i8(const uint8_t *__restrict__ X, long nslabs, int stages, const int4 *__restrict__ tiles, long n, double *__restrict__ ans,
-               long ld, long c0, unsigned long long *__restrict__ diag) {
-  xprod_pipeline<DIAG, 0, true>(X, nslabs, stages, tiles, n, ans, ld, c0, diag);
+               long ld, long c0, unsigned long long *__restrict__ diag, XPost post) {
+  xprod_pipeline<DIAG, 0, true, POST>(X, nslabs, stages, tiles, n, ans, ld, c0, diag, post);
 }
 
 int launch_plink_lut(uint8_t *d, size_t nbytes, hipStream_t s) {
@@ -373,43 +433,54 @@ struct XBuf {
 
 // one launch over a tile list with either engine (f4: FP4 MFMA, else int8 MFMA); diag_out: in-kernel clocks of the DIAG instantiation
 static int launch_tiles(bool f4, size_t ntiles, hipStream_t s, const uint8_t *d_X, long nslabs, int stages, const int4 *d_tiles, long rows, double *d_ans, long ld,
-                        long c0, unsigned long long *d_diag) {
+                        long c0, unsigned long long *d_diag, int post_kind = 0, const XPost &post = XPost()) {
   static unsigned long long m2 = 0, m3 = 0;   // per-device function attributes
   if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<false>), kF4Lds, &m2) || ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true>), kF4Lds, &m3)) return 1;
   const dim3 grid((unsigned)ntiles), block(256);
+  if (post_kind == 1 || post_kind == 2) {   // GRM / LD map fused into the epilogue (never with the diagnostic instantiations)
+    static unsigned long long p1 = 0, p2 = 0, p3 = 0, p4 = 0;
+    if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<false, 0, 1>), kF4Lds, &p1) || ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<false, 0, 2>), kF4Lds, &p2) ||
+        ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_i8<false, 1>), kF4Lds, &p3) || ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_i8<false, 2>), kF4Lds, &p4)) return 1;
+    if (f4 && post_kind == 1) hipLaunchKernelGGL((k_crossprod_f4<false, 0, 1>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, nullptr, post);
+    else if (f4) hipLaunchKernelGGL((k_crossprod_f4<false, 0, 2>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, nullptr, post);
+    else if (post_kind == 1) hipLaunchKernelGGL((k_crossprod_i8<false, 1>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, nullptr, post);
+    else hipLaunchKernelGGL((k_crossprod_i8<false, 2>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, nullptr, post);
+    MXA_HIP(hipGetLastError());
+    return 0;
+  }
   if (f4) {
     static const int exp = [] { const char *e = getenv("MXA_XPROD_EXP"); return e ? atoi(e) : 0; }();
     if (d_diag && exp == 1) {
       static unsigned long long mx1 = 0;
       if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true, 1>), kF4Lds, &mx1)) return 1;
-      hipLaunchKernelGGL((k_crossprod_f4<true, 1>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
+      hipLaunchKernelGGL((k_crossprod_f4<true, 1>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag, post);
     } else if (d_diag && exp == 2) {
       static unsigned long long mx2 = 0;
       if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true, 2>), kF4Lds, &mx2)) return 1;
-      hipLaunchKernelGGL((k_crossprod_f4<true, 2>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
+      hipLaunchKernelGGL((k_crossprod_f4<true, 2>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag, post);
     } else if (d_diag && exp == 3) {
       static unsigned long long mx3 = 0;
       if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true, 3>), kF4Lds, &mx3)) return 1;
-      hipLaunchKernelGGL((k_crossprod_f4<true, 3>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
+      hipLaunchKernelGGL((k_crossprod_f4<true, 3>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag, post);
     } else if (d_diag && exp == 4) {
       static unsigned long long mx4 = 0;
       if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true, 4>), kF4Lds, &mx4)) return 1;
-      hipLaunchKernelGGL((k_crossprod_f4<true, 4>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
+      hipLaunchKernelGGL((k_crossprod_f4<true, 4>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag, post);
     } else if (d_diag && exp == 5) {
       static unsigned long long mx5 = 0;
       if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true, 5>), kF4Lds, &mx5)) return 1;
-      hipLaunchKernelGGL((k_crossprod_f4<true, 5>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
+      hipLaunchKernelGGL((k_crossprod_f4<true, 5>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag, post);
     } else if (d_diag && exp == 6) {
       static unsigned long long mx6 = 0;
       if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true, 6>), kF4Lds, &mx6)) return 1;
-      hipLaunchKernelGGL((k_crossprod_f4<true, 6>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
-    } else if (d_diag) hipLaunchKernelGGL(k_crossprod_f4<true>, grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
-    else hipLaunchKernelGGL(k_crossprod_f4<false>, grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
+      hipLaunchKernelGGL((k_crossprod_f4<true, 6>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag, post);
+    } else if (d_diag) hipLaunchKernelGGL(k_crossprod_f4<true>, grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag, post);
+    else hipLaunchKernelGGL(k_crossprod_f4<false>, grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag, post);
   } else {
     static unsigned long long i0 = 0, i1 = 0;
     if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_i8<false>), kF4Lds, &i0) || ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_i8<true>), kF4Lds, &i1)) return 1;
-    if (d_diag) hipLaunchKernelGGL(k_crossprod_i8<true>, grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
-    else hipLaunchKernelGGL(k_crossprod_i8<false>, grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag);
+    if (d_diag) hipLaunchKernelGGL(k_crossprod_i8<true>, grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag, post);
+    else hipLaunchKernelGGL(k_crossprod_i8<false>, grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag, post);
   }
   MXA_HIP(hipGetLastError());
   return 0;
@@ -420,7 +491,7 @@ static int launch_tiles(bool f4, size_t ntiles, hipStream_t s, const uint8_t *d_
 // or the matrix end).  upper_only: only rows [0, c_end) are written -- everything above the panel's diagonal block and the block
 // itself; rows >= c_end are left untouched.  The whole matrix is c_begin = 0, c_end = rows, ld = rows.
 int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double *d_ans, hipStream_t s, long c_begin, long c_end, bool upper_only,
-                     long ld, bool f4) {
+                     long ld, bool f4, int post_kind, const XPost *post) {
   const int nb = (int)((rows + kXT - 1) / kXT);
   const int stages = (int)((k + kXStageK - 1) / kXStageK);
   const long nslabs = (long)(pitch / kXStageBytes);
@@ -449,7 +520,7 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
   const bool diag_on = getenv("MXA_DIAG") != nullptr;
   if (diag_on && d_diag.alloc(16 * tiles.size())) return 1;
   MXA_HIP(hipEventRecord(e0.e, s));
-  if (launch_tiles(f4, tiles.size(), s, d_X, nslabs, stages, (const int4 *)d_tiles.p, rows, d_ans, ld, c_begin, (unsigned long long *)d_diag.p)) return 1;
+  if (launch_tiles(f4, tiles.size(), s, d_X, nslabs, stages, (const int4 *)d_tiles.p, rows, d_ans, ld, c_begin, (unsigned long long *)d_diag.p, post ? post_kind : 0, post ? *post : XPost())) return 1;
   MXA_HIP(hipEventRecord(e1.e, s));
   MXA_HIP(hipStreamSynchronize(s));   // tiles vector / d_tiles lifetime
   if (diag_on) {   // diagnostic instantiation: in-kernel clock and cycles per stage
@@ -471,7 +542,8 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
 // (all j >= i).  Tile (i, j) stores M[J rows, I cols] and M[I rows, J cols], so once every chunk up to tile row i1 has run, columns
 // [0, 256*i1) of M are final: a helper thread copies each finished column slab to the host on its own non-blocking stream while
 // the next chunk computes (at config 3 the 80 GB device-to-host copy is as long as the compute).
-static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch, double *d_ans, double *h_ans, hipStream_t s, bool f4) {
+static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch, double *d_ans, double *h_ans, hipStream_t s, bool f4, int post_kind = 0,
+                             const XPost *post = nullptr) {
   const int nb = (int)((rows + kXT - 1) / kXT);
   const int stages = (int)((k + kXStageK - 1) / kXStageK);
   const long nslabs = (long)(pitch / kXStageBytes);
@@ -526,7 +598,7 @@ static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch
   if (hipEventRecord(e0.e, s) != hipSuccess) rc = 1;
   for (int c = 0; c < nchunks && !rc; c++) {
     const size_t cnt = first[(size_t)c + 1] - first[(size_t)c];
-    if (launch_tiles(f4, cnt, s, d_X, nslabs, stages, (const int4 *)d_tiles.p + first[(size_t)c], rows, d_ans, rows, 0L, nullptr) || hipEventRecord(ev[c].e, s) != hipSuccess) { rc = 1; break; }
+    if (launch_tiles(f4, cnt, s, d_X, nslabs, stages, (const int4 *)d_tiles.p + first[(size_t)c], rows, d_ans, rows, 0L, nullptr, post ? post_kind : 0, post ? *post : XPost()) || hipEventRecord(ev[c].e, s) != hipSuccess) { rc = 1; break; }
     launched.store(c + 1);
   }
   if (rc) abort_copy = true;
@@ -570,29 +642,113 @@ __global__ void __launch_bounds__(256) k_grm_update(double *__restrict__ M, long
   const long i = (long)blockIdx.y * 256 + threadIdx.x;
   if (i >= n) return;
   const double inv_n = 1.0 / (double)n;
-  double v = M[(size_t)j * n + i];
-  v = v - cs[i] * inv_n;
-  v = v - cs[j] * inv_n;
-  v = v + total[0] / ((double)n * (double)n);
-  if (do_scale) v /= c[0];
-  M[(size_t)j * n + i] = v;
+  M[(size_t)j * n + i] = grm_map(M[(size_t)j * n + i], cs[i], cs[j], inv_n, total[0] / ((double)n * (double)n), do_scale ? 1.0 / c[0] : 1.0, do_scale);
 }
 // LD: M <- M - 4 * indiv * f f^T ; sigma = sqrt(diag M) ; M <- M / sigma sigma^T      (crossproduct.jl:139-149)
 __global__ void __launch_bounds__(256) k_ld_center(double *__restrict__ M, long n, const double *__restrict__ f, double four_indiv) {
   const long j = blockIdx.x;
   const long i = (long)blockIdx.y * 256 + threadIdx.x;
   if (i >= n) return;
-  M[(size_t)j * n + i] = fma(-four_indiv * f[i], f[j], M[(size_t)j * n + i]);
+  M[(size_t)j * n + i] = ld_center_map(M[(size_t)j * n + i], f[i], f[j], four_indiv);
 }
 __global__ void __launch_bounds__(256) k_diag_sqrt(const double *__restrict__ M, long n, double *__restrict__ sigma) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) sigma[i] = sqrt(M[(size_t)i * n + i]);
+  if (i < n) sigma[i] = 1.0 / sqrt(M[(size_t)i * n + i]);   // reciprocal: ld_scale_map multiplies
 }
 __global__ void __launch_bounds__(256) k_ld_scale(double *__restrict__ M, long n, const double *__restrict__ sigma) {
   const long j = blockIdx.x;
   const long i = (long)blockIdx.y * 256 + threadIdx.x;
   if (i >= n) return;
-  M[(size_t)j * n + i] = M[(size_t)j * n + i] / sigma[i] / sigma[j];
+  M[(size_t)j * n + i] = ld_scale_map(M[(size_t)j * n + i], sigma[i], sigma[j]);
+}
+
+// ---- what the fused map needs, from the staged 2-bit matrix X (tiled layout, values 0..3) instead of from the 8 n^2-byte result ----------------
+// t[s] = sum over all rows of x[r][s] (int32: <= 3 rows).  One block per slab of 128 genotypes walks all row tiles; thread tid reads dword
+// it * 256 + tid of every 8-KiB tile (lane-linear), i.e. always dword `tid & 7` of a row piece: 16 fixed genotype columns per thread.  SWAR byte
+// counters (4 fields per register), flushed to 16 int32 counters before they can overflow; fixed-order reduction over the 32 threads of a column group.
+__global__ void __launch_bounds__(256) k_x_colsum(const uint8_t *__restrict__ X, long nslabs, long ntiles, int *__restrict__ t) {
+  const long slab = blockIdx.x;
+  const int tid = threadIdx.x;
+  uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  int cnt[16];
+#pragma unroll
+  for (int f = 0; f < 16; f++) cnt[f] = 0;
+  auto flush = [&]() {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      cnt[4 * q + 0] += (int)((a0 >> (8 * q)) & 255u); cnt[4 * q + 1] += (int)((a1 >> (8 * q)) & 255u);
+      cnt[4 * q + 2] += (int)((a2 >> (8 * q)) & 255u); cnt[4 * q + 3] += (int)((a3 >> (8 * q)) & 255u);
+    }
+    a0 = a1 = a2 = a3 = 0;
+  };
+  int pend = 0;
+  for (long rt = 0; rt < ntiles; rt++) {
+    const uint32_t *tile = reinterpret_cast<const uint32_t *>(X + ((size_t)rt * nslabs + (size_t)slab) * kTileBytes);
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const uint32_t w = tile[it * 256 + tid];
+      a0 += w & 0x03030303u; a1 += (w >> 2) & 0x03030303u; a2 += (w >> 4) & 0x03030303u; a3 += (w >> 6) & 0x03030303u;
+    }
+    pend += 8;                                   // every byte counter grew by at most 3 * 8
+    if (pend + 8 > 85) { flush(); pend = 0; }    // 85 * 3 = 255
+  }
+  flush();
+  __shared__ int sh[256][17];
+#pragma unroll
+  for (int f = 0; f < 16; f++) sh[tid][f] = cnt[f];
+  __syncthreads();
+  if (tid < 128) {
+    const int part = tid >> 4, f = tid & 15;     // genotype part * 16 + f of the slab = field f of dword `part` of the row piece
+    int sum = 0;
+    for (int g = 0; g < 32; g++) sum += sh[g * 8 + part][f];
+    t[slab * 128 + tid] = sum;
+  }
+}
+// per row r: cs[r] += sum_s x[r][s] * t[s]  (WANT_CS;  = column sum r of M = X X^T)  and / or  dg[r] += sum_s x[r][s]^2  (WANT_DG; = M[r][r]).
+// Grid (row tiles, K chunks); thread = row of the tile, reading its 32-byte piece of every slab of the chunk (a wave reads 2 KiB contiguous);
+// the t values of a slab are broadcast from LDS.  Exact integers: int32 within a slab (128 * 3 * 3 rows < 2^31 for rows < 1.8 M), 64-bit atomics
+// across the chunks (integer addition: order-independent).
+template <bool WANT_CS, bool WANT_DG>
+__global__ void __launch_bounds__(256) k_x_rowstats(const uint8_t *__restrict__ X, long nslabs, long slabs_per_chunk, const int *__restrict__ t,
+                                                    unsigned long long *__restrict__ cs, unsigned long long *__restrict__ dg) {
+  const long rt = blockIdx.x;
+  const long s0 = (long)blockIdx.y * slabs_per_chunk, s1 = min(nslabs, s0 + slabs_per_chunk);
+  const int tid = threadIdx.x;
+  __shared__ int tsh[128];
+  unsigned long long acc_cs = 0, acc_dg = 0;
+  for (long sl = s0; sl < s1; sl++) {
+    if (WANT_CS) {
+      __syncthreads();
+      if (tid < 128) tsh[tid] = t[sl * 128 + tid];
+      __syncthreads();
+    }
+    const uint4 *pp = reinterpret_cast<const uint4 *>(X + ((size_t)rt * nslabs + (size_t)sl) * kTileBytes + (size_t)tid * kSlabBytes);
+    const uint4 q0 = pp[0], q1 = pp[1];
+    const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    uint32_t part_cs = 0, part_dg = 0;
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+      if (WANT_CS) {
+#pragma unroll
+        for (int f = 0; f < 16; f++) part_cs += ((w[d] >> (2 * f)) & 3u) * (uint32_t)tsh[d * 16 + f];
+      }
+      if (WANT_DG) {   // x^2 = 1, 4, 9 for x = 1, 2, 3: three bit counts
+        const uint32_t L = w[d] & 0x55555555u, H = (w[d] >> 1) & 0x55555555u;
+        part_dg += (uint32_t)__popc(L & ~H) + 4u * (uint32_t)__popc(H & ~L) + 9u * (uint32_t)__popc(H & L);
+      }
+    }
+    acc_cs += part_cs; acc_dg += part_dg;
+  }
+  const long r = rt * kTileRows + tid;
+  if (WANT_CS && acc_cs) atomicAdd(cs + r, acc_cs);
+  if (WANT_DG && acc_dg) atomicAdd(dg + r, acc_dg);
+}
+// u64 -> double (exact below 2^53), or the reciprocal LD sigma: 1 / sqrt(M_ii - 4 indiv f_i^2) exactly as k_ld_center + k_diag_sqrt form it
+__global__ void __launch_bounds__(256) k_x_finish_stats(const unsigned long long *__restrict__ in, long n, const double *__restrict__ f, double four_indiv, double *__restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double v = (double)in[i];
+  out[i] = f ? 1.0 / sqrt(ld_center_map(v, f[i], f[i], four_indiv)) : v;
 }
 
 // post: 0 none, 1 GRM (do_scale as given, f = allele frequencies of length k), 2 LD (f of length rows, k = number of individuals)
@@ -676,19 +832,50 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
     d_ans = (double *)d_out.p;
     if (upper_only) MXA_HIP(hipMemsetAsync(d_ans, 0, abytes, s));   // the untouched part travels back as zeros
   }
-  if (!out_dev && !post && c_begin == 0 && c_end == rows && ld == rows && !getenv("MXA_XPROD_NO_PIPELINE"))
-    return crossprod_to_host((const uint8_t *)d_X.p, k, rows, pitch, d_ans, ans, s, f4);
-  if (crossprod_device((const uint8_t *)d_X.p, k, rows, pitch, d_ans, s, c_begin, c_end, upper_only, ld, f4)) return 1;
-  if (post) {
+  const bool whole = c_begin == 0 && c_end == rows && !upper_only;
+  // GRM / LD: the element-wise map is fused into the crossproduct epilogue (whole matrix; MXA_XPROD_FUSED_POST=0 keeps the three extra passes over
+  // the result).  What the map needs comes from the staged 2-bit matrix: ~2 passes over rows * k / 4 bytes instead of 3 over 8 * rows^2.
+  const char *e_fused = getenv("MXA_XPROD_FUSED_POST");   // read per call (tests compare both paths bit for bit)
+  const bool fused_on = !e_fused || atoi(e_fused) != 0;
+  const double *d_f = freq;
+  if (post && freq && ptr_location(freq, nullptr) != 1) {
     const long flen = post == 1 ? k : rows;
-    const double *d_f = freq;
-    if (freq && ptr_location(freq, nullptr) != 1) {
-      if (f_tmp.alloc(sizeof(double) * flen)) return 1;
-      MXA_HIP(hipMemcpyAsync(f_tmp.p, freq, sizeof(double) * flen, hipMemcpyHostToDevice, s));
-      d_f = (const double *)f_tmp.p;
-    }
-    if (postprocess_device(d_ans, rows, k, post, do_scale, d_f, s)) return 1;
+    if (f_tmp.alloc(sizeof(double) * flen)) return 1;
+    MXA_HIP(hipMemcpyAsync(f_tmp.p, freq, sizeof(double) * flen, hipMemcpyHostToDevice, s));
+    d_f = (const double *)f_tmp.p;
   }
+  XPost xp;
+  int post_kind = 0;
+  XBuf st_t, st_raw, st_out;
+  if (post && fused_on && whole) {
+    const long ntiles = rows_pad / kXT;
+    if (st_t.alloc(sizeof(int) * (size_t)nslabs * 128) || st_raw.alloc(sizeof(unsigned long long) * (size_t)rows_pad) || st_out.alloc(sizeof(double) * (size_t)(rows_pad + 4))) return 1;
+    MXA_HIP(hipMemsetAsync(st_raw.p, 0, sizeof(unsigned long long) * (size_t)rows_pad, s));
+    unsigned long long *raw = (unsigned long long *)st_raw.p;
+    double *out = (double *)st_out.p;
+    const long chunks = std::max<long>(1, std::min<long>(nslabs, (1024 + ntiles - 1) / ntiles));   // >= ~1024 blocks
+    const long spc = (nslabs + chunks - 1) / chunks;
+    const dim3 g_rows((unsigned)ntiles, (unsigned)((nslabs + spc - 1) / spc));
+    const unsigned g_fin = (unsigned)((rows + 255) / 256);
+    if (post == 1) {
+      hipLaunchKernelGGL(k_x_colsum, dim3((unsigned)nslabs), dim3(256), 0, s, (const uint8_t *)d_X.p, nslabs, ntiles, (int *)st_t.p);
+      hipLaunchKernelGGL((k_x_rowstats<true, false>), g_rows, dim3(256), 0, s, (const uint8_t *)d_X.p, nslabs, spc, (const int *)st_t.p, raw, (unsigned long long *)nullptr);
+      hipLaunchKernelGGL(k_x_finish_stats, dim3(g_fin), dim3(256), 0, s, raw, rows, (const double *)nullptr, 0.0, out);
+      hipLaunchKernelGGL(k_vec_reduce, dim3(1), dim3(1024), 0, s, out, rows, 0, out + rows_pad);
+      if (do_scale) hipLaunchKernelGGL(k_vec_reduce, dim3(1), dim3(1024), 0, s, d_f, k, 1, out + rows_pad + 1);
+      xp.u = out; xp.scal = out + rows_pad; xp.a = 1.0 / (double)rows; xp.do_scale = do_scale;
+    } else {
+      hipLaunchKernelGGL((k_x_rowstats<false, true>), g_rows, dim3(256), 0, s, (const uint8_t *)d_X.p, nslabs, spc, (const int *)nullptr, (unsigned long long *)nullptr, raw);
+      hipLaunchKernelGGL(k_x_finish_stats, dim3(g_fin), dim3(256), 0, s, raw, rows, d_f, 4.0 * (double)k, out);
+      xp.u = d_f; xp.w = out; xp.a = 4.0 * (double)k;
+    }
+    MXA_HIP(hipGetLastError());
+    post_kind = post;
+  }
+  if (!out_dev && (!post || post_kind) && whole && ld == rows && !getenv("MXA_XPROD_NO_PIPELINE"))
+    return crossprod_to_host((const uint8_t *)d_X.p, k, rows, pitch, d_ans, ans, s, f4, post_kind, &xp);
+  if (crossprod_device((const uint8_t *)d_X.p, k, rows, pitch, d_ans, s, c_begin, c_end, upper_only, ld, f4, post_kind, &xp)) return 1;
+  if (post && !post_kind && postprocess_device(d_ans, rows, k, post, do_scale, d_f, s)) return 1;
   if (!out_dev) MXA_HIP(hipMemcpyAsync(ans, d_ans, abytes, hipMemcpyDeviceToHost, s));
   MXA_HIP(hipStreamSynchronize(s));
   return 0;

@@ -208,7 +208,9 @@ int launch_transpose_2bit(const uint8_t *d_in, long rows, long cols, uint8_t *d_
 int launch_allele_freq(const uint8_t *d_plink, long snps, long indiv, double *d_f, hipStream_t s);
 // crossproduct
 int launch_plink_lut(uint8_t *d, size_t nbytes, hipStream_t s);
-int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double *d_ans, hipStream_t s, long c_begin, long c_end, bool upper_only, long ld, bool f4);
+struct XPost;   // element-wise map of the crossproduct epilogue (GRM / LD post-processing, mxa_crossprod.hip)
+int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double *d_ans, hipStream_t s, long c_begin, long c_end, bool upper_only, long ld, bool f4,
+                     int post_kind = 0, const XPost *post = nullptr);
 // sparse_times_plink (mxa_sparse.hip): one slab of C columns [e_base, e_base + e_count) (e_base a multiple of 4), C slab pointer = column e_base
 int launch_sparse_times_plink(const uint8_t *dP, size_t pitch, long entries, int nIdx, const int *d_rowIdx, const int *d_colIdx, const double *d_val,
                               double *dC_slab, long ldc, long e_base, long e_count, hipStream_t s);
