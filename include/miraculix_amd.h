@@ -253,7 +253,11 @@ int mxa_snp_multiply_panel(const unsigned char *snp_matrix, int snps, int indiv,
  * src/bindings/Julia/crossproduct.jl:83-110 grm(), :128-152 ld(); maths docs/grm.md:5-12).
  * mxa_grm: G(indiv x indiv) = P Z Z^T P^T [/ (2 sum f(1-f))], plink_transposed = indiv rows of ceil(snps/4) bytes.
  * mxa_ld : R(snps x snps)  = D^-1/2 (Z^T Z - 4 indiv f f^T) D^-1/2,  plink = snps rows of ceil(indiv/4) bytes.
- * Pointers may be host or device.  Return 0 / 1. */
+ * Pointers may be host or device.  Return 0 / 1.
+ * The element-wise map runs INSIDE the crossproduct epilogue (round 3): the column sums and the diagonal of the crossproduct are formed from
+ * the packed matrix before the product (exact integers), so the result is written once and a host result leaves through the same slab
+ * pipeline as snp_multiply_gpu's.  The reference's divisions (by 2 sum f(1-f); by sigma_i, sigma_j) are multiplications by reciprocals
+ * (<= 1 ulp from the quotients).  MXA_XPROD_FUSED_POST=0 runs the three separate passes over the result instead (bit-identical). */
 int mxa_grm(const unsigned char *plink_transposed, int snps, int indiv, double *G, int is_plink_format, int do_scale,
             const double *allele_freq);
 int mxa_ld(const unsigned char *plink, int snps, int indiv, double *R, int is_plink_format, const double *allele_freq);
