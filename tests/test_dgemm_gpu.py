@@ -84,13 +84,14 @@ def test_missing_codes_are_zero_then_centred(mx):
         assert np.abs(C.T - ref).max() / np.abs(ref).max() <= RTOL
 
 
-@pytest.mark.parametrize("idx", range(7))
-def test_dgemm_vs_reference_golden(mx, idx):
-    """the HIP path against the outputs of the reference's own CPU library (tests/golden/dgemm_golden.npz), through the raw
+@pytest.mark.parametrize("fixture,idx", [("dgemm_golden.npz", i) for i in range(7)] + [("dgemm_golden2.npz", i) for i in range(6)])
+def test_dgemm_vs_reference_golden(mx, fixture, idx):
+    """the HIP path against the outputs of the reference's own CPU library (tests/golden/dgemm_golden.npz; dgemm_golden2.npz: the operand
+    patterns of the reference's Fortran tests, n = 40 / 65, SIMD variants 32 and 128 of the reference), through the raw
     C ABI with the fixtures' leading dimensions (padded ldb with poison, padded ldc zero-filled)"""
     import ctypes
     import os
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dgemm_golden.npz"))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture))
     name = str(g["names"][idx])
     snps, indiv, n, ldb_pad, ldc_pad = [int(x) for x in g[f"{name}/dims"]]
     L = mx.check_library_handle()

@@ -65,6 +65,32 @@ def test_dense_and_gpuorder_oracles_vs_reference_golden(golden, oracle, idx):
             assert np.abs(Cg[:, :m] - ref[:, :m]).max() <= 1e-12 * scale
 
 
+GOLDEN2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dgemm_golden2.npz")
+
+
+@pytest.mark.parametrize("idx", range(6))
+def test_oracles_vs_second_reference_golden_set(oracle, idx):
+    """tests/golden/dgemm_golden2.npz (make_golden2.py): the Fortran tests' operand patterns, n = 40 / 65, the reference's SIMD variants 32 and 128.
+    The 5codes port reproduces the AVX2 variant (256) bit for bit; the other variants add in another order and agree to rounding; the dense
+    long-double oracle -- the checker of the -m gpu tests -- agrees with every one of them to 1e-13."""
+    g2 = np.load(GOLDEN2)
+    name = str(g2["names"][idx])
+    prob, n, _, _ = _case(g2, name)
+    h = oracle.five_create(prob, int(g2["cores"][0]) if "cores" in g2 else 8)
+    for trans in (0, 1):
+        B = np.ascontiguousarray(g2[f"{name}/B{trans}"])
+        for centered in (0, 1):
+            ref = g2[f"{name}/C{trans}{centered}"]
+            scale = np.abs(ref).max()
+            C5 = oracle.five_dgemm(h, trans, prob, B, centered)
+            if "variant" not in name:
+                assert np.array_equal(C5, ref), (name, trans, centered, np.abs(C5 - ref).max())
+            else:
+                assert np.abs(C5 - ref).max() <= 1e-13 * scale
+            assert np.abs(oracle.dgemm_dense(trans, prob, B, centered) - ref).max() <= 1e-13 * scale
+    oracle.five_free(h)
+
+
 def test_missing_is_zero_then_centred(golden, oracle):
     """code 01 decodes to 0 and is centred like any other entry (both reference engines)"""
     name = "missing_1203x610_n6"
