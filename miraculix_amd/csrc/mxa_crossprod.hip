@@ -115,9 +115,10 @@ __device__ __forceinline__ double ld_scale_map(double v, double is_i, double is_
 // so its lanes run along gi as well.  AccT = v16i: exact int32 sums; v16f: sums of z z' / 4 (FP4 engine), exact, times 4.
 typedef float v16f __attribute__((ext_vector_type(16)));
 // POST: 0 plain crossproduct, 1 GRM map, 2 LD map (XPost above); each stored element is mapped with ITS OWN (row, column), so both images equal what
-// the unfused element-wise kernels produce.  With a map the 32 x 32 block goes to the LDS scratch first (static accumulator indices, unrolled) and both
-// images are written by ROLLED loops over it: the fp64 divisions of the maps, unrolled 512 times, exceed the compiler's full-unroll budget, and a
-// rolled loop over the accumulators themselves would index them dynamically, i.e. move them to scratch memory for the whole kernel (measured: 10x).
+// the unfused element-wise kernels produce.  With a map the 32 x 32 block goes to the LDS scratch first (static accumulator indices) and both images
+// are written by loops over IT, never over the accumulators: when the maps still held fp64 divisions, their 512-fold unrolled code exceeded the
+// compiler's full-unroll budget, the loops stayed rolled, and a rolled loop over the accumulators indexes them dynamically, i.e. moves them to
+// scratch memory for the whole kernel (measured: 10x).  With the reciprocal maps everything unrolls; this form stays safe if it ever does not.
 template <typename AccT, int POST>
 __device__ __forceinline__ void xprod_store(const AccT (&acc)[4][4], char *smem, int wave, int lane, int wi, int wj, long i0, long j0, int images, long n,
                                             double *__restrict__ ans, long ld, long c0, const XPost &post) {
@@ -164,14 +165,14 @@ __device__ __forceinline__ void xprod_store(const AccT (&acc)[4][4], char *smem,
 #pragma unroll
         for (int r = 0; r < 16; r++) scratch[((r & 3) + 8 * (r >> 2) + rq) * 33 + col] = (double)acc[a][b][r] * scale;
         if ((images & 1) && gj < n) {                          // direct image: row index gj, column index gi_base + row
-#pragma unroll 4
+#pragma unroll
           for (int r = 0; r < 16; r++) {
             const int row = (r & 3) + 8 * (r >> 2) + rq;
             if (gi_base + row < n) ans[(size_t)gj + (size_t)(gi_base + row - c0) * ld] = map(scratch[row * 33 + col], gj, gi_base + row);
           }
         }
         if ((images & 2) && gi < n) {                          // mirror image: row index gi, column index gj_base + cc
-#pragma unroll 4
+#pragma unroll
           for (int it = 0; it < 16; it++) {
             const int cc = 2 * it + hh;
             if (gj_base + cc < n) ans[(size_t)gi + (size_t)(gj_base + cc - c0) * ld] = map(scratch[col * 33 + cc], gi, gj_base + cc);
