@@ -325,7 +325,7 @@ def config5_cg_step_leg(torch, mx, L, dev, snps=250_000, indiv=100_000, reps=20)
         tbs = bytes_step / t_step * 1e-12
         return {"workload": f"{snps} SNPs x {indiv} indiv (per-GPU shard of config 5), n=1, centred, one mxa_gram_matvec = 'T' + 'N'",
                 "ms_per_cg_step": round(t_step * 1e3, 4), "ms_per_cg_step_back_to_back_no_host_wait": round(t_async * 1e3, 4), "kernel_path": path, "dominant_kernel_ms": {"T": round(ms_t / max(1, la_t), 4), "N": round(ms_n / max(1, la_n), 4)},
-                "algorithmic_TB_per_s": round(tbs, 3), "frac_of_8_TBs_spec": round(tbs / 8.0, 4), "frac_of_6.3_TBs_achievable": round(tbs / 6.3, 4),
+                "algorithmic_TB_per_s": round(tbs, 3), "frac_of_8_TBs_spec": round(tbs / 8.0, 4), "frac_of_7.0_TBs_read_ceiling": round(tbs / 7.0, 4),   # 7.0: what one MI355X reads with non-temporal loads (tools/hbm_read_probe.hip; 6.3-6.5 with the default policy)
                 "check": {"T_32_sampled_rows_vs_dense_oracle_max_rel_err": err_t, "N_32_sampled_rows_vs_dense_oracle_max_rel_err": err_n,
                           "gram_matvec_bitwise_equals_T_then_N": same, "checker_tolerance": 1e-11}}
     finally:

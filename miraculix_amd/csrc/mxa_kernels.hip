@@ -287,6 +287,20 @@ using lptr_t = __attribute__((address_space(3))) void *;
 __device__ __forceinline__ void dma16_s(const void *sbase, uint32_t voff, uint32_t lds_addr) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
 }
+// non-temporal variant for the packed genotype stream (read once per pass, far larger than every cache): see mxa_gemm_i8.hip, idma16_stream.
+// Measured on the config-5 shard (tools/gpu_r3_nt_ab.sh): k_gemm_i8 at n = 1 0.96-0.97 ms with the hint against 1.01-1.02 without; the lookup kernel
+// k_lut 1.66 against 1.63 (LDS-bound: no gain, MXA_NT_LUT stays 0) and k_gemm 43.95-43.99 against 43.87-43.97 (MFMA-bound: nothing, MXA_NT_GEMM stays 0).
+#ifndef MXA_NT_LUT
+#define MXA_NT_LUT 0
+#endif
+#ifndef MXA_NT_GEMM
+#define MXA_NT_GEMM 0
+#endif
+template <bool NT>
+__device__ __forceinline__ void dma16_p(const void *sbase, uint32_t voff, uint32_t lds_addr) {
+  if (NT) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0 nt" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
+  else dma16_s(sbase, voff, lds_addr);
+}
 
 template <int A, int C>
 struct GemmCfg {
@@ -384,7 +398,7 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
 #pragma unroll
     for (int i = 0; i < (Cfg::kAUnits + kWaves - 1) / kWaves; i++) {
       const int q = wave + i * kWaves;
-      if (Cfg::kAUnits % kWaves == 0 || q < Cfg::kAUnits) dma16_s(aslab + q * 1024, a_lane, base + Cfg::kBBytes + q * 1024);
+      if (Cfg::kAUnits % kWaves == 0 || q < Cfg::kAUnits) dma16_p<MXA_NT_GEMM != 0>(aslab + q * 1024, a_lane, base + Cfg::kBBytes + q * 1024);
     }
   };
 
@@ -778,7 +792,7 @@ k_lut(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B,
   auto issue_rows = [&](int slab, int buf) {
     const char *src = G_u + (size_t)slab * kTileBytes;
 #pragma unroll
-    for (int c = 0; c < Cfg::kChunks; c++) dma16_s(src + c * 16, r_lane, lds0 + buf * Cfg::kBufBytes + (c * Cfg::kRows + wave * 64) * 16);
+    for (int c = 0; c < Cfg::kChunks; c++) dma16_p<MXA_NT_LUT != 0>(src + c * 16, r_lane, lds0 + buf * Cfg::kBufBytes + (c * Cfg::kRows + wave * 64) * 16);
   };
   // Table build: the slab has KS/2 pair tables x 16 entries; thread t writes entries q = t + T*e (pair q>>4, nibble q&15), so a
   // wave writes 64 consecutive entries (conflict-free ds_write).  The pair's two B values are loaded one slab ahead into
