@@ -58,8 +58,10 @@ __global__ void __launch_bounds__(256) k_xstage(const uint8_t *__restrict__ src,
     const long r = idx / dpr, d = idx - r * dpr, b = d * 4;
     const uint8_t *p = src + (size_t)r * src_pitch + b;
     uint32_t w = 0, keep = 0;
-    for (int u = 0; u < 4; u++)
-      if (b + u < row_bytes) { w |= (uint32_t)p[u] << (8 * u); keep |= 0xFFu << (8 * u); }
+    if (b + 4 <= row_bytes && (reinterpret_cast<size_t>(p) & 3) == 0) { w = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p)); keep = 0xFFFFFFFFu; }   // one aligned dword (read once)
+    else
+      for (int u = 0; u < 4; u++)
+        if (b + u < row_bytes) { w |= (uint32_t)p[u] << (8 * u); keep |= 0xFFu << (8 * u); }
     if (apply_lut) w = plink_lut4(w) & keep;
     if (w & (w >> 1) & 0x55555555u) atomicOr(has3, 1);
     const long R = dst_row0 + r;
@@ -114,6 +116,18 @@ __device__ __forceinline__ double ld_scale_map(double v, double is_i, double is_
 // ans[gi + (gj-c0)*ld]: the tile is transposed through a per-wave LDS scratch (row stride 33 doubles: conflict-free both ways)
 // so its lanes run along gi as well.  AccT = v16i: exact int32 sums; v16f: sums of z z' / 4 (FP4 engine), exact, times 4.
 typedef float v16f __attribute__((ext_vector_type(16)));
+// the result is written once and never read by this kernel: non-temporal stores keep the 8 n^2 bytes from displacing the packed operand tiles, which ~n/256
+// tiles re-read, in the L2s and the Infinity Cache (MXA_XPROD_NT_STORE=0 at compile time: plain stores, for the A/B of tools/gpu_r3_xstore_ab.sh)
+#ifndef MXA_XPROD_NT_STORE
+#define MXA_XPROD_NT_STORE 1
+#endif
+__device__ __forceinline__ void xstore(double *p, double v) {
+#if MXA_XPROD_NT_STORE
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 // POST: 0 plain crossproduct, 1 GRM map, 2 LD map (XPost above); each stored element is mapped with ITS OWN (row, column), so both images equal what
 // the unfused element-wise kernels produce.  With a map the 32 x 32 block goes to the LDS scratch first (static accumulator indices) and both images
 // are written by loops over IT, never over the accumulators: when the maps still held fp64 divisions, their 512-fold unrolled code exceeded the
@@ -136,7 +150,7 @@ __device__ __forceinline__ void xprod_store(const AccT (&acc)[4][4], char *smem,
         for (int r = 0; r < 16; r++) {
           const int row = (r & 3) + 8 * (r >> 2) + rq;
           const double v = (double)acc[a][b][r] * scale;
-          if ((images & 1) && gi_base + row < n && gj < n) ans[(size_t)gj + (size_t)(gi_base + row - c0) * ld] = v;
+          if ((images & 1) && gi_base + row < n && gj < n) xstore(&ans[(size_t)gj + (size_t)(gi_base + row - c0) * ld], v);
           scratch[row * 33 + col] = v;
         }
         if (images & 2) {
@@ -145,7 +159,7 @@ __device__ __forceinline__ void xprod_store(const AccT (&acc)[4][4], char *smem,
             const int cc = 2 * it + hh;                       // column of the tile = gj offset; lanes (lane&31) run along gi
             const double v = scratch[col * 33 + cc];
             const long gi = gi_base + col, gjj = gj_base + cc;
-            if (gi < n && gjj < n) ans[(size_t)gi + (size_t)(gjj - c0) * ld] = v;
+            if (gi < n && gjj < n) xstore(&ans[(size_t)gi + (size_t)(gjj - c0) * ld], v);
           }
         }
       }
@@ -168,14 +182,14 @@ __device__ __forceinline__ void xprod_store(const AccT (&acc)[4][4], char *smem,
 #pragma unroll
           for (int r = 0; r < 16; r++) {
             const int row = (r & 3) + 8 * (r >> 2) + rq;
-            if (gi_base + row < n) ans[(size_t)gj + (size_t)(gi_base + row - c0) * ld] = map(scratch[row * 33 + col], gj, gi_base + row);
+            if (gi_base + row < n) xstore(&ans[(size_t)gj + (size_t)(gi_base + row - c0) * ld], map(scratch[row * 33 + col], gj, gi_base + row));
           }
         }
         if ((images & 2) && gi < n) {                          // mirror image: row index gi, column index gj_base + cc
 #pragma unroll
           for (int it = 0; it < 16; it++) {
             const int cc = 2 * it + hh;
-            if (gj_base + cc < n) ans[(size_t)gi + (size_t)(gj_base + cc - c0) * ld] = map(scratch[col * 33 + cc], gi, gj_base + cc);
+            if (gj_base + cc < n) xstore(&ans[(size_t)gi + (size_t)(gj_base + cc - c0) * ld], map(scratch[col * 33 + cc], gi, gj_base + cc));
           }
         }
       }
