@@ -289,12 +289,15 @@ __device__ __forceinline__ void dma16_s(const void *sbase, uint32_t voff, uint32
 }
 // non-temporal variant for the packed genotype stream (read once per pass, far larger than every cache): see mxa_gemm_i8.hip, idma16_stream.
 // Measured on the config-5 shard (tools/gpu_r3_nt_ab.sh): k_gemm_i8 at n = 1 0.96-0.97 ms with the hint against 1.01-1.02 without; the lookup kernel
-// k_lut 1.66 against 1.63 (LDS-bound: no gain, MXA_NT_LUT stays 0) and k_gemm 43.95-43.99 against 43.87-43.97 (MFMA-bound: nothing, MXA_NT_GEMM stays 0).
+// k_lut 1.66 against 1.63 (LDS-bound: no gain, MXA_NT_LUT stays 0).  k_gemm is MFMA-bound and its time does not move (C2: 43.89-43.99 ms with, 43.87-44.02
+// without), but its HBM traffic does: the packed stream no longer pushes the B-fragment slabs, which every row block re-reads, out of the L2s --
+// 15.0 GB per launch by the counters instead of 18.9 (12.8 algorithmic; FETCH_SIZE calibrated for the hinted stream too: factor 2.000,
+// profiles/r03_pmc_calibration_nt.json).  MXA_NT_GEMM = 1.
 #ifndef MXA_NT_LUT
 #define MXA_NT_LUT 0
 #endif
 #ifndef MXA_NT_GEMM
-#define MXA_NT_GEMM 0
+#define MXA_NT_GEMM 1
 #endif
 template <bool NT>
 __device__ __forceinline__ void dma16_p(const void *sbase, uint32_t voff, uint32_t lds_addr) {

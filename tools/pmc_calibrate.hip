@@ -15,6 +15,10 @@ __device__ __forceinline__ void dma16_s(const void *sbase, uint32_t voff, uint32
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
 }
 
+__device__ __forceinline__ void dma16_nt(const void *sbase, uint32_t voff, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0 nt" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
+}
+
 // each workgroup (256 threads) streams a contiguous 64 KiB piece per iteration: 16 units of 1 KiB per wave
 template <int STRIDE32>
 __global__ void __launch_bounds__(256) k_stream_dma(const char *__restrict__ src, size_t pieces) {
@@ -26,7 +30,8 @@ __global__ void __launch_bounds__(256) k_stream_dma(const char *__restrict__ src
     const char *base = src + p * 65536 + (size_t)wave * 16384;
 #pragma unroll
     for (int u = 0; u < 16; u++) {
-      if (STRIDE32) dma16_s(base + (u >> 1) * 2048 + (u & 1) * 16, lane * 32, lds0 + wave * 16384 + u * 1024);
+      if (STRIDE32 == 1) dma16_s(base + (u >> 1) * 2048 + (u & 1) * 16, lane * 32, lds0 + wave * 16384 + u * 1024);
+      else if (STRIDE32 == 2) dma16_nt(base + u * 1024, lane * 16, lds0 + wave * 16384 + u * 1024);   // round 3: the non-temporal hint (k_gemm_i8's packed stream)
       else dma16_s(base + u * 1024, lane * 16, lds0 + wave * 16384 + u * 1024);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -56,6 +61,7 @@ int main(int argc, char **argv) {
     hipLaunchKernelGGL(k_stream_dma<0>, dim3(2048), dim3(256), 0, 0, d, pieces);
     hipLaunchKernelGGL(k_stream_dma<1>, dim3(2048), dim3(256), 0, 0, d, pieces);
     hipLaunchKernelGGL(k_stream_vec, dim3(4096), dim3(256), 0, 0, (const uint4 *)d, bytes / 16, sink);
+    hipLaunchKernelGGL(k_stream_dma<2>, dim3(2048), dim3(256), 0, 0, d, pieces);
   }
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
