@@ -13,6 +13,7 @@
 //   k_crossprod_i8  (longer K)  v_mfma_i32_32x32x32_i8, 7 VALU per 16 values, exact int32 for K < 2.3e8; the same K-step pipeline.
 #include "../../include/miraculix_amd.h"
 #include "mxa_internal.h"
+#include "mxa_queue.h"
 #include <atomic>
 #include <thread>
 #include <algorithm>
@@ -237,16 +238,14 @@ template <bool I8> struct XFrag { using type = v4i; using acc = v16f; };
 template <> struct XFrag<true> { using type = FragI8; using acc = v16i; };
 
 template <bool DIAG, int EXP, bool I8, int POST>
-__device__ __forceinline__ void xprod_pipeline(const uint8_t *__restrict__ X, long nslabs, int stages, const int4 *__restrict__ tiles, long n, double *__restrict__ ans,
-                                               long ld, long c0, unsigned long long *__restrict__ diag, const XPost &post) {
+__device__ __forceinline__ void xprod_tile(const uint8_t *__restrict__ X, long nslabs, int stages, const int4 t, size_t tile_index, long n, double *__restrict__ ans,
+                                           long ld, long c0, unsigned long long *__restrict__ diag, const XPost &post) {
   using FragT = typename XFrag<I8>::type;
   using AccT = typename XFrag<I8>::acc;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wi = wave >> 1, wj = wave & 1;
-  const int4 t = tiles[blockIdx.x];
-  if (t.z == 0) return;                         // padding entry of the XCD-aware tile order (whole workgroup, before any barrier)
   const long i0 = (long)t.x * kXT, j0 = (long)t.y * kXT;
   const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
   const uint32_t v_lane = (uint32_t)lane * 16;
@@ -371,7 +370,7 @@ __device__ __forceinline__ void xprod_pipeline(const uint8_t *__restrict__ X, lo
   __syncthreads();   // all waves are done with the ring before it is reused as the epilogue scratch
   if (DIAG) {
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0 && diag) { diag[2 * (size_t)blockIdx.x] = t1 - t0; diag[2 * (size_t)blockIdx.x + 1] = r1 - r0; }
+    if (threadIdx.x == 0 && diag) { diag[2 * tile_index] = t1 - t0; diag[2 * tile_index + 1] = r1 - r0; }
   }
   xprod_store<AccT, POST>(acc, smem, wave, lane, wi, wj, i0, j0, t.z, n, ans, ld, c0, post);
 }
@@ -380,13 +379,78 @@ template <bool DIAG, int EXP = 0, int POST = 0>
 __global__ void __launch_bounds__(256, 1)
 k_crossprod_f4(const uint8_t *__restrict__ X, long nslabs, int stages, const int4 *__restrict__ tiles, long n, double *__restrict__ ans,
                long ld, long c0, unsigned long long *__restrict__ diag, XPost post) {
-  xprod_pipeline<DIAG, EXP, false, POST>(X, nslabs, stages, tiles, n, ans, ld, c0, diag, post);
+  const int4 t = tiles[blockIdx.x];
+  if (t.z == 0) return;                         // padding entry of the XCD-aware tile order (whole workgroup, before any barrier)
+  xprod_tile<DIAG, EXP, false, POST>(X, nslabs, stages, t, blockIdx.x, n, ans, ld, c0, diag, post);
 }
 template <bool DIAG, int POST = 0>
 __global__ void __launch_bounds__(256, 1)
 k_crossprod_i8(const uint8_t *__restrict__ X, long nslabs, int stages, const int4 *__restrict__ tiles, long n, double *__restrict__ ans,
                long ld, long c0, unsigned long long *__restrict__ diag, XPost post) {
-  xprod_pipeline<DIAG, 0, true, POST>(X, nslabs, stages, tiles, n, ans, ld, c0, diag, post);
+  const int4 t = tiles[blockIdx.x];
+  if (t.z == 0) return;
+  xprod_tile<DIAG, 0, true, POST>(X, nslabs, stages, t, blockIdx.x, n, ans, ld, c0, diag, post);
+}
+
+// ---- gang-synchronised persistent form (round 3) ------------------------------------------------------------------------------------------
+// Every 256-row block of X is an operand of ~n/256 tiles, and the kernel above lets the tiles of an XCD drift apart along K (a finished workgroup is
+// replaced at once, at its own time), so concurrent tiles rarely find each other's rows in the XCD's L2: the counters show 3.0 TB fetched per config-3
+// launch (12.5 GB of operand, 243x), 3.7 TB/s next to a power-bound MFMA stream -- with every tile reading the SAME two blocks (results wrong) the
+// clock rises from 2.01 to 2.19 GHz and the launch takes 7 % less.  Here ONE workgroup per CU stays resident and the P workgroups of an XCD advance
+// through that XCD's tile list in GANGS: a workgroup that has finished claims the next slot (one returning atomic add) and waits until all P slots of
+// the gang are claimed, i.e. until the whole XCD is ready, so that the gang's tiles -- 4 x 8 tiles of a super-tile: 12 row blocks for 32 tiles --
+// start together and stream their operands in step (launches cut into waves of 256 tiles, the same synchronisation by other means, fetch 1.13 TB
+// instead of 3.0).  Every wait is bounded by the clock (s_memrealtime): a workgroup that is not joined in time goes on alone, so the grid always
+// drains whatever the hardware did with the workgroups (fewer CUs, another process on the chip); only the sharing is lost then.
+// gang[0..7]: claim counters of the XCD lists, gang[8..15]: workgroups seen per XCD, gang[16]: workgroups seen in total (zeroed by the launcher).
+constexpr int kGangCtrs = 17;
+constexpr unsigned long long kGangJoinTicks = 10000;      // 100 us at the 100 MHz of s_memrealtime: ~4 % of a config-3 tile
+constexpr unsigned long long kGangStartTicks = 200000;    // 2 ms for the whole grid to become resident
+template <bool I8, int POST>
+__global__ void __launch_bounds__(256, 1)
+k_crossprod_gang(const uint8_t *__restrict__ X, long nslabs, int stages, const int4 *__restrict__ tiles, int slots_per_xcd, long n, double *__restrict__ ans,
+                 long ld, long c0, XPost post, int *__restrict__ gang, unsigned join_ticks, int xcc_mask) {
+  __shared__ int sh_val;
+  const int xcc = hw_xcc_id() & xcc_mask;             // mask 7; the tests narrow it to emulate a chip that populates fewer XCDs (the other lists are then stolen)
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(gang + 8 + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(gang + 16, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(gang + 16, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x && __builtin_amdgcn_s_memrealtime() - t0 < kGangStartTicks)
+      __builtin_amdgcn_s_sleep(16);
+    sh_val = __hip_atomic_load(gang + 8 + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const int P = max(1, sh_val);                       // workgroups of this XCD = gang size
+  __syncthreads();
+  __shared__ int sh_list;
+  int phase = 0;                                      // lane 0 only: 0 = the own XCD's list (in gangs), 1..7 = the other XCDs' lists once the own one is empty
+  for (;;) {                                          // (no waiting there: correctness must not depend on which XCDs the hardware populated, e.g. a partitioned chip)
+    if (threadIdx.x == 0) {
+      int slot = -1, y = xcc;
+      while (phase < 8) {
+        y = (xcc + phase) & 7;
+        slot = __hip_atomic_fetch_add(gang + y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (slot < slots_per_xcd) break;
+        slot = -1; phase++;
+      }
+      if (slot >= 0 && phase == 0) {
+        const int target = min((slot / P + 1) * P, slots_per_xcd);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(gang + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && __builtin_amdgcn_s_memrealtime() - t0 < join_ticks)
+          __builtin_amdgcn_s_sleep(4);
+      }
+      sh_val = slot; sh_list = y;
+    }
+    __syncthreads();
+    const int slot = __builtin_amdgcn_readfirstlane(sh_val), list = __builtin_amdgcn_readfirstlane(sh_list);
+    if (slot < 0) break;                               // wave-uniform: every list is empty, the whole workgroup leaves
+    const int4 tv = tiles[(size_t)8 * slot + list];
+    const int4 t = make_int4(__builtin_amdgcn_readfirstlane(tv.x), __builtin_amdgcn_readfirstlane(tv.y), __builtin_amdgcn_readfirstlane(tv.z), 0);   // scalar: the DMA bases live in SGPRs
+    if (t.z) xprod_tile<false, 0, I8, POST>(X, nslabs, stages, t, 0, n, ans, ld, c0, nullptr, post);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores of the epilogue: the DMA bookkeeping of the next tile starts from an empty counter
+    __syncthreads();                                   // ... and the LDS scratch of the epilogue is free (sh_val / sh_list are rewritten only after this barrier)
+  }
 }
 
 int launch_plink_lut(uint8_t *d, size_t nbytes, hipStream_t s) {
@@ -402,9 +466,10 @@ int launch_plink_lut(uint8_t *d, size_t nbytes, hipStream_t s) {
 // super-tiles of sr x 8 tiles (sr tile rows, 8 tile columns), whole super-tiles go to the XCD with the shortest list so far, and the
 // lists are interleaved (list index = 8 * slot + xcd, padded with no-op entries {0,0,0,0}) so that an XCD streams sr + 8 row blocks
 // for 8 * sr tiles.  MXA_XPROD_XCD=0 keeps the plain order (A/B measurement).
-static void xcd_order_tiles(std::vector<int4> &tiles, int nb, int sr) {
+// Returns true when the list has the interleaved per-XCD form (false: left in plain order).
+static bool xcd_order_tiles(std::vector<int4> &tiles, int nb, int sr) {
   static const bool on = [] { const char *e = getenv("MXA_XPROD_XCD"); return e ? atoi(e) != 0 : true; }();
-  if (!on || tiles.size() < 8 * 64 || sr < 1) return;
+  if (!on || tiles.size() < 8 * 64 || sr < 1) return false;
   int i_min = tiles[0].x;
   for (const int4 &t : tiles) i_min = std::min(i_min, t.x);
   const int ncb = (nb + 7) / 8;
@@ -424,6 +489,7 @@ static void xcd_order_tiles(std::vector<int4> &tiles, int nb, int sr) {
   for (size_t slot = 0; slot < longest; slot++)
     for (int x = 0; x < 8; x++) inter.push_back(slot < per_xcd[x].size() ? per_xcd[x][slot] : make_int4(0, 0, 0, 0));
   tiles.swap(inter);
+  return true;
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
@@ -448,10 +514,33 @@ struct XBuf {
 
 // one launch over a tile list with either engine (f4: FP4 MFMA, else int8 MFMA); diag_out: in-kernel clocks of the DIAG instantiation
 static int launch_tiles(bool f4, size_t ntiles, hipStream_t s, const uint8_t *d_X, long nslabs, int stages, const int4 *d_tiles, long rows, double *d_ans, long ld,
-                        long c0, unsigned long long *d_diag, int post_kind = 0, const XPost &post = XPost()) {
+                        long c0, unsigned long long *d_diag, int post_kind = 0, const XPost &post = XPost(), int *d_gang = nullptr) {
   static unsigned long long m2 = 0, m3 = 0;   // per-device function attributes
   if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<false>), kF4Lds, &m2) || ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true>), kF4Lds, &m3)) return 1;
   const dim3 grid((unsigned)ntiles), block(256);
+  // gang-synchronised persistent form: needs the interleaved per-XCD lists (d_gang != nullptr) and is not instrumented (MXA_DIAG keeps the classic kernels)
+  static const bool gang_on = [] { const char *e = getenv("MXA_XPROD_GANG"); return !e || atoi(e) != 0; }();
+  if (gang_on && d_gang && !d_diag && ntiles % 8 == 0) {
+    int dev = 0, cus = 0;
+    MXA_HIP(hipGetDevice(&dev));
+    MXA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int slots = (int)(ntiles / 8);
+    const dim3 pgrid((unsigned)std::max(8, std::min<int>(cus, (int)ntiles)));
+    MXA_HIP(hipMemsetAsync(d_gang, 0, sizeof(int) * kGangCtrs, s));
+    static unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0;
+    static const int xcc_mask = [] { const char *e = getenv("MXA_XPROD_GANG_XCC_MASK"); return e ? atoi(e) & 7 : 7; }();
+    static const unsigned join_ticks = [] { const char *e = getenv("MXA_XPROD_GANG_US"); return e ? (unsigned)std::max(0, atoi(e)) * 100u : (unsigned)kGangJoinTicks; }();
+#define MXA_GANG_LAUNCH(I8, POST, MASK)                                                                                                          \
+    {                                                                                                                                            \
+      if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_gang<I8, POST>), kF4Lds, &MASK)) return 1;                                   \
+      hipLaunchKernelGGL((k_crossprod_gang<I8, POST>), pgrid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, slots, rows, d_ans, ld, c0, post, d_gang, join_ticks, xcc_mask); \
+    }
+    if (f4) { if (post_kind == 1) MXA_GANG_LAUNCH(false, 1, g1) else if (post_kind == 2) MXA_GANG_LAUNCH(false, 2, g2) else MXA_GANG_LAUNCH(false, 0, g0) }
+    else { if (post_kind == 1) MXA_GANG_LAUNCH(true, 1, g4) else if (post_kind == 2) MXA_GANG_LAUNCH(true, 2, g5) else MXA_GANG_LAUNCH(true, 0, g3) }
+#undef MXA_GANG_LAUNCH
+    MXA_HIP(hipGetLastError());
+    return 0;
+  }
   if (post_kind == 1 || post_kind == 2) {   // GRM / LD map fused into the epilogue (never with the diagnostic instantiations)
     static unsigned long long p1 = 0, p2 = 0, p3 = 0, p4 = 0;
     if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<false, 0, 1>), kF4Lds, &p1) || ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<false, 0, 2>), kF4Lds, &p2) ||
@@ -526,8 +615,9 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
       if (flags) tiles.push_back(make_int4(i, j, flags, 0));
     }
   if (tiles.empty()) return 0;
-  xcd_order_tiles(tiles, nb, 8);
-  XBuf d_tiles, d_diag;
+  const bool xcd_lists = xcd_order_tiles(tiles, nb, 8);
+  XBuf d_tiles, d_diag, d_gang;
+  if (d_gang.alloc(sizeof(int) * kGangCtrs)) return 1;
   if (d_tiles.alloc(tiles.size() * sizeof(int4))) return 1;
   MXA_HIP(hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, s));
   XEvent e0, e1;
@@ -535,7 +625,8 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
   const bool diag_on = getenv("MXA_DIAG") != nullptr;
   if (diag_on && d_diag.alloc(16 * tiles.size())) return 1;
   MXA_HIP(hipEventRecord(e0.e, s));
-  if (launch_tiles(f4, tiles.size(), s, d_X, nslabs, stages, (const int4 *)d_tiles.p, rows, d_ans, ld, c_begin, (unsigned long long *)d_diag.p, post ? post_kind : 0, post ? *post : XPost())) return 1;
+  if (launch_tiles(f4, tiles.size(), s, d_X, nslabs, stages, (const int4 *)d_tiles.p, rows, d_ans, ld, c_begin, (unsigned long long *)d_diag.p, post ? post_kind : 0, post ? *post : XPost(),
+                   xcd_lists ? (int *)d_gang.p : nullptr)) return 1;
   MXA_HIP(hipEventRecord(e1.e, s));
   MXA_HIP(hipStreamSynchronize(s));   // tiles vector / d_tiles lifetime
   if (diag_on) {   // diagnostic instantiation: in-kernel clock and cycles per stage
@@ -570,17 +661,18 @@ static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch
   // one tile list per chunk of tile rows, each in XCD-aware order (super-tiles = the chunk's rows x 8 tile columns)
   std::vector<int4> tiles;
   std::vector<size_t> first((size_t)nchunks + 1, 0);
+  std::vector<char> chunk_xcd((size_t)nchunks, 0);      // the chunk's list has the interleaved per-XCD form (gang-synchronised kernel)
   for (int c = 0; c < nchunks; c++) {
     first[(size_t)c] = tiles.size();
     std::vector<int4> part;
     for (int i = c * rows_per_chunk; i < std::min(nb, (c + 1) * rows_per_chunk); i++)
       for (int j = i; j < nb; j++) part.push_back(make_int4(i, j, i == j ? 1 : 3, 0));
-    xcd_order_tiles(part, nb, std::min(rows_per_chunk, 8));
+    chunk_xcd[(size_t)c] = xcd_order_tiles(part, nb, std::min(rows_per_chunk, 8));
     tiles.insert(tiles.end(), part.begin(), part.end());
   }
   first[(size_t)nchunks] = tiles.size();
-  XBuf d_tiles;
-  if (d_tiles.alloc(tiles.size() * sizeof(int4))) return 1;
+  XBuf d_tiles, d_gang;
+  if (d_tiles.alloc(tiles.size() * sizeof(int4)) || d_gang.alloc(sizeof(int) * kGangCtrs)) return 1;
   MXA_HIP(hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, s));
   std::vector<XEvent> ev((size_t)nchunks);
   int dev = 0;
@@ -613,7 +705,7 @@ static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch
   if (hipEventRecord(e0.e, s) != hipSuccess) rc = 1;
   for (int c = 0; c < nchunks && !rc; c++) {
     const size_t cnt = first[(size_t)c + 1] - first[(size_t)c];
-    if (launch_tiles(f4, cnt, s, d_X, nslabs, stages, (const int4 *)d_tiles.p + first[(size_t)c], rows, d_ans, rows, 0L, nullptr, post ? post_kind : 0, post ? *post : XPost()) || hipEventRecord(ev[c].e, s) != hipSuccess) { rc = 1; break; }
+    if (launch_tiles(f4, cnt, s, d_X, nslabs, stages, (const int4 *)d_tiles.p + first[(size_t)c], rows, d_ans, rows, 0L, nullptr, post ? post_kind : 0, post ? *post : XPost(), chunk_xcd[(size_t)c] ? (int *)d_gang.p : nullptr) || hipEventRecord(ev[c].e, s) != hipSuccess) { rc = 1; break; }
     launched.store(c + 1);
   }
   if (rc) abort_copy = true;

@@ -106,3 +106,34 @@ def test_fp4_threshold_boundaries_bit_exact(plink, k_below, k_above):
                 both = min(ones[a], ones[b]); either = max(ones[a], ones[b])
                 want = top * top * (k - either) + top * lo * (either - both) + lo * lo * both
                 assert got[a, b] == float(want), (k, a, b)
+
+
+@pytest.mark.parametrize("env", [{"MXA_XPROD_GANG": "0"}, {"MXA_XPROD_GANG_XCC_MASK": "0"}, {"MXA_XPROD_GANG_XCC_MASK": "1"}, {"MXA_XPROD_GANG_US": "0"}])
+def test_gang_synchronised_kernel_does_not_depend_on_the_xcd_population(env):
+    """k_crossprod_gang (one resident workgroup per CU, the workgroups of an XCD advance through that XCD's tile list in step): the result must not
+    depend on which XCDs the hardware populated -- with the XCD id masked to one or two values the other lists are stolen --, on the join timeout,
+    or on the kernel form at all (MXA_XPROD_GANG=0: one workgroup per tile).  The knobs are read once per process: a child process per setting;
+    2304 rows = 45 upper tiles... too few for the per-XCD lists, so 6000 rows (300 tiles, lists of 64 slots) and both engines."""
+    import os
+    import subprocess
+    import sys
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import miraculix_amd as mx
+from _util import pack_plink
+mx.load_shared_library()
+rng = np.random.default_rng(3)
+rows, k = 6000, 900
+Z = rng.integers(0, 3, size=(rows, k)).astype(np.int8)
+X = np.ascontiguousarray(pack_plink(Z))
+ref = (Z.astype(np.int64) @ Z.astype(np.int64).T).astype(np.float64)
+import os
+for eng in ("f4", "i8"):
+    os.environ["MXA_XPROD_ENGINE"] = eng
+    M = mx.crossproduct.snp_crossprod(X, k, rows, is_snpmajor=False, is_plink_format=True)
+    assert np.array_equal(M, ref), eng
+print("gang ok")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+    assert r.returncode == 0 and "gang ok" in r.stdout, r.stdout + r.stderr
