@@ -410,6 +410,7 @@ def config3_crossprod_leg(torch, mx, L, dev, snps=500_000, indiv=100_000):
                 exact &= bool(np.array_equal(M[rj[0]:rj[-1] + 1, ri[0]:ri[-1] + 1].cpu().numpy(), ref.T))
             sym = bool(torch.equal(M[:2048, :], M[:, :2048].t())) and float(M[-4096:].min()) >= 0.0
             k_ms = ms / max(1, la)
+            # kernel names in a rocprofv3 trace: k_crossprod_gang<false, 0> (FP4) / <true, 0> (int8) -- the gang-synchronised persistent form of the tile pipeline
             out["k_crossprod_f4 (FP4 MFMA, default)" if eng == "f4" else "k_crossprod_i8 (int8 MFMA)"] = {
                 "kernel_ms": round(k_ms, 2), "call_ms_incl_staging": round(wall * 1e3, 1), "Pop_s_full_matrix_count": round(full_ops / (k_ms * 1e-3) * 1e-15, 3),
                 "Pop_s_executed": round(exec_ops / (k_ms * 1e-3) * 1e-15, 3), "dense_peak_Pop_s": peak, "frac_of_peak_executed": round(exec_ops / (k_ms * 1e-3) * 1e-15 / peak, 4),
