@@ -492,6 +492,39 @@ static bool xcd_order_tiles(std::vector<int4> &tiles, int nb, int sr) {
   return true;
 }
 
+// Order for the gang-synchronised kernel: the list is cut into GANGS of 32 tiles (the workgroups of an XCD) that are compact in the tile grid -- bands of 4
+// tile rows, walked column by column, so a gang is 4 x 8 tiles = 12 row blocks (a little more where it meets the diagonal or the end of a band) -- and the
+// gangs are dealt whole to the 8 XCD lists (neighbouring gangs of a band run on different XCDs at the same time and share the band's 4 row blocks through
+// the Infinity Cache).  Gang boundaries stay aligned with multiples of 32 slots in every list; with the 8 x 8 super-tiles of xcd_order_tiles one
+// partial super-tile (36 tiles on the diagonal) shifts every later gang of that list across two super-tile halves.
+static bool gang_order_tiles(std::vector<int4> &tiles) {
+  static const bool on = [] { const char *e = getenv("MXA_XPROD_XCD"); return e ? atoi(e) != 0 : true; }();
+  constexpr size_t kGang = 32;
+  if (!on || tiles.size() < 8 * 64) return false;
+  std::sort(tiles.begin(), tiles.end(), [](const int4 &a, const int4 &b) {
+    if (a.x / 4 != b.x / 4) return a.x / 4 < b.x / 4;
+    if (a.y != b.y) return a.y < b.y;
+    return a.x < b.x;
+  });
+  std::vector<std::vector<int4>> per_xcd(8);
+  size_t next = 0;
+  for (size_t g0 = 0; g0 < tiles.size(); g0 += kGang) {
+    std::vector<int4> &l = per_xcd[next];
+    next = (next + 1) & 7;
+    const size_t g1 = std::min(tiles.size(), g0 + kGang);
+    l.insert(l.end(), tiles.begin() + (long)g0, tiles.begin() + (long)g1);
+    l.resize((l.size() + kGang - 1) / kGang * kGang, make_int4(0, 0, 0, 0));      // only the very last gang is short
+  }
+  size_t longest = 0;
+  for (auto &v : per_xcd) longest = std::max(longest, v.size());
+  std::vector<int4> inter;
+  inter.reserve(longest * 8);
+  for (size_t slot = 0; slot < longest; slot++)
+    for (int x = 0; x < 8; x++) inter.push_back(slot < per_xcd[x].size() ? per_xcd[x][slot] : make_int4(0, 0, 0, 0));
+  tiles.swap(inter);
+  return true;
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------------------
 static std::mutex g_xprof_mutex;   // panels of one call run in several threads (MIRACULIX_NUM_GPUS): the profile counters are shared
 namespace {
@@ -615,7 +648,8 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
       if (flags) tiles.push_back(make_int4(i, j, flags, 0));
     }
   if (tiles.empty()) return 0;
-  const bool xcd_lists = xcd_order_tiles(tiles, nb, 8);
+  static const int gang_order = [] { const char *e = getenv("MXA_XPROD_GANG_ORDER"); return e ? atoi(e) : 1; }();   // 0: the 8 x 8 super-tiles (A/B)
+  const bool xcd_lists = gang_order ? gang_order_tiles(tiles) : xcd_order_tiles(tiles, nb, 8);
   XBuf d_tiles, d_diag, d_gang;
   if (d_gang.alloc(sizeof(int) * kGangCtrs)) return 1;
   if (d_tiles.alloc(tiles.size() * sizeof(int4))) return 1;
