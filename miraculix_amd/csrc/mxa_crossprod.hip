@@ -692,6 +692,7 @@ static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch
   const long slab_bytes = (slab_env && atol(slab_env) > 0 ? atol(slab_env) : 1024L) << 20;
   const int rows_per_chunk = (int)std::max<long>(1, slab_bytes / (rows * 8 * kXT));         // ~1 GiB column slabs
   const int nchunks = (nb + rows_per_chunk - 1) / rows_per_chunk;
+  static const int gang_order = [] { const char *e = getenv("MXA_XPROD_GANG_ORDER"); return e ? atoi(e) : 1; }();
   // one tile list per chunk of tile rows, each in XCD-aware order (super-tiles = the chunk's rows x 8 tile columns)
   std::vector<int4> tiles;
   std::vector<size_t> first((size_t)nchunks + 1, 0);
@@ -701,7 +702,7 @@ static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch
     std::vector<int4> part;
     for (int i = c * rows_per_chunk; i < std::min(nb, (c + 1) * rows_per_chunk); i++)
       for (int j = i; j < nb; j++) part.push_back(make_int4(i, j, i == j ? 1 : 3, 0));
-    chunk_xcd[(size_t)c] = xcd_order_tiles(part, nb, std::min(rows_per_chunk, 8));
+    chunk_xcd[(size_t)c] = gang_order ? gang_order_tiles(part) : xcd_order_tiles(part, nb, std::min(rows_per_chunk, 8));
     tiles.insert(tiles.end(), part.begin(), part.end());
   }
   first[(size_t)nchunks] = tiles.size();
