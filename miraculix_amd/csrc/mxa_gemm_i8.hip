@@ -264,9 +264,8 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
   const char *A_u = reinterpret_cast<const char *>(G) + (size_t)rb * (pitch / kSlabBytes) * kTileBytes;
   const char *B_u = reinterpret_cast<const char *>(Bs) + (size_t)nc * ((size_t)T_total * NT * 1024);
 
-  // the packed tiles are read once per pass only when there is ONE column chunk (the default routes: n <= 6); with several chunks (the opt-in engines at
-  // wide n) the same tile is an operand of every chunk and should stay in the L2 / Infinity Cache: default policy there (wave-uniform choice)
-  const bool stream_once = nchunks == 1;
+  // (with several column chunks -- the opt-in engines at wide n -- a packed tile is an operand of every chunk; choosing the policy per launch with a
+  // wave-uniform branch around the DMA issue cost those power-bound launches 4 % (the branch splits the stage's basic block), the hint itself < 1 %: it stays)
   auto issue = [&](int stage, int buf) {   // stage index relative to st0
     const uint32_t base = lds0 + buf * Cfg::kBufBytes;
     const char *asrc = A_u + (size_t)(st0 + stage) * kTileBytes;
@@ -275,7 +274,7 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
     for (int i = 0; i < (Cfg::kUnits + kI8Waves - 1) / kI8Waves; i++) {
       const int u = wave + i * kI8Waves;
       if (Cfg::kUnits % kI8Waves == 0 || u < Cfg::kUnits) {
-        if (u < 8) { if (stream_once) idma16_stream(asrc + u * 1024, v_lane, base + u * 1024); else idma16_s(asrc + u * 1024, v_lane, base + u * 1024); }
+        if (u < 8) idma16_stream(asrc + u * 1024, v_lane, base + u * 1024);
         else idma16_s(bsrc + (u - 8) * 1024, v_lane, base + kI8ABytes + (u - 8) * 1024);
       }
     }
