@@ -552,11 +552,16 @@ static int launch_tiles(bool f4, size_t ntiles, hipStream_t s, const uint8_t *d_
   if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<false>), kF4Lds, &m2) || ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true>), kF4Lds, &m3)) return 1;
   const dim3 grid((unsigned)ntiles), block(256);
   // gang-synchronised persistent form: needs the interleaved per-XCD lists (d_gang != nullptr) and is not instrumented (MXA_DIAG keeps the classic kernels)
-  static const bool gang_on = [] { const char *e = getenv("MXA_XPROD_GANG"); return !e || atoi(e) != 0; }();
+  // It pays when the launch is long enough for the power limit to matter and a tile long enough to carry the meeting: config 3 -5 ... -8 %, 30 000 rows x
+  // 500k -3.4 %, but K = 50 000 (0.26 ms per tile) +2 ... +8 % at 8 192 - 40 000 rows.  MXA_XPROD_GANG: 0 never, 1 (default) by this estimate, 2 whenever possible.
+  static const int gang_on = [] { const char *e = getenv("MXA_XPROD_GANG"); return e ? atoi(e) : 1; }();
+  int dev = 0, cus = 0;
   if (gang_on && d_gang && !d_diag && ntiles % 8 == 0) {
-    int dev = 0, cus = 0;
     MXA_HIP(hipGetDevice(&dev));
     MXA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  const double est_ms = cus > 0 ? (double)stages * (f4 ? 0.66e-3 : 1.0e-3) * ((double)ntiles / cus) : 0.0;
+  if (cus > 0 && (gang_on >= 2 || (stages >= 1024 && est_ms >= 20.0))) {
     const int slots = (int)(ntiles / 8);
     const dim3 pgrid((unsigned)std::max(8, std::min<int>(cus, (int)ntiles)));
     MXA_HIP(hipMemsetAsync(d_gang, 0, sizeof(int) * kGangCtrs, s));

@@ -108,11 +108,12 @@ def test_fp4_threshold_boundaries_bit_exact(plink, k_below, k_above):
                 assert got[a, b] == float(want), (k, a, b)
 
 
-@pytest.mark.parametrize("env", [{"MXA_XPROD_GANG": "0"}, {"MXA_XPROD_GANG_XCC_MASK": "0"}, {"MXA_XPROD_GANG_XCC_MASK": "1"}, {"MXA_XPROD_GANG_US": "0"}])
+@pytest.mark.parametrize("env", [{"MXA_XPROD_GANG": "0"}, {"MXA_XPROD_GANG": "2"}, {"MXA_XPROD_GANG": "2", "MXA_XPROD_GANG_XCC_MASK": "0"}, {"MXA_XPROD_GANG": "2", "MXA_XPROD_GANG_XCC_MASK": "1"},
+                                 {"MXA_XPROD_GANG": "2", "MXA_XPROD_GANG_US": "0"}])
 def test_gang_synchronised_kernel_does_not_depend_on_the_xcd_population(env):
     """k_crossprod_gang (one resident workgroup per CU, the workgroups of an XCD advance through that XCD's tile list in step): the result must not
     depend on which XCDs the hardware populated -- with the XCD id masked to one or two values the other lists are stolen --, on the join timeout,
-    or on the kernel form at all (MXA_XPROD_GANG=0: one workgroup per tile).  The knobs are read once per process: a child process per setting;
+    or on the kernel form at all (MXA_XPROD_GANG=0: one workgroup per tile; 2: the gang form also for launches too short for it to pay, like this one).  The knobs are read once per process: a child process per setting;
     2304 rows = 45 upper tiles... too few for the per-XCD lists, so 6000 rows (300 tiles, lists of 64 slots) and both engines."""
     import os
     import subprocess
@@ -133,6 +134,12 @@ for eng in ("f4", "i8"):
     os.environ["MXA_XPROD_ENGINE"] = eng
     M = mx.crossproduct.snp_crossprod(X, k, rows, is_snpmajor=False, is_plink_format=True)
     assert np.array_equal(M, ref), eng
+    # the mapped epilogues (GRM / LD) in the same kernel form: fused == the three separate passes, bit for bit
+    f = rng.uniform(0.1, 0.5, size=k)
+    os.environ["MXA_XPROD_FUSED_POST"] = "1"; G1 = mx.crossproduct.grm(X, k, rows, is_plink_format=True, do_scale=True, allele_freq=f)
+    os.environ["MXA_XPROD_FUSED_POST"] = "0"; G0 = mx.crossproduct.grm(X, k, rows, is_plink_format=True, do_scale=True, allele_freq=f)
+    assert np.array_equal(G1, G0), eng
+    del os.environ["MXA_XPROD_FUSED_POST"]
 print("gang ok")
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
