@@ -618,7 +618,15 @@ GemmPlan plan_gemm(long m, long k_pad, int n, const GemmPlan *ksplits_like) {
   // the packed rows passing through: 3 MiB.  Measured at C2 (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE per launch): pieces of 1.5 ms (214 / 181 slabs,
   // 6.8 / 5.8 MB of B) 25.3 GB, pieces of 0.66 ms (96 slabs, 3 MB) 18.9 GB against 12.8 GB algorithmic, for 0.3 % of the time.
   static const long b_l2_bytes = [] { const char *e = getenv("MXA_GEMM_B_L2_BYTES"); return e ? atol(e) : 3L << 20; }();
-  if (b_l2_bytes > 0) l1 = std::max<long>(8, std::min<long>(l1, b_l2_bytes / ((long)p.c * 4096)));
+  if (b_l2_bytes > 0) {
+    long cap = b_l2_bytes / ((long)p.c * 4096);
+    // a SHORT K (the 'T' product of C2: 391 slabs) would be cut into a handful of pieces per row block only to respect the cap: every cut costs a partial
+    // result in HBM and an epilogue.  With the packed stream loaded non-temporally the slabs of a 4x longer range survive in the L2s well enough
+    // (C2 'T': 43.77-43.80 ms with 2-3 splits against 43.98-44.00 with 5; 'N', K = 7813 slabs, keeps the cap: 44.04 against 44.10-44.16)
+    static const bool relax_short_k = [] { const char *e = getenv("MXA_GEMM_RELAX_SHORT_K"); return !e || atoi(e) != 0; }();
+    if (relax_short_k && p.slabs_total <= 6 * cap && units >= 4 * resident) cap *= 4;   // ... and only with row blocks to spare (the 125k-row shard of C2 loses 1.3 % otherwise)
+    l1 = std::max<long>(8, std::min<long>(l1, cap));
+  }
   while (l1 > 16 && units * ((p.slabs_total + l1 - 1) / l1) < 6 * resident) l1 = l1 * 3 / 4;   // at least ~6 rounds of pieces: the queues balance the slots
   const long lt = tail_us > 0 ? std::max<long>(8, (long)(tail_us / slab_us + 0.5)) : 0;
   const bool taper = lt > 0 && units * ((p.slabs_total + l1 - 1) / l1) >= 3 * resident;
