@@ -623,7 +623,8 @@ GemmPlan plan_gemm(long m, long k_pad, int n, const GemmPlan *ksplits_like) {
     // a SHORT K (the 'T' product of C2: 391 slabs) would be cut into a handful of pieces per row block only to respect the cap: every cut costs a partial
     // result in HBM and an epilogue.  With the packed stream loaded non-temporally the slabs of a 4x longer range survive in the L2s well enough
     // (C2 'T': 43.77-43.80 ms with 2-3 splits against 43.98-44.00 with 5; 'N', K = 7813 slabs, keeps the cap: 44.04 against 44.10-44.16)
-    static const bool relax_short_k = [] { const char *e = getenv("MXA_GEMM_RELAX_SHORT_K"); return !e || atoi(e) != 0; }();
+    // OFF by default: the 0.3-0.5 % of the 'T' call (0.2 % of a step) cost 6.5 GB more fabric traffic per 'T' launch (19.7 GB against 13.2; 12.8 algorithmic)
+    static const bool relax_short_k = [] { const char *e = getenv("MXA_GEMM_RELAX_SHORT_K"); return e && atoi(e) != 0; }();
     if (relax_short_k && p.slabs_total <= 6 * cap && units >= 4 * resident) cap *= 4;   // ... and only with row blocks to spare (the 125k-row shard of C2 loses 1.3 % otherwise)
     l1 = std::max<long>(8, std::min<long>(l1, cap));
   }
