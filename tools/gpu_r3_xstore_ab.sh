@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of non-temporal result stores in the crossproduct epilogue: default build (on) against build/xst0 (plain stores); alternating, config 3
+# build the variant first: make -C miraculix_amd/csrc OUT=../../build/xst0 CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result -Wno-inline-asm -I../../include -DMXA_XPROD_NT_STORE=0"
 cd $GRAFT_REPO_ROOT
 for rep in 1 2; do
 for lib in "" build/xst0/libmiraculix_amd.so; do
