@@ -541,7 +541,7 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
               const double *q = scr + (gg * C + hq + blk) * kPitch + j + 16 * i;
               const double out = (q[0] + q[4]) + (q[8] + q[12]);
               const int col = 4 * (u.nc * C + hq + blk) + j;
-              Pbase[(size_t)col * Cfg::kRowsWG + row] = out;
+              Pbase[(size_t)col * Cfg::kRowsWG + row] = out;   // (a non-temporal store here more than doubles WRITE_SIZE: the 32-byte runs of a wave are no longer merged in the L2)
             }
           }
         }
@@ -961,9 +961,9 @@ __global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, lo
       // host-operand pipeline: B was scaled per K chunk (e_splits splits share one exponent row of E).  Every partial is scaled back
       // BEFORE it is added, in the same ascending order: power-of-two scaling commutes with rounding, so the sum is bit-identical to the
       // one-exponent path below
-      for (int s = 0; s < splits; s++) v += ldexp(P[(((size_t)s * ntiles + tile) * n_pad + j) * p_rows + within], back + E[(size_t)(s / e_splits) * e_stride + j]);
+      for (int s = 0; s < splits; s++) v += ldexp(__builtin_nontemporal_load(&P[(((size_t)s * ntiles + tile) * n_pad + j) * p_rows + within]), back + E[(size_t)(s / e_splits) * e_stride + j]);
     } else {
-      for (int s = 0; s < splits; s++) v += P[(((size_t)s * ntiles + tile) * n_pad + j) * p_rows + within];
+      for (int s = 0; s < splits; s++) v += __builtin_nontemporal_load(&P[(((size_t)s * ntiles + tile) * n_pad + j) * p_rows + within]);   // read once
       if (E) v = ldexp(v, back + E[j]);          // undo the operand scaling of the denormal-operand mode (exact)
     }
     if (centered) {
