@@ -37,8 +37,11 @@ void setOptions_compressed(int use_gpu, int cores, int floatLoop, int meanSubstr
  * plink: SNP-major bed payload without the 3 header bytes, snps rows of ceil(indiv/4) bytes;
  * plink_transposed: indiv rows of ceil(snps/4) bytes; f: snps allele frequencies (required when centring);
  * max_n: largest n later passed to dgemm_compressed (buffers grow if exceeded).  The data is copied: the caller
- * may free its buffers afterwards.  Either matrix pointer may also be a device pointer.  On failure
- * *compressed is left NULL and a message is printed (reference: print + handle unset). */
+ * may free its buffers afterwards.  Either matrix pointer may also be a device pointer.
+ * plink_transposed may be NULL or the same pointer as plink -- the call shape of the reference's CPU path, which never reads it
+ * (5codesChar.cc:368-393; utils/benchmark/benchmark.f90:185 passes the same pointer twice): then only the SNP-major matrix is uploaded
+ * and the individual-major copy is produced on the device (2-bit transpose of the raw PLINK codes), bit-identical to the object built
+ * from two pointers.  On failure *compressed is left NULL and a message is printed (reference: print + handle unset). */
 void plink2compressed(char *plink, char *plink_transposed, int snps, int indiv, double *f, int max_n,
                       void **compressed);
 
@@ -122,7 +125,8 @@ int mxa_device_count(void);
  * plink_transposed at the FULL individual-major payload (row pitch ceil(snps_total/4)); f at the FULL frequency
  * vector.  snp_begin must be a multiple of 4 so that packed bytes split cleanly.
  * For 'N' the caller passes rows [snp_begin, snp_end) of B and sum-reduces C over the shards
- * (the centring term is a partial sum too and rides along); for 'T' C holds rows [snp_begin, snp_end). */
+ * (the centring term is a partial sum too and rides along); for 'T' C holds rows [snp_begin, snp_end).
+ * plink_transposed may be NULL (or == plink): the shard transposes its own SNP block on the device. */
 void mxa_plink2compressed_shard(char *plink, char *plink_transposed, int snps_total, int indiv, int snp_begin,
                                 int snp_end, double *f, int max_n, void **compressed);
 
@@ -308,6 +312,11 @@ void mxa_profile_get(int *launches, double *total_ms);
 
 /* geometry of the last dgemm_compressed call (for roofline accounting): rows, inner dim, n, split count */
 void mxa_last_geometry(long *m, long *k, int *n, int *splits, int *a_tile, int *c_tile);
+/* doubles of split-K partial sums the fp64 MFMA launch of an m x k x n product writes (no device needed: tests check that the plan of the
+ * columns left after a peel, which can be LARGER than the plan of all n columns, never outgrows the workspace) */
+long mxa_plan_partial_doubles(long m, long k, int n);
+/* capacity (doubles) of the partial-sum workspace an object holds right now; -1 for an invalid / multi-device object */
+long mxa_partial_capacity(void *compressed);
 
 #ifdef __cplusplus
 }

@@ -184,6 +184,38 @@ static int stage_matrix(PackedMatrix &M, const uint8_t *src, size_t src_pitch, l
   return rc;
 }
 
+// Both orientations from the SNP-major PLINK matrix alone: the raw bytes are brought to the device once (a host source: one compact upload;
+// a device source is used in place), recoded into the SNP-major object, transposed on the device (raw PLINK codes, so a missing 01 stays a
+// missing 01) and the transposed bytes recoded into the individual-major object -- bit-identical to staging a caller-supplied transposed
+// copy.  Temporary device memory: the raw matrix (host sources only) + its transpose, released before the workspace is allocated.
+static int stage_from_snp_major(Handle *h, const uint8_t *plink, size_t plink_pitch) {
+  const long snps = h->snps, indiv = h->indiv;
+  const size_t bps = ((size_t)indiv + 3) / 4, bpi = ((size_t)snps + 3) / 4;
+  hipStream_t s = h->stream;
+  int src_dev = -1;
+  const bool src_on_device = ptr_location(plink, &src_dev) == 1;
+  uint8_t *d_raw = nullptr, *d_raw_t = nullptr;
+  int rc = 0;
+  const uint8_t *d_src = plink;
+  size_t d_pitch = plink_pitch;
+  if (!src_on_device || src_dev != h->device || plink_pitch != bps) {   // compact copy on this device (the transpose kernels want pitch = ceil(indiv/4))
+    if (src_on_device && src_dev != h->device && sync_foreign_producer(src_dev)) return 1;
+    MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_raw), (size_t)snps * bps));
+    hipError_t e = plink_pitch == bps ? hipMemcpyAsync(d_raw, plink, (size_t)snps * bps, hipMemcpyDefault, s)
+                                      : hipMemcpy2DAsync(d_raw, bps, plink, plink_pitch, bps, snps, hipMemcpyDefault, s);
+    if (!check_hip(e, __func__, __LINE__) || !check_hip(hipStreamSynchronize(s), __func__, __LINE__)) { (void)hipFree(d_raw); return 1; }
+    d_src = d_raw; d_pitch = bps;
+  }
+  rc = stage_matrix(h->snp_major, d_src, d_pitch, snps, indiv, s);
+  if (!rc && !check_hip(hipMalloc(reinterpret_cast<void **>(&d_raw_t), (size_t)indiv * bpi), __func__, __LINE__)) rc = 1;
+  if (!rc) rc = launch_transpose_2bit(d_src, snps, indiv, d_raw_t, s);
+  if (!rc && !check_hip(hipStreamSynchronize(s), __func__, __LINE__)) rc = 1;
+  if (d_raw) { (void)hipFree(d_raw); d_raw = nullptr; }
+  if (!rc) rc = stage_matrix(h->ind_major, d_raw_t, bpi, indiv, snps, s);
+  if (d_raw_t) (void)hipFree(d_raw_t);
+  return rc;
+}
+
 void destroy_handle(Handle *h) {
   if (!h) return;
   {   // mxa_last_path() must not read a flag of this object once its memory is gone
@@ -202,6 +234,16 @@ void destroy_handle(Handle *h) {
   free(h->h_f);
   h->magic = 0;
   delete h;
+}
+
+// The partial-sum workspace is sized by ensure_workspace for the plans of n columns; a product that peels odd columns multiplies fewer columns
+// with a DIFFERENT plan (tile width, K pieces), which can need more room than the unpeeled one (100 000 x 30 000, n = 9..11: 12.81 M doubles
+// against 11.96 M).  Every launch path calls this with the plan it is about to launch.
+static int ensure_partials(Workspace &w, const GemmPlan &p, hipStream_t s) {
+  const size_t need = (size_t)p.splits * p.n_pad * p.m_pad;
+  if (need <= w.cap_P) return 0;
+  MXA_HIP(hipStreamSynchronize(s));   // earlier products on this stream may still be reading the old buffer
+  return grow(&w.d_P, &w.cap_P, need);
 }
 
 static int ensure_workspace(Handle *h, int n) {
@@ -228,7 +270,11 @@ int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink
                   int max_n, void **out, int device) {
   if (out) *out = nullptr;
   if (!out) { set_error(1, "plink2compressed: compressed is NULL"); return 1; }
-  if (!plink || !plink_t) { set_error(1, "plink2compressed: both plink and plink_transposed are required on the GPU path"); return 1; }
+  if (!plink) { set_error(1, "plink2compressed: plink is NULL"); return 1; }
+  // plink_transposed NULL or the same pointer as plink: the reference's CPU path never reads it and its Fortran benchmark passes the same
+  // pointer twice (5codesChar.cc:368-393, utils/benchmark/benchmark.f90:185).  Only the SNP-major matrix crosses PCIe then; the
+  // individual-major copy is produced on the device (k_transpose_2bit*), as mxa_bed2compressed does.
+  const bool one_pointer = !plink_t || plink_t == plink;
   if (snps <= 0 || indiv <= 0) { set_error(1, "plink2compressed: snps and indiv must be positive"); return 1; }
   Options &o = options();
   if (!o.set) {  // reference default before any user call: gpu when compiled with CUDA, centred (5codesChar.cc:127-143)
@@ -259,8 +305,9 @@ int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink
   // enqueued on the default stream (e.g. PyTorch ops) is complete before k_pack_B reads it, and later default-stream work sees
   // C.  Callers on other streams pass theirs to mxa_dgemm_compressed_device.
   if (!check_hip(hipStreamCreateWithFlags(&h->stream, hipStreamDefault), __func__, __LINE__)) { destroy_handle(h); return 1; }
-  if (stage_matrix(h->snp_major, plink, plink_pitch, snps, indiv, h->stream) ||
-      stage_matrix(h->ind_major, plink_t, plink_t_pitch, indiv, snps, h->stream)) { destroy_handle(h); return 1; }
+  if (one_pointer ? stage_from_snp_major(h, plink, plink_pitch) :
+                    (stage_matrix(h->snp_major, plink, plink_pitch, snps, indiv, h->stream) ||
+                     stage_matrix(h->ind_major, plink_t, plink_t_pitch, indiv, snps, h->stream))) { destroy_handle(h); return 1; }
   if (!check_hip(hipMalloc(reinterpret_cast<void **>(&h->d_f), sizeof(double) * snps), __func__, __LINE__)) { destroy_handle(h); return 1; }
   h->h_f = (double *)calloc((size_t)snps, sizeof(double));
   if (f) {
@@ -426,6 +473,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     if (rc8 == 0 || rc8 == 3) {
       if (rc8 == 3) {   // fp64 pair tables, run only if the flag is set
         const GemmPlan pl = plan_lut(m, G.k_pad, n);
+        if (ensure_partials(w, pl, s)) return 1;
         if (launch_lut(G, dB, ldb, n, w.d_P, pl, s, d_flag)) return 1;
         if (launch_finish(w.d_P, pl, m, n, dC, ldc, fill_rows, trans ? 1 : 0, centered, d_sumB, d_sumfB, h->d_f, s, nullptr, 0, 0, d_flag)) return 1;
       }
@@ -460,6 +508,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   static const int lut_max_n = [] { const char *e = getenv("MXA_LUT_MAX_N"); return e ? atoi(e) : 2; }();
   const bool use_lut = n <= lut_max_n && n <= 4;
   GemmPlan p = use_lut ? plan_lut(m, G.k_pad, n) : plan_gemm(m, G.k_pad, n);
+  if (ensure_partials(w, p, s)) return 1;   // the plan of the columns left after a peel may need more than the plan ensure_workspace sized for
   {
     std::lock_guard<std::mutex> lk(g_prof_mutex);
     Geometry &geo = last_geometry();
@@ -576,6 +625,7 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
   const GemmPlan p = plan_gemm(m, G.k_pad, n);
   const int mode = gemm_default_mode(p.c);
   if (mode != 2 && mode != 3) return 2;
+  if (ensure_partials(w, p, s)) return 1;
   { std::lock_guard<std::mutex> lk(g_prof_mutex); Geometry &geo = last_geometry(); geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c; geo.path = 0; }
   MXA_HIP(hipMemsetAsync(w.d_denflag, 0, sizeof(int), s));   // range guard of the denormal-operand mode, raised by any K group's launch_colexp
   MXA_HIP(hipEventRecord(h->pev[0], s));
@@ -792,7 +842,7 @@ void mxa_plink2compressed_shard(char *plink, char *plink_transposed, int snps_to
   }
   const size_t ps = ((size_t)indiv + 3) / 4, pi = ((size_t)snps_total + 3) / 4;
   const uint8_t *p = reinterpret_cast<const uint8_t *>(plink) + (size_t)snp_begin * ps;
-  const uint8_t *pt = reinterpret_cast<const uint8_t *>(plink_transposed) + (size_t)snp_begin / 4;
+  const uint8_t *pt = (!plink_transposed || plink_transposed == plink) ? nullptr : reinterpret_cast<const uint8_t *>(plink_transposed) + (size_t)snp_begin / 4;
   (void)create_handle(p, ps, pt, pi, snp_end - snp_begin, indiv, f ? f + snp_begin : nullptr, max_n, compressed);
 }
 
@@ -1002,6 +1052,17 @@ int mxa_last_range_fallback(void *compressed) {
 void mxa_last_geometry(long *m, long *k, int *n, int *splits, int *a_tile, int *c_tile) {
   const Geometry &g = last_geometry();
   if (m) *m = g.m; if (k) *k = g.k; if (n) *n = g.n; if (splits) *splits = g.splits; if (a_tile) *a_tile = g.a; if (c_tile) *c_tile = g.c;
+}
+
+long mxa_plan_partial_doubles(long m, long k, int n) {
+  if (m <= 0 || k <= 0 || n <= 0) return 0;
+  const GemmPlan p = plan_gemm(m, (k + kSlabK - 1) / kSlabK * kSlabK, n);
+  return (long)p.splits * p.n_pad * p.m_pad;
+}
+long mxa_partial_capacity(void *compressed) {
+  if (!compressed || is_multi(compressed)) return -1;
+  Handle *h = as_handle(compressed, "mxa_partial_capacity");
+  return h ? (long)h->ws.cap_P : -1;
 }
 
 // ---- .bed staging owned by the library

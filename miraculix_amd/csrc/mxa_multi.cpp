@@ -166,6 +166,14 @@ struct Multi {
   hipStream_t root_stream = nullptr;
   hipEvent_t ev_red0 = nullptr, ev_red1 = nullptr; // around the reduction kernel; ev_red1 doubles as "the previous reduction has read all partials"
   bool red_recorded = false, red_pending = false;
+  // "the result of the last reduction is where the caller asked for it": recorded on the root stream at the END of multi_reduce (after the
+  // copy from d_red when C is not memory of the root device).  Every shard stream waits for it before its next product of any kind, so that
+  // products issued back to back with sync = 0 are ordered like calls on one stream -- an 'N' into C followed by a 'T' that reads that C as B
+  hipEvent_t ev_result = nullptr;
+  bool result_recorded = false;
+  const char *res_lo = nullptr, *res_hi = nullptr;   // byte range of that result: only a product that touches it has to wait (the 'T' product of a
+                                                      // step reads other memory and keeps running beside the reduction of the step's 'N' product)
+
   int reductions = 0; double reduce_ms = 0.0;
   bool use_rccl = false, rccl_checked = false;
   double rccl_diff = -1.0;
@@ -266,6 +274,7 @@ int finish_setup(Multi *m) {
   MXA_HIP(hipStreamCreateWithFlags(&m->root_stream, hipStreamDefault));
   MXA_HIP(hipEventCreate(&m->ev_red0));
   MXA_HIP(hipEventCreate(&m->ev_red1));
+  MXA_HIP(hipEventCreateWithFlags(&m->ev_result, hipEventDisableTiming));
   const char *red = getenv("MXA_REDUCE");
   if (red && std::string(red) == "rccl") {
     const int rc = init_rccl(m);
@@ -330,6 +339,7 @@ void multi_destroy(void *obj) {
   if (m->d_chk) (void)hipFree(m->d_chk);
   if (m->ev_red0) (void)hipEventDestroy(m->ev_red0);
   if (m->ev_red1) (void)hipEventDestroy(m->ev_red1);
+  if (m->ev_result) (void)hipEventDestroy(m->ev_result);
   if (m->root_stream) (void)hipStreamDestroy(m->root_stream);
   m->magic = 0;
   delete m;
@@ -372,11 +382,12 @@ static int multi_build(long snps, long indiv, int shards, void **out, const std:
 }
 
 int multi_create(const uint8_t *plink, const uint8_t *plink_t, long snps, long indiv, const double *f, int max_n, int shards, void **out) {
-  if (!plink || !plink_t) { if (out) *out = nullptr; set_error(1, "plink2compressed: both plink and plink_transposed are required on the GPU path"); return 1; }
+  if (!plink) { if (out) *out = nullptr; set_error(1, "plink2compressed: plink is NULL"); return 1; }
+  const bool one_pointer = !plink_t || plink_t == plink;   // the reference's CPU call shape (benchmark.f90:185): every shard transposes its own SNP block on its device
   const size_t ps = ((size_t)indiv + 3) / 4, pi = ((size_t)snps + 3) / 4;
   return multi_build(snps, indiv, shards, out, [=](int, long b, long e, int dev, void **h) {
     // rows [b, e) of the SNP-major matrix; byte columns [b/4, ..) of the individual-major matrix (row pitch of the FULL matrix)
-    return create_handle(plink + (size_t)b * ps, ps, plink_t + (size_t)b / 4, pi, e - b, indiv, f ? f + b : nullptr, max_n, h, dev);
+    return create_handle(plink + (size_t)b * ps, ps, one_pointer ? nullptr : plink_t + (size_t)b / 4, pi, e - b, indiv, f ? f + b : nullptr, max_n, h, dev);
   });
 }
 
@@ -406,6 +417,13 @@ static void harvest_reduce(Multi *m) {
   float ms = 0.f;
   if (hipEventSynchronize(m->ev_red1) != hipSuccess || hipEventElapsedTime(&ms, m->ev_red0, m->ev_red1) != hipSuccess) { (void)hipGetLastError(); return; }
   m->reductions += 1; m->reduce_ms += ms;
+}
+
+// does the column-major operand p (rows x n, leading dimension ld) overlap the memory the last reduction delivered its result to?
+static bool touches_last_result(const Multi *m, const void *p, long rows, long ld, int n) {
+  if (!m->result_recorded || !p) return false;
+  const char *lo = reinterpret_cast<const char *>(p), *hi = lo + sizeof(double) * ((size_t)ld * (size_t)(n - 1) + (size_t)rows);
+  return lo < m->res_hi && m->res_lo < hi;
 }
 
 static int run_all(Multi *m, const std::function<int(int)> &job) {
@@ -559,6 +577,10 @@ static int multi_reduce(Multi *m, long rows, int n, double *C, long ldc, bool sy
   } else if (reduce_p2p(m, rows, n, dC, dldc, ldc, true)) return 1;
   MXA_HIP(hipSetDevice(m->root));
   if (!c_local) MXA_HIP(hipMemcpyAsync(C, dC, sizeof(double) * (size_t)ldc * n, hipMemcpyDefault, m->root_stream));
+  MXA_HIP(hipEventRecord(m->ev_result, m->root_stream));
+  m->result_recorded = true;
+  m->res_lo = reinterpret_cast<const char *>(C);
+  m->res_hi = m->res_lo + sizeof(double) * ((size_t)ldc * (size_t)(n - 1) + (size_t)std::max(rows, ldc));
   if (sync || !c_dev) MXA_HIP(hipStreamSynchronize(m->root_stream));
   return 0;
 }
@@ -612,6 +634,10 @@ static int multi_product(Multi *m, bool trans, int n, const double *B, const dou
       // ranges behind the product (gemm_host_pipelined)
       int bd = -1, cd = -1;
       const bool remote_op = ptr_location(Bg, &bd) == 0 || bd != S.h->device || ptr_location(Cg, &cd) == 0 || cd != S.h->device;
+      // B may be the result of the 'N' product issued just before (sync = 0): the root stream delivers it, the shard streams are not
+      // ordered against the root stream by themselves
+      MXA_HIP(hipSetDevice(S.h->device));
+      if (touches_last_result(m, Bg, indiv, ldb, n) || touches_last_result(m, Cg, fill, ldc, n)) MXA_HIP(hipStreamWaitEvent(S.h->stream, m->ev_result, 0));
       if (gemm_any(S.h, true, n, Bg, ldb, Cg, ldc, fill, sync || remote_op, true)) return 1;
       return 0;
     });
@@ -624,6 +650,7 @@ static int multi_product(Multi *m, bool trans, int n, const double *B, const dou
       if (m->red_recorded) MXA_HIP(hipStreamWaitEvent(S.h->stream, m->ev_red1, 0));
       if (S.pushed_recorded) MXA_HIP(hipStreamWaitEvent(S.h->stream, S.ev_pushed, 0));   // ... and this shard's own push / ncclReduce has read it
       const double *Bg = per_shard ? Bs[g] : B + S.begin;
+      if (touches_last_result(m, Bg, S.end - S.begin, ldb, n)) MXA_HIP(hipStreamWaitEvent(S.h->stream, m->ev_result, 0));   // B is (part of) the previous result
       // a B in host memory or on another GPU: synchronous inside the shard's own worker thread, so that a big one arrives in K ranges behind
       // the product (gemm_host_pipelined)
       int bd = -1;
@@ -672,6 +699,7 @@ int multi_gram(void *obj, int n, const double *V, long ldv, double *out, long ld
     Shard &S = m->sh[g];
     MXA_HIP(hipSetDevice(S.h->device));
     if (m->red_recorded) MXA_HIP(hipStreamWaitEvent(S.h->stream, m->ev_red1, 0));
+    if (touches_last_result(m, V, indiv, ldv, n)) MXA_HIP(hipStreamWaitEvent(S.h->stream, m->ev_result, 0));
     if (S.pushed_recorded) MXA_HIP(hipStreamWaitEvent(S.h->stream, S.ev_pushed, 0));
     if (gram_any(S.h, n, V, ldv, S.d_part, indiv, false)) return 1;
     return publish_partial(m, g, indiv, n, !m->use_rccl);

@@ -54,10 +54,13 @@ def check_storage_object(obj_ref):
 
 def init_compressed(plink, plink_transposed, snps, indiv, freq, max_ncol):
     """dgemm_compressed.jl:82-93.  plink: snps rows x ceil(indiv/4) bytes, plink_transposed: indiv rows x ceil(snps/4) bytes
-    (uint8, C-contiguous numpy arrays or torch uint8 tensors, host or device).  Returns the opaque object reference."""
+    (uint8, C-contiguous numpy arrays or torch uint8 tensors, host or device).  plink_transposed may be None (or plink itself, the call
+    shape of the reference's CPU benchmark, utils/benchmark/benchmark.f90:185): the library then builds the individual-major copy on the
+    device.  Returns the opaque object reference."""
     obj_ref = ctypes.c_void_p(None)
     check_dimensions(plink, snps, indiv)
-    check_dimensions(plink_transposed, indiv, snps)
+    if plink_transposed is not None and plink_transposed is not plink:
+        check_dimensions(plink_transposed, indiv, snps)
     L = _lib.check_library_handle()
     if not _lib.is_torch_tensor(freq):
         freq = np.ascontiguousarray(freq, dtype=np.float64)

@@ -150,3 +150,24 @@ def test_shard_partition_covers_all_snps_at_multiples_of_4(built):
             for g in range(cnt, shards):
                 pb, pe = shard_bounds(snps, shards, g)
                 assert pb == pe
+
+
+def test_peeled_plan_can_need_more_partials_than_the_unpeeled_one(built):
+    """The partial-sum workspace is sized for the plan of n columns, but a product that peels its odd columns into the exact int8 route launches
+    the fp64 MFMA kernel with the plan of the REMAINING columns -- another tile width and other K pieces -- which may write more partial sums
+    (advisor finding, round 3: 100 000 x 30 000, n = 9..11).  The planner runs without a device (256 CUs assumed): document that such shapes
+    exist, so that the growth check in gemm_device (ensure_partials) is known to be load-bearing; the GPU test
+    tests/test_workspace_gpu.py runs one of them."""
+    L = ctypes.CDLL(built)
+    L.mxa_plan_partial_doubles.restype = ctypes.c_long
+    L.mxa_plan_partial_doubles.argtypes = [ctypes.c_long, ctypes.c_long, ctypes.c_int]
+    worse = []
+    for m, k in [(30_000, 100_000), (100_000, 30_000), (12_000, 50_000), (50_000, 12_000), (2050, 777), (50_000, 1_000_000)]:
+        for n in range(5, 132):
+            if n % 4 == 0:
+                continue
+            full, peeled = L.mxa_plan_partial_doubles(m, k, n), L.mxa_plan_partial_doubles(m, k, n - n % 4)
+            assert full > 0 and peeled > 0
+            if peeled > full:
+                worse.append((m, k, n, full, peeled))
+    assert any(m == 30_000 and k == 100_000 and n == 10 for m, k, n, _, _ in worse), worse[:5]

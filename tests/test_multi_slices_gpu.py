@@ -231,3 +231,44 @@ def test_two_physical_devices(mx):
         assert all(s["peer_to_root"] in (-1, 0, 1) for s in info["per_shard"])
     finally:
         dg.free_compressed(obj)
+
+
+@pytest.mark.parametrize("shards", [2, 8])
+def test_async_chain_T_reads_the_result_of_the_preceding_N(mx, shards):
+    """products issued back to back with sync = 0 are ordered like calls on one stream (include/miraculix_amd.h): an 'N' product into C followed at
+    once by a 'T' product whose B IS that C (the step Z^T (Z x)) -- the reduction delivers C on the root stream, the shard streams must wait for
+    it (advisor finding of round 3: the 'T' branch did not).  A big enough problem that the reduction is still running when 'T' is enqueued;
+    the asynchronous chain must equal the synchronous one bit for bit, five times in a row."""
+    import torch
+    snps, indiv, n = 60_000, 20_000, 8
+    prob = make_problem(snps, indiv, n, seed=18)
+    dg = mx.dgemm_compressed
+    dg.set_options(use_gpu=True, not_center=False, verbose=0)
+    obj = _make(mx, prob, n, shards)
+    try:
+        dev = torch.device("cuda", 0)
+        bounds = dg.shard_bounds(obj, snps)
+        ld = max(e - b for b, e in bounds)
+        g = torch.Generator(device=dev); g.manual_seed(2)
+        X = torch.randn((n, snps), dtype=torch.float64, device=dev, generator=g)
+        X_s = []
+        for b, e in bounds:
+            buf = torch.zeros((n, ld), dtype=torch.float64, device=dev)
+            buf[:, : e - b] = X[:, b:e]
+            X_s.append(buf.t()[: e - b])
+
+        def chain(sync):
+            CN = torch.full((n, indiv), float("nan"), dtype=torch.float64, device=dev).t()
+            CT_s = [torch.full((n, ld), float("nan"), dtype=torch.float64, device=dev).t()[: e - b] for b, e in bounds]
+            dg.dgemm_compressed_multi(False, obj, X_s, [CN] + [None] * (shards - 1), sync=sync)
+            dg.dgemm_compressed_multi(True, obj, [CN] * shards, CT_s, sync=sync)
+            dg.multi_synchronize(obj)
+            return CN, torch.cat([c for c in CT_s])
+
+        CN0, CT0 = chain(True)
+        assert bool(torch.isfinite(CT0).all())
+        for _ in range(5):
+            CN1, CT1 = chain(False)
+            assert torch.equal(CN1, CN0) and torch.equal(CT1, CT0)
+    finally:
+        dg.free_compressed(obj)

@@ -107,3 +107,59 @@ def test_bed_file_staging(mx, tmp_path):
     # python-side reader agrees
     p2, s2, i2 = mx.read_plink.read_bed(base + ".bed")
     assert (s2, i2) == (1237, 415) and np.array_equal(p2, prob["plink"])
+
+
+@pytest.mark.parametrize("snps,indiv,missing", [(1003, 501, 0.0), (2064, 784, 0.1), (130, 1027, 0.05), (4097, 255, 0.0)])
+@pytest.mark.parametrize("how", ["null", "same_pointer", "device_source"])
+def test_one_pointer_staging_is_bit_identical(mx, snps, indiv, missing, how):
+    """plink2compressed with plink_transposed == NULL or == plink (the reference's CPU call shape: 5codesChar.cc:368-393 never reads the
+    transposed matrix, utils/benchmark/benchmark.f90:185 passes plink twice): the individual-major copy is built on the device from the
+    raw PLINK codes, so both products are bit-identical to those of the object staged from two pointers -- missing codes (01) included --
+    and agree with the oracle."""
+    import torch
+    o = Oracle()
+    n = 9
+    prob = make_problem(snps, indiv, n, seed=snps + 1, missing_frac=missing)
+    dg = mx.dgemm_compressed
+    dg.set_options(use_gpu=True, not_center=False, verbose=0)
+    ref_obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], n)
+    if how == "null":
+        obj = dg.init_compressed(prob["plink"], None, snps, indiv, prob["f"], n)
+    elif how == "same_pointer":
+        obj = dg.init_compressed(prob["plink"], prob["plink"], snps, indiv, prob["f"], n)
+    else:
+        obj = dg.init_compressed(torch.from_numpy(prob["plink"]).cuda(), None, snps, indiv, prob["f"], n)
+    try:
+        for trans in (0, 1):
+            k, m = (indiv, snps) if trans else (snps, indiv)
+            B = make_B(k, n, seed=3 + trans)
+            C2 = dg.dgemm_compressed_main(bool(trans), ref_obj, np.asfortranarray(B.T), snps, indiv)
+            C1 = dg.dgemm_compressed_main(bool(trans), obj, np.asfortranarray(B.T), snps, indiv)
+            assert np.array_equal(C1, C2)
+            ref = o.dgemm_dense(trans, prob, B, 1)[:, :m]
+            assert np.abs(C1.T - ref).max() <= 1e-11 * np.abs(ref).max()
+    finally:
+        dg.free_compressed(obj)
+        dg.free_compressed(ref_obj)
+
+
+def test_one_pointer_staging_under_num_gpus(mx, monkeypatch):
+    """the same call shape with MIRACULIX_NUM_GPUS = 3 (virtual shards on one device): every shard transposes its own SNP block"""
+    o = Oracle()
+    snps, indiv, n = 3001, 777, 5
+    prob = make_problem(snps, indiv, n, seed=21)
+    dg = mx.dgemm_compressed
+    dg.set_options(use_gpu=True, not_center=False, verbose=0)
+    monkeypatch.setenv("MIRACULIX_NUM_GPUS", "3")
+    obj = dg.init_compressed(prob["plink"], None, snps, indiv, prob["f"], n)
+    monkeypatch.delenv("MIRACULIX_NUM_GPUS")
+    try:
+        assert dg.num_shards(obj) == 3
+        for trans in (0, 1):
+            k, m = (indiv, snps) if trans else (snps, indiv)
+            B = make_B(k, n, seed=8 + trans)
+            C = dg.dgemm_compressed_main(bool(trans), obj, np.asfortranarray(B.T), snps, indiv)
+            ref = o.dgemm_dense(trans, prob, B, 1)[:, :m]
+            assert np.abs(C.T - ref).max() <= 1e-11 * np.abs(ref).max()
+    finally:
+        dg.free_compressed(obj)
