@@ -242,31 +242,59 @@ def measure_traffic(args):
 
 
 # ====================================================================================================== helpers shared by the legs
+def extract_sample(torch, S, nsample=64, seed=1):
+    """the packed rows a sampled check needs, copied to the host: nsample individuals (rows of the individual-major matrix) for 'N' and
+    nsample SNPs (rows of the SNP-major matrix) for 'T'.  After this the raw device matrices may be released (the full-extent legs need
+    the memory for the staged objects)."""
+    import numpy as np
+    dev, snps, indiv = S["dev"], S["snps"], S["indiv"]
+    rng = np.random.default_rng(seed)
+    ii = np.sort(rng.choice(indiv, min(nsample, indiv), replace=False))
+    ss = np.sort(rng.choice(snps, min(nsample, snps), replace=False))
+    f = S["f"].cpu().numpy()
+    return dict(snps=snps, indiv=indiv, dev=dev, f=f, ii=ii, ss=ss,
+                rows_t=np.ascontiguousarray(S["plink_t"][torch.from_numpy(ii).to(dev)].cpu().numpy()),      # nsample x ceil(snps/4)
+                rows_s=np.ascontiguousarray(S["plink"][torch.from_numpy(ss).to(dev)].cpu().numpy()))       # nsample x ceil(indiv/4)
+
+
+def check_sample(torch, sample, trans, Bdev, Cdev, cols, centered, row_offset=0):
+    """sampled rows of a result (individuals for 'N', SNPs for 'T'), columns `cols`, against the long-double dense oracle on the extracted
+    packed rows.  Cdev may be a row block of the result starting at row_offset (per-shard results).  Returns max|C - ref| / max|ref|.
+    (Checker use of oracle/: tests and this file's parity legs only.)"""
+    import numpy as np
+    from _util import Oracle
+    o = Oracle()
+    dev, snps, indiv = sample["dev"], sample["snps"], sample["indiv"]
+    Bs = np.ascontiguousarray(Bdev[:, cols].t().cpu().numpy())                        # len(cols) x k, row j = column cols[j]
+    if not trans:
+        ii, rows = sample["ii"], sample["rows_t"]
+        sub_plink = o.transpose_2bit(rows, len(ii), snps)                              # snps x ceil(nsample/4)
+        prob = dict(snps=snps, indiv=len(ii), plink=sub_plink, plink_t=rows, f=sample["f"])
+        ref = o.dgemm_dense(0, prob, Bs, centered)                                     # len(cols) x nsample
+        got = Cdev[torch.from_numpy(ii - row_offset).to(Cdev.device)][:, cols].t().cpu().numpy()
+    else:
+        ss, srows = sample["ss"], sample["rows_s"]
+        prob = dict(snps=len(ss), indiv=indiv, plink=srows, plink_t=None, f=np.ascontiguousarray(sample["f"][ss]))
+        ref = o.dgemm_dense(1, prob, Bs, centered)
+        got = Cdev[torch.from_numpy(ss - row_offset).to(Cdev.device)][:, cols].t().cpu().numpy()
+    return float(np.abs(got - ref).max() / np.abs(ref).max())
+
+
 def sampled_rows_vs_oracle(torch, S, trans, Bdev, Cdev, cols, centered, nsample=64, seed=1):
     """nsample rows of a result (individuals for 'N', SNPs for 'T'), columns `cols`, against the long-double dense oracle on the
     extracted rows of the packed matrix.  S: dict(dev, snps, indiv, plink (SNP-major, device), plink_t (individual-major, device),
-    f (device)).  Returns max|C - ref| / max|ref|.  (Checker use of oracle/: tests and this file's parity legs only.)"""
+    f (device)).  Returns max|C - ref| / max|ref|."""
     import numpy as np
-    from _util import Oracle
     dev, snps, indiv = S["dev"], S["snps"], S["indiv"]
-    o = Oracle()
     rng = np.random.default_rng(seed)
-    f = S["f"].cpu().numpy()
-    Bs = np.ascontiguousarray(Bdev[:, cols].t().cpu().numpy())                        # len(cols) x k, row j = column cols[j]
+    sample = dict(snps=snps, indiv=indiv, dev=dev, f=S["f"].cpu().numpy())
     if not trans:
-        ii = np.sort(rng.choice(indiv, nsample, replace=False))
-        rows = S["plink_t"][torch.from_numpy(ii).to(dev)].cpu().numpy()               # nsample x ceil(snps/4)
-        sub_plink = o.transpose_2bit(np.ascontiguousarray(rows), nsample, snps)        # snps x ceil(nsample/4)
-        prob = dict(snps=snps, indiv=nsample, plink=sub_plink, plink_t=rows, f=f)
-        ref = o.dgemm_dense(0, prob, Bs, centered)                                     # len(cols) x nsample
-        got = Cdev[torch.from_numpy(ii).to(dev)][:, cols].t().cpu().numpy()
+        sample["ii"] = np.sort(rng.choice(indiv, nsample, replace=False))
+        sample["rows_t"] = np.ascontiguousarray(S["plink_t"][torch.from_numpy(sample["ii"]).to(dev)].cpu().numpy())
     else:
-        ss = np.sort(rng.choice(snps, nsample, replace=False))
-        srows = S["plink"][torch.from_numpy(ss).to(dev)].cpu().numpy()                # nsample x ceil(indiv/4)
-        prob = dict(snps=nsample, indiv=indiv, plink=np.ascontiguousarray(srows), plink_t=None, f=np.ascontiguousarray(f[ss]))
-        ref = o.dgemm_dense(1, prob, Bs, centered)
-        got = Cdev[torch.from_numpy(ss).to(dev)][:, cols].t().cpu().numpy()
-    return float(np.abs(got - ref).max() / np.abs(ref).max())
+        sample["ss"] = np.sort(rng.choice(snps, nsample, replace=False))
+        sample["rows_s"] = np.ascontiguousarray(S["plink"][torch.from_numpy(sample["ss"]).to(dev)].cpu().numpy())
+    return check_sample(torch, sample, trans, Bdev, Cdev, cols, centered)
 
 
 def stage_object(torch, mx, dev, snps, indiv, n, seed, centered):
@@ -423,6 +451,167 @@ def config3_crossprod_leg(torch, mx, L, dev, snps=500_000, indiv=100_000):
         del X, M
         torch.cuda.empty_cache()
     return out
+
+
+def _stage_full(torch, mx, dev, snps, indiv, n, seed, shards):
+    """raw synthetic matrices on the device + one object over `shards` SNP blocks behind the plain symbols (MIRACULIX_NUM_GPUS; on a
+    one-GPU box the shards share the device: the real SNP partition, worker threads, per-shard streams and the fixed-order reduction)"""
+    plink = synth_genotypes_device(torch, snps, indiv, seed, dev)
+    plink_t = mx.compressed_operations.transpose_genotype_matrix(plink, snps, indiv)
+    f = mx.read_plink.calc_freq(plink, snps, indiv)
+    return dict(torch=torch, mx=mx, dev=dev, plink=plink, plink_t=plink_t, f=f, dg=mx.dgemm_compressed, snps=snps, indiv=indiv, n=n)
+
+
+def _make_object(S, shards, centered):
+    dg = S["dg"]
+    dg.set_options(use_gpu=True, not_center=not centered, verbose=0)
+    old = os.environ.get("MIRACULIX_NUM_GPUS")
+    try:
+        if shards > 1:
+            os.environ["MIRACULIX_NUM_GPUS"] = str(shards)
+        else:
+            os.environ.pop("MIRACULIX_NUM_GPUS", None)
+        obj = dg.init_compressed(S["plink"], S["plink_t"], S["snps"], S["indiv"], S["f"], S["n"])
+    finally:
+        if old is None:
+            os.environ.pop("MIRACULIX_NUM_GPUS", None)
+        else:
+            os.environ["MIRACULIX_NUM_GPUS"] = old
+    assert dg.num_shards(obj) == shards
+    return obj
+
+
+def config5_full_leg(torch, mx, L, dev, snps=2_000_000, indiv=100_000, shards=8, iters=20):
+    """BASELINE config 5 at its FULL extent on one GPU: 2M SNPs x 100k individuals (2 x 50 GB packed), the GBLUP / CG loop of the reference's
+    examples/iterative_solver/grm_solve_cg.jl:74-84,108-134 -- `iters` iterations of (Zc Zc^T + lambda I) x = b, one mxa_gram_matvec each --
+    (i) on the object cut into 8 SNP shards behind the plain symbols (MIRACULIX_NUM_GPUS=8: the partition, staging, per-shard products and the
+    fixed-order reduction of the 8-GPU run, here with all shards on one device) and (ii) on one plain object.  Checks: sampled rows of both
+    products against the long-double dense oracle, the residual the loop reports against a separately computed one, bitwise repeatability,
+    and sharded == single object bit for bit on an integer-valued vector (uncentred: every partial sum is an exact integer)."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    from grm_solve_cg import cg
+    S = _stage_full(torch, mx, dev, snps, indiv, 1, 48, shards)
+    dg = S["dg"]
+    sample = extract_sample(torch, S, nsample=32, seed=5)
+    res = {"workload": f"{snps} SNPs x {indiv} indiv (config 5 at full extent, {2 * snps * ((indiv + 3) // 4) / 1e9:.0f} GB packed in two orientations), n=1, centred, "
+                       f"{iters} CG iterations, one mxa_gram_matvec each"}
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    b = torch.randn((1, indiv), dtype=torch.float64, device=dev, generator=g).t()
+    vint = torch.randint(-3, 4, (1, indiv), device=dev, generator=g).to(torch.float64).t()
+    lam = float(snps)
+    sync = torch.cuda.synchronize
+    keep = {}
+    for name, nsh in ((f"{shards}_virtual_shards", shards), ("one_object", 1)):
+        obj = _make_object(S, nsh, centered=True)
+        if name == "one_object":        # the raw matrices are no longer needed: the samples are on the host
+            S["plink"] = S["plink_t"] = None
+            torch.cuda.empty_cache()
+        try:
+            class Op:
+                def gram(self, v):
+                    return dg.gram_matvec(obj, v, snps, indiv)
+            x0 = torch.zeros_like(b)
+            cg(Op(), b, x0, lam, max_iter=2, conv_crit=0.0, verbose=False)            # warm-up (workspace growth, first launches)
+            sync(); t0 = time.perf_counter()
+            crit = 1e-30                                                                 # never met: the loop runs all its iterations (config 5 asks for >= 20)
+            x, resid, it = cg(Op(), b, x0, lam, max_iter=iters, conv_crit=crit, verbose=False)
+            sync(); dt = time.perf_counter() - t0
+            v = x / torch.linalg.vector_norm(x)
+            out = torch.zeros_like(v)
+            dg.gram_matvec(obj, v, snps, indiv, out=out)
+            t_step = timed(lambda: dg.gram_matvec(obj, v, snps, indiv, out=out), sync, 5)
+            # the two products of the step on their own, under the checker
+            T = dg.dgemm_compressed_main(True, obj, v, snps, indiv)
+            N = dg.dgemm_compressed_main(False, obj, T, snps, indiv)
+            err_t = check_sample(torch, sample, 1, v, T, [0], 1)
+            err_n = check_sample(torch, sample, 0, T, N, [0], 1)
+            gram_vs_pair = float((out - N).abs().max() / N.abs().max())
+            Ax = dg.gram_matvec(obj, x, snps, indiv) + lam * x
+            bnorm = float(torch.linalg.vector_norm(b))
+            res_gap = abs(float(torch.linalg.vector_norm(b - Ax)) - resid) / bnorm
+            x2, resid2, _ = cg(Op(), b, x0, lam, max_iter=iters, conv_crit=crit, verbose=False)
+            repeat = bool(torch.equal(x, x2)) and resid == resid2
+            # integer-valued vector, uncentred: exact integers throughout -> independent of the partition
+            dg.set_options(use_gpu=True, not_center=True, verbose=0)
+            Ti = dg.dgemm_compressed_main(True, obj, vint, snps, indiv)
+            Ni = dg.dgemm_compressed_main(False, obj, Ti, snps, indiv)
+            Gi = dg.gram_matvec(obj, vint, snps, indiv)
+            dg.set_options(use_gpu=True, not_center=False, verbose=0)
+            keep[name] = (Ti, Ni, Gi)
+            bytes_step = 2.0 * snps * ((indiv + 3) // 4)
+            res[name] = {"ms_per_cg_iteration_incl_vector_ops": round(dt / (it + 1) * 1e3, 3), "ms_per_gram_matvec": round(t_step * 1e3, 3),
+                         "algorithmic_TB_per_s": round(bytes_step / t_step * 1e-12, 3), "frac_of_8_TBs_spec": round(bytes_step / t_step * 1e-12 / 8.0, 4),
+                         "cg_iterations": it, "cg_residual": resid, "rhs_norm": bnorm,
+                         "check": {"T_32_sampled_rows_vs_dense_oracle_max_rel_err": err_t, "N_32_sampled_rows_vs_dense_oracle_max_rel_err": err_n,
+                                   "gram_matvec_vs_T_then_N_max_rel_err": gram_vs_pair,
+                                   "residual_recomputed_minus_reported_over_rhs_norm": res_gap, "cg_residual_consistent_ok": bool(res_gap <= 1e-6 + 10 * resid / bnorm),
+                                   "cg_converging_ok": bool(resid < 1e-3 * bnorm), "cg_bitwise_repeatable": repeat, "checker_tolerance": 1e-11}}
+        finally:
+            dg.free_compressed(obj)
+            torch.cuda.empty_cache()
+    a, c = keep[f"{shards}_virtual_shards"], keep["one_object"]
+    res["check"] = {"sharded_equals_one_object_bitwise_on_integer_vector": bool(torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]) and torch.equal(a[2], c[2])),
+                    "integer_gram_equals_T_then_N_bitwise": bool(torch.equal(c[1], c[2]))}
+    S.clear(); keep.clear()
+    torch.cuda.empty_cache()
+    return res
+
+
+def config4_full_extent_leg(torch, mx, L, dev, snps=5_000_000, indiv=25_000, n=128, shards=8, reps=2):
+    """BASELINE config 4's FULL 5M-SNP extent (at a reduced individual count so that both orientations, 2 x 31 GB, fit one GPU), ncol = 128,
+    allele-frequency centred, cut into 8 SNP shards behind the plain symbols (MIRACULIX_NUM_GPUS=8: 625 000 SNPs per shard, as on the 8-GPU
+    node; here all shards on one device), 'N' (with the fixed-order reduction of the indiv x 128 partials) and 'T'.  Checks: sampled rows against
+    the centred long-double oracle, the centred adjoint identity, bitwise repeatability, and sharded == single object bit for bit on an
+    integer-valued B (uncentred)."""
+    S = _stage_full(torch, mx, dev, snps, indiv, n, 49, shards)
+    dg = S["dg"]
+    sample = extract_sample(torch, S, nsample=16, seed=6)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    Y = torch.randn((n, snps), dtype=torch.float64, device=dev, generator=g).t()
+    X = torch.randn((n, indiv), dtype=torch.float64, device=dev, generator=g).t()
+    Yi = torch.randint(-2, 3, (8, snps), device=dev, generator=g).to(torch.float64).t()      # 8 integer columns for the partition-independence check
+    Xi = torch.randint(-2, 3, (8, indiv), device=dev, generator=g).to(torch.float64).t()
+    CN = torch.zeros((n, indiv), dtype=torch.float64, device=dev).t()
+    CT = torch.zeros((n, snps), dtype=torch.float64, device=dev).t()
+    sync = torch.cuda.synchronize
+    res = {"workload": f"{snps} SNPs x {indiv} indiv (config 4's full SNP extent at reduced indiv, {2 * snps * ((indiv + 3) // 4) / 1e9:.0f} GB packed), ncol={n}, centred, "
+                       f"SNP-sharded into {shards} blocks behind dgemm_compressed"}
+    keep = {}
+    cols = [0, 31, 32, 127] if n >= 128 else [0, n - 1]
+    flops = 2.0 * snps * indiv * n
+    for name, nsh in ((f"{shards}_virtual_shards", shards), ("one_object", 1)):
+        obj = _make_object(S, nsh, centered=True)
+        if name == "one_object":
+            S["plink"] = S["plink_t"] = None
+            torch.cuda.empty_cache()
+        try:
+            r = {}
+            for tname, trans, B, C in (("N", False, Y, CN), ("T", True, X, CT)):
+                dg.dgemm_compressed_main(trans, obj, B, snps, indiv, out=C)
+                t = timed(lambda: dg.dgemm_compressed_main(trans, obj, B, snps, indiv, out=C), sync, reps)
+                r[tname] = {"ms_per_call": round(t * 1e3, 2), "TFLOPs_call": round(flops / t * 1e-12, 2), "frac_of_fp64_mfma_peak_call": round(flops / t * 1e-12 / FP64_MFMA_PEAK_TFLOPS, 4)}
+            err_n = check_sample(torch, sample, 0, Y, CN, cols, 1)
+            err_t = check_sample(torch, sample, 1, X, CT, cols, 1)
+            lhs, rhs = (X * CN).sum(dim=0), (CT * Y).sum(dim=0)
+            adj = float(((lhs - rhs).abs() / (X.abs() * CN.abs()).sum(dim=0)).max())
+            CN2 = dg.dgemm_compressed_main(False, obj, Y, snps, indiv)
+            rep = bool(torch.equal(CN2, CN))
+            del CN2
+            dg.set_options(use_gpu=True, not_center=True, verbose=0)
+            keep[name] = (dg.dgemm_compressed_main(False, obj, Yi, snps, indiv), dg.dgemm_compressed_main(True, obj, Xi, snps, indiv))
+            dg.set_options(use_gpu=True, not_center=False, verbose=0)
+            r["check"] = {"N_16_sampled_rows_vs_dense_oracle_max_rel_err": err_n, "T_16_sampled_rows_vs_dense_oracle_max_rel_err": err_t,
+                          "centred_adjoint_identity_max_rel_err": adj, "N_bitwise_repeatable": rep, "checker_tolerance": 1e-11}
+            res[name] = r
+        finally:
+            dg.free_compressed(obj)
+            torch.cuda.empty_cache()
+    a, c = keep[f"{shards}_virtual_shards"], keep["one_object"]
+    res["check"] = {"sharded_equals_one_object_bitwise_on_integer_B": bool(torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]))}
+    S.clear(); keep.clear()
+    del Y, X, CN, CT, Yi, Xi
+    torch.cuda.empty_cache()
+    return res
 
 
 # ====================================================================================================== the headline workload
@@ -820,7 +1009,9 @@ def main():
         r = lambda x, q: x if sc == 1.0 else max(q, int(x * sc) // q * q)
         legs = (("config5_cg_step", lambda: config5_cg_step_leg(torch, mx, L, W.device, r(250_000, 4), r(100_000, 4))),
                 ("config4_shard", lambda: config4_shard_leg(torch, mx, L, W.device, r(625_000, 4), r(200_000, 4))),
-                ("config3_crossprod", lambda: config3_crossprod_leg(torch, mx, L, W.device, r(500_000, 4), r(100_000, 256))))
+                ("config3_crossprod", lambda: config3_crossprod_leg(torch, mx, L, W.device, r(500_000, 4), r(100_000, 256))),
+                ("config5_full_8_virtual_shards", lambda: config5_full_leg(torch, mx, L, W.device, r(2_000_000, 32), r(100_000, 4))),
+                ("config4_full_extent_8_virtual_shards", lambda: config4_full_extent_leg(torch, mx, L, W.device, r(5_000_000, 32), r(25_000, 4))))
         for name, fn in legs:
             t_leg = time.perf_counter()
             try:
@@ -829,7 +1020,7 @@ def main():
             except Exception as ex:   # a leg must not take the headline number down: it reports its failure instead
                 out[name] = {"failed": f"{type(ex).__name__}: {ex}"}
         dg.set_options(use_gpu=True, not_center=not args.centered, verbose=0)
-        bad = [k for k in ("config5_cg_step", "config4_shard", "config3_crossprod") if not leg_checks_ok(out[k])]
+        bad = [k for k, _ in legs if not leg_checks_ok(out[k])]
         if bad:
             raise SystemExit(f"bench.py: parity check failed in {bad}: {json.dumps({k: out[k] for k in bad})}")
     if W.rank == 0:
@@ -850,7 +1041,7 @@ def leg_checks_ok(leg):
                 walk(v)
             elif k.endswith("max_rel_err"):
                 ok &= v <= 1e-11
-            elif k.startswith("four_256") or k.startswith("first_panel") or k.startswith("gram_matvec_bitwise"):
+            elif k.startswith("four_256") or k.startswith("first_panel") or "bitwise" in k or k.endswith("_ok"):
                 ok &= bool(v)
     walk(leg)
     return ok

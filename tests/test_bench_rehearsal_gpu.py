@@ -63,6 +63,13 @@ def test_bench_single_gpu_line_is_complete():
     assert c4["check"]["N_16_sampled_rows_vs_dense_oracle_max_rel_err"] <= 1e-11 and c4["check"]["T_16_sampled_rows_vs_dense_oracle_max_rel_err"] <= 1e-11
     for eng in ("k_crossprod_f4 (FP4 MFMA, default)", "k_crossprod_i8 (int8 MFMA)"):
         assert c3[eng]["kernel_ms"] > 0 and c3[eng]["check"]["four_256x256_tiles_and_mirrors_bit_exact_vs_int32_oracle"] is True
+    # configs 5 and 4 at their "full extent" legs (8 virtual shards + one object), here at 2 % of the sizes
+    c5f, c4f = out["config5_full_8_virtual_shards"], out["config4_full_extent_8_virtual_shards"]
+    assert c5f["check"]["sharded_equals_one_object_bitwise_on_integer_vector"] is True and c4f["check"]["sharded_equals_one_object_bitwise_on_integer_B"] is True
+    for name in ("8_virtual_shards", "one_object"):
+        assert c5f[name]["ms_per_gram_matvec"] > 0 and c5f[name]["check"]["cg_bitwise_repeatable"] is True
+        assert c5f[name]["check"]["T_32_sampled_rows_vs_dense_oracle_max_rel_err"] <= 1e-11 and c5f[name]["check"]["N_32_sampled_rows_vs_dense_oracle_max_rel_err"] <= 1e-11
+        assert c4f[name]["N"]["ms_per_call"] > 0 and c4f[name]["check"]["N_16_sampled_rows_vs_dense_oracle_max_rel_err"] <= 1e-11
 
 
 def test_bench_inprocess_two_shards_behind_the_c_abi():
