@@ -2,7 +2,7 @@
 """bench.py -- headline benchmark: effective GFLOP/s of dgemm_compressed (2-bit SNP x fp64) on N MI355X.
 
 Structure: setup_process / stage_headline / make_step_and_sync / run_timed (the timed region and `value`), then legs that never feed
-`value`: per_rank (launcher) or per_shard + rccl_reduction + hub_operands_on_first_device (in-process N > 1), opt_in_engine,
+`value`: per_rank (launcher) or per_shard + rccl_reduction / p2p_reduction (the one --reduce did not select) + hub_operands_on_first_device (in-process N > 1), opt_in_engine,
 abi_end_to_end, cpu_baseline + check, and at N = 1 the other BASELINE configs under their own checkers: config5_cg_step,
 config4_shard, config3_crossprod (reference harness shape: utils/benchmark/benchmark.f90:182-254).
 
@@ -114,11 +114,15 @@ def physical_cores():
 def cpu_baseline_and_check(torch, mx, plink_dev, freq_dev, snps, indiv, n, B_T, C_T, B_N, C_N, plink_t_rows_fn):
     """CPU 5codes baseline on a bounded sample of the SAME workload -- the first SAMPLE_SNPS SNPs of the bench matrix, all
     individuals, same n, one 'N' + one 'T' multiply -- timed on this host's physical cores (reference harness
-    utils/benchmark/benchmark.f90:185-209).  kind 'reference' when oracle/_ref (the reference's own library built from its
-    sources) travelled with the repo, else 'port' (oracle/oracle.c, bit-exact with it on the pinned fixtures).
+    utils/benchmark/benchmark.f90:185-209).
+    `cpu_baseline` is ALWAYS the tracked port (oracle/oracle.c: oracle5_dgemm, the from-scratch restatement of the reference's 5codes
+    engine, bit-exact with the reference library on the pinned fixtures): a clean checkout reproduces it.  When
+    oracle/_ref -- the reference's own library, compiled from /root/reference in the build container, git-ignored but carried along by
+    gpurun pushes -- happens to be present, it is timed too and reported under the separate key `cpu_baseline_reference_build`.
     The same leg is the in-run parity check against the checker: rows [0, SAMPLE_SNPS) of the GPU's 'T' result are compared with
-    the CPU library's own output on the sample (same packed rows, same B), and 64 sampled individuals of the GPU's 'N' result with
-    the long-double dense oracle.  Everything under oracle/ is used here as baseline / checker only."""
+    the CPU engine's own output on the sample (same packed rows, same B), and 64 sampled individuals of the GPU's 'N' result with
+    the long-double dense oracle.  Everything under oracle/ is used here as baseline / checker only.
+    Returns (cpu_baseline, cpu_baseline_reference_build or None, check)."""
     import numpy as np
     from _util import Oracle, have_reference, run_reference
     sample = min(snps, 100_000)
@@ -128,29 +132,37 @@ def cpu_baseline_and_check(torch, mx, plink_dev, freq_dev, snps, indiv, n, B_T, 
     prob = dict(snps=sample, indiv=indiv, plink=np.ascontiguousarray(plink), plink_t=None, f=f)
     Bt = np.ascontiguousarray(B_T.t().cpu().numpy())                                   # n x indiv
     Bn = np.ascontiguousarray(B_N[:sample].t().cpu().numpy())                          # n x sample
-    times, Ct_cpu = {}, None
     o = Oracle()
-    if have_reference():
-        kind = "reference"
-        _, times[0] = run_reference(prob, 0, Bn, centered=False, variant=256, cores=cores, reps=2)
-        Ct_cpu, times[1] = run_reference(prob, 1, Bt, centered=False, variant=256, cores=cores, reps=2)
-    else:
-        kind = "port"
-        os.environ["OMP_NUM_THREADS"] = str(cores)
-        h = o.five_create(prob, cores)
-        for trans, B in ((0, Bn), (1, Bt)):
-            best = 1e30
-            for _ in range(2):
-                t0 = time.perf_counter()
-                C = o.five_dgemm(h, trans, prob, B, 0)
-                best = min(best, time.perf_counter() - t0)
-            times[trans] = best
-            if trans:
-                Ct_cpu = C
-        o.five_free(h)
     flops = 2.0 * sample * indiv * n
-    gflops = 2 * flops / (times[0] + times[1]) * 1e-9
-    # parity: GPU 'T' rows of the sample against the CPU library
+    what = f"first {sample} SNPs of the bench matrix x {indiv} indiv, n={n}, one 'N' + one 'T' multiply, uncentred, best of 2"
+    # the tracked port
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    times, Ct_cpu = {}, None
+    h = o.five_create(prob, cores)
+    for trans, B in ((0, Bn), (1, Bt)):
+        best = 1e30
+        for _ in range(2):
+            t0 = time.perf_counter()
+            C = o.five_dgemm(h, trans, prob, B, 0)
+            best = min(best, time.perf_counter() - t0)
+        times[trans] = best
+        if trans:
+            Ct_cpu = C
+    o.five_free(h)
+    base = {"value": round(2 * flops / (times[0] + times[1]) * 1e-9, 2), "unit": "GFLOP/s", "cores": cores, "cores_counted_as": how, "kind": "port",
+            "engine": "oracle/oracle.c oracle5_dgemm: 5-codes tables + lookup-add, OpenMP over the cores above (tracked source, built by __graft_entry__.build())",
+            "sample": what + f" (N {times[0]:.3f}s, T {times[1]:.3f}s)"}
+    ref_build = None
+    if have_reference():
+        rt = {}
+        _, rt[0] = run_reference(prob, 0, Bn, centered=False, variant=256, cores=cores, reps=2)
+        Ct_ref, rt[1] = run_reference(prob, 1, Bt, centered=False, variant=256, cores=cores, reps=2)
+        ref_build = {"value": round(2 * flops / (rt[0] + rt[1]) * 1e-9, 2), "unit": "GFLOP/s", "cores": cores, "kind": "reference",
+                     "engine": "oracle/_ref/libmiraculix_ref.so: the reference's own CPU library compiled from /root/reference by oracle/Makefile.ref (AVX2 variant 256); "
+                               "git-ignored build output that travelled with this push -- absent from a clean checkout",
+                     "sample": what + f" (N {rt[0]:.3f}s, T {rt[1]:.3f}s)",
+                     "port_T_output_bitwise_equal_to_reference_build": bool(np.array_equal(Ct_ref[:, :sample], Ct_cpu[:, :sample]))}
+    # parity: GPU 'T' rows of the sample against the CPU engine
     got = C_T[:sample].t().cpu().numpy()
     err_t = float(np.abs(got - Ct_cpu[:, :sample]).max() / np.abs(Ct_cpu[:, :sample]).max())
     # parity: 64 sampled individuals of the GPU 'N' result against the dense long-double oracle on their extracted rows
@@ -162,11 +174,8 @@ def cpu_baseline_and_check(torch, mx, plink_dev, freq_dev, snps, indiv, n, B_T, 
     ref = o.dgemm_dense(0, dict(snps=snps, indiv=64, plink=sub_plink, plink_t=rows, f=np.zeros(snps)), np.ascontiguousarray(B_N[:, cols].t().cpu().numpy()), 0)
     got_n = C_N[torch.from_numpy(ii).to(C_N.device)][:, cols].t().cpu().numpy()
     err_n = float(np.abs(got_n - ref).max() / np.abs(ref).max())
-    base = {"value": round(gflops, 2), "unit": "GFLOP/s", "cores": cores, "cores_counted_as": how, "kind": kind,
-            "sample": f"first {sample} SNPs of the bench matrix x {indiv} indiv, n={n}, one 'N' + one 'T' multiply, uncentred, AVX2 variant 256, "
-                      f"best of 2 (N {times[0]:.3f}s, T {times[1]:.3f}s)"}
     check = {"gpu_T_rows_vs_cpu_library_max_rel_err": err_t, "gpu_N_64_sampled_rows_vs_dense_oracle_max_rel_err": err_n, "checker_tolerance": 1e-11}
-    return base, check
+    return base, ref_build, check
 
 
 def pmc_child(args):
@@ -780,6 +789,22 @@ def per_shard_report(W, mx, args, flops_shard):
     return rep, info
 
 
+def predicted_step_ms(n_gpus, snps, indiv, n, slowest_avg_kgemm_ms):
+    """What a step SHOULD take on N physical GPUs if the design holds, so that a measured scaling curve can be judged
+    against it: the 'N' and the 'T' product of the slowest shard back to back, with the reduction of the indiv x n partials (p2p pushes + one
+    addition kernel, or the RCCL collective) hidden behind the collective-free 'T' product of the same step.
+      from_this_run    : 2 x the slowest shard's average k_gemm launch measured in THIS run + 0.3 ms for the small kernels around the two
+                         launches (pack_B, colexp, finish: 0.13-0.16 ms per call, profiles/r03_bench_n1_kernel_stats.csv)
+      single_gpu_table : the same sum measured on ONE MI355X at the per-shard shape of the default workload (1M x 50k x 32; round 3:
+                         1 GPU 88.6 ms, 2 x 500k 45.0, 4 x 250k 23.1, 8 x 125k 11.6), None for other workloads
+      if_reduction_not_hidden : + 8 indiv n bytes over one xGMI link at ~50 GB/s effective + the addition kernel"""
+    table = {1: 88.6, 2: 45.0, 4: 23.1, 8: 11.6} if (snps, indiv, n) == (1_000_000, 50_000, 32) else {}
+    this = 2.0 * slowest_avg_kgemm_ms + 0.3
+    exposed = 8.0 * indiv * n / 50e9 * 1e3 + 0.06
+    return {"from_this_run": round(this, 3), "single_gpu_table": table.get(n_gpus), "if_reduction_not_hidden": round(this + exposed, 3),
+            "model": "2 x slowest shard's avg k_gemm launch + 0.3 ms of small kernels; reduction hidden behind the 'T' product (DESIGN.md section 6)"}
+
+
 def opt_in_engine_leg(W, L, args, step, sync, engine, flops_step, description):
     """the headline steps once more under another multiply engine: fp64-equivalent rate, kernel time, executed int8 rate, and the
     column-wise difference from the fp64 engine's results (which the caller has checked against the oracle)"""
@@ -817,6 +842,10 @@ def main():
     ap.add_argument("--indiv", type=int, default=50_000)
     ap.add_argument("--ncol", type=int, default=32)
     ap.add_argument("--centered", type=int, default=0)
+    ap.add_argument("--reduce", choices=["p2p", "rccl"], default="p2p",
+                    help="in-process N > 1 (no launcher): the reduction of the 'N' partials that is TIMED -- p2p = peer-to-peer pushes + one fixed-order addition "
+                         "kernel (default, bitwise reproducible), rccl = ncclReduce over xGMI (the collective north_star names); the other one is reported beside it. "
+                         "Under the torch.distributed launcher the reduction is always RCCL's all-reduce.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-engine", action="store_true", help="skip the extra (untimed, informational) pass with the opt-in int8 engine")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic")
@@ -846,6 +875,19 @@ def main():
 
     # ---- the timed region: W untimed steps, then exactly K steps between barrier + synchronize on both sides
     step, sync = make_step_and_sync(W, mx)
+    reduction = "none (one GPU)"
+    if dist.is_initialized():
+        reduction = "rccl all-reduce (torch.distributed, one process per GPU)" if os.environ.get("MXA_BENCH_BACKEND", "nccl") == "nccl" else "gloo all-reduce (rehearsal)"
+    elif W.inprocess:
+        reduction = "p2p"
+        if args.reduce == "rccl":
+            try:
+                if dg.multi_set_reduction(W.eng.obj, "rccl"):
+                    reduction = "rccl"
+                else:
+                    reduction = "p2p (--reduce rccl not applicable: several shards share a device, RCCL needs one rank per device)"
+            except RuntimeError as ex:
+                reduction = f"p2p (--reduce rccl failed: {ex})"
     for _ in range(args.warmup):
         step()
     sync()
@@ -875,21 +917,23 @@ def main():
     extra_multi = None
     if W.inprocess:
         extra_multi = {}
+        other = "p2p" if reduction == "rccl" else "rccl"
+        key = other + "_reduction"
         try:   # a failure of this optional leg is reported in its key; it must not take the headline number down
-            if dg.multi_set_reduction(W.eng.obj, "rccl"):
+            if dg.multi_set_reduction(W.eng.obj, other):
                 L.mxa_multi_reset_profile(W.eng.obj)
                 dt_r = run_timed(W, step, sync, 1, args.steps)
                 rep_r, info_r = per_shard_report(W, mx, args, flops_launch)
                 adjoint_check(W)
-                extra_multi["rccl_reduction"] = {"value": round(flops_step * args.steps / dt_r * 1e-9, 1), "unit": "GFLOP/s", "ms_per_step": round(dt_r / args.steps * 1e3, 3),
-                                                 "rccl_vs_p2p_max_rel_diff": info_r["rccl_vs_p2p_max_rel_diff"], "rccl_checked": bool(info_r["rccl_checked"]),
-                                                 "avg_ncclReduce_ms_on_root_rank": rep_r["shards"][0]["avg_push_ms"]}
+                extra_multi[key] = {"value": round(flops_step * args.steps / dt_r * 1e-9, 1), "unit": "GFLOP/s", "ms_per_step": round(dt_r / args.steps * 1e3, 3),
+                                    "rccl_vs_p2p_max_rel_diff": info_r["rccl_vs_p2p_max_rel_diff"], "rccl_checked": bool(info_r["rccl_checked"]),
+                                    "avg_push_or_ncclReduce_ms_on_root_rank": rep_r["shards"][0]["avg_push_ms"]}
             else:
-                extra_multi["rccl_reduction"] = {"skipped": "several shards share a device (RCCL needs one rank per device)"}
+                extra_multi[key] = {"skipped": "several shards share a device (RCCL needs one rank per device)"}
         except RuntimeError as ex:
-            extra_multi["rccl_reduction"] = {"failed": str(ex)}
+            extra_multi[key] = {"failed": str(ex)}
         try:
-            dg.multi_set_reduction(W.eng.obj, "p2p")
+            dg.multi_set_reduction(W.eng.obj, "rccl" if reduction == "rccl" else "p2p")
         except RuntimeError:
             pass
         hub_step, hub_sync = make_step_and_sync(W, mx, hub=True)
@@ -957,6 +1001,27 @@ def main():
                "mean_ms_per_step": round(sum(ts) / len(ts) * 1e3, 3), "min_ms_per_step": round(min(ts) * 1e3, 3),
                "host_bytes_per_step": int(8 * 2 * (snps + indiv) * n), "bitwise_equal_to_device_resident_results": same}
         del hB_N, hB_T, hC_N, hC_T, dev_T
+        if W.keep_raw:
+            # row a2 of the path: plink2compressed itself with HOST matrices, as the reference harness times it (utils/benchmark/benchmark.f90:187):
+            # both orientations over PCIe (the reference's call shape for its GPU path), and the SNP-major matrix alone with the individual-major copy
+            # built on the device (plink_transposed = NULL / = plink, the call shape of its CPU path, benchmark.f90:185).  Never part of `value`.
+            hp, hpt, hf = W.plink.cpu().numpy(), W.plink_t.cpu().numpy(), W.freq.cpu().numpy()
+            stage = {}
+            for key, second in (("two_host_pointers", hpt), ("snp_major_only_device_transpose", None)):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                o2 = dg.init_compressed(hp, second, snps, indiv, hf, n)
+                stage[key] = time.perf_counter() - t1
+                C2 = dg.dgemm_compressed_main(True, o2, W.B_T, snps, indiv)
+                stage[key + "_same"] = bool(torch.equal(C2, W.C_T))
+                del C2
+                dg.free_compressed(o2)
+            abi["plink2compressed_host_staging_s"] = round(stage["two_host_pointers"], 3)
+            abi["plink2compressed_host_staging_GB"] = round((hp.nbytes + hpt.nbytes) / 1e9, 2)
+            abi["plink2compressed_snp_major_only_s"] = round(stage["snp_major_only_device_transpose"], 3)
+            abi["plink2compressed_snp_major_only_GB"] = round(hp.nbytes / 1e9, 2)
+            abi["staged_objects_reproduce_the_T_result_bitwise"] = stage["two_host_pointers_same"] and stage["snp_major_only_device_transpose_same"]
+            del hp, hpt, hf
 
     out = None
     if W.rank == 0:
@@ -964,7 +1029,7 @@ def main():
             "metric": "effective GFLOP/s for dgemm_compressed (2-bit SNP x fp64)",
             "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": W.n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic", "reduction": reduction,
             "config": {"workload": f"{snps} SNPs x {indiv} indiv, ncol={n}, dgemm_compressed 'N' + 'T' per step, "
                                    f"{'centred' if args.centered else 'uncentred'}, SNP-sharded over {W.n_gpus} GPU(s)"
                                    + (" inside one process behind the C ABI (MIRACULIX_NUM_GPUS), operands per shard on the shards' devices" if W.inprocess else ""),
@@ -977,6 +1042,9 @@ def main():
                          "algorithmic_bytes_per_launch_GB": round((W.snps_loc / W.n_shards * ((indiv + 3) // 4) + 8.0 * (W.snps_loc / W.n_shards + indiv) * n) / 1e9, 3),
                          "kernel": "k_gemm<8,8> (v_mfma_f64_4x4x4_4b_f64)", "launches": launches, "avg_launch_ms": round(avg_ms, 3)},
         }
+        if W.n_gpus > 1:
+            slowest = max(per_rank["avg_k_gemm_launch_ms"]) if per_rank is not None else avg_ms
+            out["predicted_ms_per_step_from_per_shard"] = predicted_step_ms(W.n_gpus, snps, indiv, n, slowest)
         if per_rank is not None:
             out["per_rank"] = per_rank
         if per_shard is not None:
@@ -991,8 +1059,10 @@ def main():
         if W.keep_raw:   # CPU baseline + parity against the checker: rank 0 at N = 1 only
             def rows_of_plink_t(ii):
                 return W.plink_t[torch.from_numpy(ii).to(W.device)].cpu().numpy()
-            base, chk = cpu_baseline_and_check(torch, mx, W.plink, W.freq, snps, indiv, n, W.B_T, W.C_T, W.B_N, W.C_N, rows_of_plink_t)
+            base, ref_build, chk = cpu_baseline_and_check(torch, mx, W.plink, W.freq, snps, indiv, n, W.B_T, W.C_T, W.B_N, W.C_N, rows_of_plink_t)
             out["cpu_baseline"] = base
+            if ref_build is not None:
+                out["cpu_baseline_reference_build"] = ref_build
             out["check"].update(chk)
             if not (chk["gpu_T_rows_vs_cpu_library_max_rel_err"] <= 1e-11 and chk["gpu_N_64_sampled_rows_vs_dense_oracle_max_rel_err"] <= 1e-11):
                 raise SystemExit(f"bench.py: GPU results differ from the checker ({chk}): no number reported")

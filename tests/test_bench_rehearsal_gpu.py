@@ -22,6 +22,7 @@ def test_bench_two_ranks_one_gpu_gloo():
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-1500:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "strong" and out["dtype"] == "f64"
+    assert "all-reduce" in out["reduction"] and out["predicted_ms_per_step_from_per_shard"]["from_this_run"] > 0
     assert out["unit"] == "GFLOP/s" and out["value"] > 0 and out["higher_is_better"] is True
     assert out["check"]["adjoint_identity_max_rel_err"] <= 1e-10          # 'N' (all-reduced over the ranks) against 'T' (sharded)
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
@@ -49,9 +50,12 @@ def test_bench_single_gpu_line_is_complete():
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert (isinstance(rf["traffic"], float) and rf["traffic"] > 0 and rf["traffic_detail"]["launches"] == 2) or "skipped" in rf["traffic_detail"]
     cb = out["cpu_baseline"]
-    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and "cores_counted_as" in cb
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "cores_counted_as" in cb          # always the tracked port: reproducible from a clean checkout
+    if "cpu_baseline_reference_build" in out:                                                                    # only where oracle/_ref travelled with the push
+        assert out["cpu_baseline_reference_build"]["kind"] == "reference" and out["cpu_baseline_reference_build"]["port_T_output_bitwise_equal_to_reference_build"] is True
     ab = out["abi_end_to_end"]
     assert ab["bitwise_equal_to_device_resident_results"] is True and ab["max_GFLOPs"] >= ab["mean_GFLOPs"] > 0
+    assert ab["plink2compressed_host_staging_s"] > 0 and ab["plink2compressed_snp_major_only_s"] > 0 and ab["staged_objects_reproduce_the_T_result_bitwise"] is True
     ck = out["check"]
     assert ck["gpu_T_rows_vs_cpu_library_max_rel_err"] <= 1e-11 and ck["gpu_N_64_sampled_rows_vs_dense_oracle_max_rel_err"] <= 1e-11
     # the legs for BASELINE configs 3, 4 (shard) and 5 (shard), here at 2 % of their sizes: each carries its rates, its roofline fraction and its checks
@@ -87,5 +91,6 @@ def test_bench_inprocess_two_shards_behind_the_c_abi():
         assert s["k_gemm_launches"] == 4 and s["avg_k_gemm_ms"] > 0 and s["operand_copies_in"] == 0 and s["result_copies_out"] == 0
         assert s["peer_access_to_root"] == -1 and s["partial_pushes"] == 0      # one device: nothing to push
     assert "skipped" in out["rccl_reduction"]
+    assert out["reduction"] == "p2p" and out["predicted_ms_per_step_from_per_shard"]["from_this_run"] > 0
     hub = out["hub_operands_on_first_device"]
     assert hub["value"] > 0 and len(hub["avg_copy_in_ms_per_shard"]) == 2
