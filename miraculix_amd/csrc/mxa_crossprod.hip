@@ -14,7 +14,9 @@
 #include "../../include/miraculix_amd.h"
 #include "mxa_internal.h"
 #include "mxa_queue.h"
+#include "mxa_hostmem.h"
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <algorithm>
 #include <cstdio>
@@ -727,16 +729,28 @@ static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch
   constexpr int kCopiers = 4;
   XStream cs[kCopiers];
   for (auto &c : cs) if (c.create(hipStreamNonBlocking)) return 1;
+  // where the host time of a call goes, per copier: waiting for a slab to be computed, and inside the copies; the slowest single copy with its
+  // slab (a stall shows up there).  Printed under PRINT_LEVEL / print_details (debug_info) together with the prefault of the destination.
+  struct CopierLog { double wait_s = 0, copy_s = 0, worst_s = 0; int worst_slab = -1; size_t bytes = 0; };
+  CopierLog clog[kCopiers];
+  const auto t_call = std::chrono::steady_clock::now();
+  auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
   auto copy_loop = [&](int t) {
     if (hipSetDevice(dev) != hipSuccess) { copy_err = 1; return; }
     for (int c = 0; c < nchunks; c++) {
+      const auto tw = std::chrono::steady_clock::now();
       while (launched.load() <= c) { if (abort_copy.load()) return; std::this_thread::yield(); }
       if (hipEventSynchronize(ev[c].e) != hipSuccess) { copy_err = 1; return; }
+      clog[t].wait_s += since(tw);
       const long col0 = (long)c * rows_per_chunk * kXT, col1 = std::min<long>(rows, (long)(c + 1) * rows_per_chunk * kXT);
       const long w = col1 - col0, a = col0 + w * t / kCopiers, b = col0 + w * (t + 1) / kCopiers;
       if (b <= a) continue;
       const size_t off = (size_t)a * rows, cnt = (size_t)(b - a) * rows;
+      const auto tc = std::chrono::steady_clock::now();
       if (hipMemcpyAsync(h_ans + off, d_ans + off, cnt * sizeof(double), hipMemcpyDeviceToHost, cs[t].s) != hipSuccess || hipStreamSynchronize(cs[t].s) != hipSuccess) { copy_err = 1; return; }
+      const double dt = since(tc);
+      clog[t].copy_s += dt; clog[t].bytes += cnt * sizeof(double);
+      if (dt > clog[t].worst_s) { clog[t].worst_s = dt; clog[t].worst_slab = c; }
     }
   };
   std::vector<std::thread> copiers;
@@ -750,8 +764,13 @@ static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch
   }
   if (rc) abort_copy = true;
   if (!rc && hipEventRecord(e1.e, s) != hipSuccess) rc = 1;
+  const double t_launched = since(t_call);
   for (auto &t : copiers) t.join();
   if (hipStreamSynchronize(s) != hipSuccess) rc = 1;
+  for (int t = 0; t < kCopiers; t++)
+    debug_info("crossproduct host result: copier %d waited %.3f s for slabs, copied %.2f GB in %.3f s (%.1f GB/s), slowest single copy %.3f s (slab %d of %d)", t, clog[t].wait_s,
+               clog[t].bytes * 1e-9, clog[t].copy_s, clog[t].copy_s > 0 ? clog[t].bytes * 1e-9 / clog[t].copy_s : 0.0, clog[t].worst_s, clog[t].worst_slab, nchunks);
+  debug_info("crossproduct host result: %d slab launches enqueued after %.3f s, all copies done after %.3f s", nchunks, t_launched, since(t_call));
   if (!rc && !copy_err.load()) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e0.e, e1.e) == hipSuccess) { profile().launches += 1; profile().total_ms += ms; }
@@ -941,6 +960,18 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
   MXA_HIP(hipMemGetInfo(&free_b, &total_b));
   const size_t need = xbytes + (out_dev ? 0 : abytes) + (in_dev ? 0 : std::min<size_t>((size_t)rows * row_bytes, (size_t)256 << 20));
   if (need > free_b) { set_error(12, "snp_multiply_gpu: not enough device memory: required %zu GB, free %zu GB", need >> 30, free_b >> 30); return 1; }
+  // a host result in fresh memory (crossproduct.jl:56 `M = zeros(...)`): its pages are populated in the background from now on -- during the
+  // staging of X and the kernel -- so that the copies at the end do not pay the first-touch faults (mxa_hostmem.h).  Joined when this returns.
+  HostPrefault prefault;
+  if (!out_dev) prefault.start(ans, abytes);
+  struct PrefaultReport {
+    HostPrefault &p;
+    ~PrefaultReport() {
+      p.join();
+      if (p.threads()) debug_info("host result: %.2f GB of destination pages populated in the background by %d threads in %.3f s%s", p.populated() * 1e-9, p.threads(), p.seconds(),
+                                  p.unsupported() ? " (MADV_POPULATE_WRITE not supported by this kernel: first-touch faults stay in the copies)" : "");
+    }
+  } prefault_report{prefault};
   XStream st;
   if (st.create(hipStreamDefault)) return 1;   // blocking: ordered against the caller's default-stream work
   hipStream_t s = st.s;
