@@ -544,6 +544,7 @@ struct XBuf {
   void *p = nullptr;
   ~XBuf() { if (p) (void)hipFree(p); }
   int alloc(size_t bytes) { MXA_HIP(hipMalloc(&p, bytes ? bytes : 1)); return 0; }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; } }
 };
 }  // namespace
 
@@ -779,6 +780,120 @@ static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch
   return 0;
 }
 
+// Host result WITHOUT a device copy of the whole matrix (round 4).  crossprod_to_host above needs the full n x n device buffer (80 GB at config 3):
+// hipMalloc of such a buffer takes anything from nothing to 4.6 s on this pool (the phase clock of crossprod_any, profiles/r04_crossprod_host_*.txt:
+// that -- not a copy scheme -- was round 3's unexplained "one call in 24 takes 4-5 s"), and the result could never exceed HBM.  Here the matrix is
+// produced column slab by column slab into a RING of three ~1 GiB device buffers: slab [c0, c1) is the column panel of mxa_snp_multiply_panel (every
+// tile (i, j >= i) that touches it: its direct image when i lies in the panel, its mirror image when j does), computed by the same kernels, and leaves
+// through the four copier threads while the next slab is computed.  Every off-diagonal tile is computed twice (once per image): twice the arithmetic of
+// the triangular launch -- taken only where the call is bound by the copy anyway (the caller compares the two estimates).
+static int crossprod_to_host_ring(const uint8_t *d_X, long k, long rows, size_t pitch, double *h_ans, hipStream_t s, bool f4, int post_kind, const XPost *post) {
+  const int nb = (int)((rows + kXT - 1) / kXT);
+  const int stages = (int)((k + kXStageK - 1) / kXStageK);
+  const long nslabs = (long)(pitch / kXStageBytes);
+  if (stages > nslabs) { set_error(4, "internal: crossproduct pitch too small"); return 1; }
+  const char *slab_env = getenv("MXA_XPROD_SLAB_MB");                                        // tests use small slabs
+  const long slab_bytes = (slab_env && atol(slab_env) > 0 ? atol(slab_env) : 1024L) << 20;
+  const int tcols = (int)std::max<long>(1, slab_bytes / (rows * 8 * kXT));                   // tile columns per slab
+  const int nchunks = (nb + tcols - 1) / tcols;
+  constexpr int kRing = 3, kCopiers = 4;
+  const size_t slot_elems = (size_t)rows * (size_t)std::min<long>(rows, (long)tcols * kXT);
+  XBuf ring[kRing], d_tiles, d_gang;
+  for (auto &r : ring) if (r.alloc(slot_elems * sizeof(double))) return 1;
+  static const int gang_order = [] { const char *e = getenv("MXA_XPROD_GANG_ORDER"); return e ? atoi(e) : 1; }();
+  // tile lists of all slabs, one after the other (uploaded once)
+  std::vector<int4> tiles;
+  std::vector<size_t> first((size_t)nchunks + 1, 0);
+  std::vector<char> chunk_xcd((size_t)nchunks, 0);
+  for (int c = 0; c < nchunks; c++) {
+    first[(size_t)c] = tiles.size();
+    const int t0 = c * tcols, t1 = std::min(nb, t0 + tcols);
+    std::vector<int4> part;
+    for (int i = 0; i < nb; i++)
+      for (int j = i; j < nb; j++) {
+        int flags = 0;
+        if (i >= t0 && i < t1) flags |= 1;                   // direct image M[J rows, I cols]: columns of tile i
+        if (j >= t0 && j < t1 && i != j) flags |= 2;         // mirror image M[I rows, J cols]: columns of tile j
+        if (flags) part.push_back(make_int4(i, j, flags, 0));
+      }
+    chunk_xcd[(size_t)c] = gang_order ? gang_order_tiles(part) : xcd_order_tiles(part, nb, 8);
+    tiles.insert(tiles.end(), part.begin(), part.end());
+  }
+  first[(size_t)nchunks] = tiles.size();
+  if (d_tiles.alloc(tiles.size() * sizeof(int4)) || d_gang.alloc(sizeof(int) * kGangCtrs)) return 1;
+  MXA_HIP(hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, s));
+  std::vector<XEvent> ev((size_t)nchunks);
+  int dev = 0;
+  MXA_HIP(hipGetDevice(&dev));
+  for (auto &e : ev) if (e.create(hipEventDisableTiming)) return 1;
+  XEvent e0, e1;
+  if (e0.create() || e1.create()) return 1;
+  std::atomic<int> launched{0}, copy_err{0};
+  std::atomic<bool> abort_copy{false};
+  std::vector<std::atomic<int>> copied((size_t)nchunks);
+  for (auto &c : copied) c.store(0);
+  XStream cs[kCopiers];
+  for (auto &c : cs) if (c.create(hipStreamNonBlocking)) return 1;
+  struct CopierLog { double wait_s = 0, copy_s = 0, worst_s = 0; int worst_slab = -1; size_t bytes = 0; };
+  CopierLog clog[kCopiers];
+  const auto t_call = std::chrono::steady_clock::now();
+  auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
+  auto copy_loop = [&](int t) {
+    if (hipSetDevice(dev) != hipSuccess) { copy_err = 1; abort_copy = true; return; }
+    for (int c = 0; c < nchunks; c++) {
+      const auto tw = std::chrono::steady_clock::now();
+      while (launched.load() <= c) { if (abort_copy.load()) return; std::this_thread::yield(); }
+      if (hipEventSynchronize(ev[c].e) != hipSuccess) { copy_err = 1; abort_copy = true; return; }
+      clog[t].wait_s += since(tw);
+      const long col0 = (long)c * tcols * kXT, col1 = std::min<long>(rows, (long)(c + 1) * tcols * kXT);
+      const long w = col1 - col0, a = w * t / kCopiers, b = w * (t + 1) / kCopiers;   // columns of the slab, relative
+      if (b > a) {
+        const double *src = (const double *)ring[c % kRing].p + (size_t)a * rows;
+        const size_t cnt = (size_t)(b - a) * rows;
+        const auto tc = std::chrono::steady_clock::now();
+        if (hipMemcpyAsync(h_ans + (size_t)(col0 + a) * rows, src, cnt * sizeof(double), hipMemcpyDeviceToHost, cs[t].s) != hipSuccess || hipStreamSynchronize(cs[t].s) != hipSuccess) { copy_err = 1; abort_copy = true; return; }
+        const double dt = since(tc);
+        clog[t].copy_s += dt; clog[t].bytes += cnt * sizeof(double);
+        if (dt > clog[t].worst_s) { clog[t].worst_s = dt; clog[t].worst_slab = c; }
+      }
+      copied[(size_t)c].fetch_add(1);
+    }
+  };
+  std::vector<std::thread> copiers;
+  for (int t = 0; t < kCopiers; t++) copiers.emplace_back(copy_loop, t);
+  int rc = 0;
+  double t_wait_slot = 0.0;
+  if (hipEventRecord(e0.e, s) != hipSuccess) rc = 1;
+  for (int c = 0; c < nchunks && !rc; c++) {
+    if (c >= kRing) {   // the slot is free once all copiers have taken slab c - kRing out of it
+      const auto tw = std::chrono::steady_clock::now();
+      while (copied[(size_t)(c - kRing)].load() < kCopiers) { if (abort_copy.load()) { rc = 1; break; } std::this_thread::yield(); }
+      t_wait_slot += since(tw);
+      if (rc) break;
+    }
+    const size_t cnt = first[(size_t)c + 1] - first[(size_t)c];
+    const long col0 = (long)c * tcols * kXT;
+    if (launch_tiles(f4, cnt, s, d_X, nslabs, stages, (const int4 *)d_tiles.p + first[(size_t)c], rows, (double *)ring[c % kRing].p, rows, col0, nullptr, post ? post_kind : 0, post ? *post : XPost(),
+                     chunk_xcd[(size_t)c] ? (int *)d_gang.p : nullptr) || hipEventRecord(ev[c].e, s) != hipSuccess) { rc = 1; break; }
+    launched.store(c + 1);
+  }
+  if (rc) abort_copy = true;
+  if (!rc && hipEventRecord(e1.e, s) != hipSuccess) rc = 1;
+  const double t_launched = since(t_call);
+  for (auto &t : copiers) t.join();
+  if (hipStreamSynchronize(s) != hipSuccess) rc = 1;
+  for (int t = 0; t < kCopiers; t++)
+    debug_info("crossproduct host result (ring of %d slabs): copier %d waited %.3f s for slabs, copied %.2f GB in %.3f s (%.1f GB/s), slowest single copy %.3f s (slab %d of %d)", kRing, t, clog[t].wait_s,
+               clog[t].bytes * 1e-9, clog[t].copy_s, clog[t].copy_s > 0 ? clog[t].bytes * 1e-9 / clog[t].copy_s : 0.0, clog[t].worst_s, clog[t].worst_slab, nchunks);
+  debug_info("crossproduct host result (ring): %d slab launches enqueued after %.3f s (%.3f s of it waiting for a free slot), all copies done after %.3f s", nchunks, t_launched, t_wait_slot, since(t_call));
+  if (!rc && !copy_err.load()) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0.e, e1.e) == hipSuccess) { std::lock_guard<std::mutex> lk(g_xprof_mutex); profile().launches += 1; profile().total_ms += ms; }
+  }
+  if (rc || copy_err.load()) { set_error(13, "snp_multiply_gpu: pipelined device-to-host copy of the result failed"); return 1; }
+  return 0;
+}
+
 // ---- GRM / LD post-processing on the device (reference: host BLAS in src/bindings/Julia/crossproduct.jl:83-152, maths docs/grm.md)
 // column sums of the symmetric n x n matrix, fixed-order tree per column
 __global__ void __launch_bounds__(256) k_sym_colsum(const double *__restrict__ M, long n, double *__restrict__ cs) {
@@ -872,7 +987,7 @@ __global__ void __launch_bounds__(256) k_x_colsum(const uint8_t *__restrict__ X,
 }
 // per row r: cs[r] += sum_s x[r][s] * t[s]  (WANT_CS;  = column sum r of M = X X^T)  and / or  dg[r] += sum_s x[r][s]^2  (WANT_DG; = M[r][r]).
 // Grid (row tiles, K chunks); thread = row of the tile, reading its 32-byte piece of every slab of the chunk (a wave reads 2 KiB contiguous);
-// the t values of a slab are broadcast from LDS.  Exact integers: int32 within a slab (128 * 3 * 3 rows < 2^31 for rows < 1.8 M), 64-bit atomics
+// the t values of a slab are broadcast from LDS.  Exact integers: 32 bits within a dword of 16 fields (rows < 29.8 M: kXFusedMaxRows), 64 bits beyond, 64-bit atomics
 // across the chunks (integer addition: order-independent).
 template <bool WANT_CS, bool WANT_DG>
 __global__ void __launch_bounds__(256) k_x_rowstats(const uint8_t *__restrict__ X, long nslabs, long slabs_per_chunk, const int *__restrict__ t,
@@ -891,12 +1006,15 @@ __global__ void __launch_bounds__(256) k_x_rowstats(const uint8_t *__restrict__ 
     const uint4 *pp = reinterpret_cast<const uint4 *>(X + ((size_t)rt * nslabs + (size_t)sl) * kTileBytes + (size_t)tid * kSlabBytes);
     const uint4 q0 = pp[0], q1 = pp[1];
     const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-    uint32_t part_cs = 0, part_dg = 0;
+    unsigned long long part_cs = 0;
+    uint32_t part_dg = 0;
 #pragma unroll
     for (int d = 0; d < 8; d++) {
-      if (WANT_CS) {
+      if (WANT_CS) {   // 32 bits hold the 16 fields of one dword (16 * 3 * 3 rows < 2^32 for rows < 29.8 M, guarded by the caller); across dwords 64 bits
+        uint32_t pd = 0;
 #pragma unroll
-        for (int f = 0; f < 16; f++) part_cs += ((w[d] >> (2 * f)) & 3u) * (uint32_t)tsh[d * 16 + f];
+        for (int f = 0; f < 16; f++) pd += ((w[d] >> (2 * f)) & 3u) * (uint32_t)tsh[d * 16 + f];
+        part_cs += pd;
       }
       if (WANT_DG) {   // x^2 = 1, 4, 9 for x = 1, 2, 3: three bit counts
         const uint32_t L = w[d] & 0x55555555u, H = (w[d] >> 1) & 0x55555555u;
@@ -958,7 +1076,10 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
   const size_t xbytes = (size_t)rows_pad * pitch, abytes = (size_t)ld * (size_t)(c_end - c_begin) * sizeof(double);
   size_t free_b = 0, total_b = 0;
   MXA_HIP(hipMemGetInfo(&free_b, &total_b));
-  const size_t need = xbytes + (out_dev ? 0 : abytes) + (in_dev ? 0 : std::min<size_t>((size_t)rows * row_bytes, (size_t)256 << 20));
+  // a whole-matrix host result can leave through a ring of three ~1 GiB slabs (crossprod_to_host_ring): the n x n device copy is then not needed
+  const bool ring_ok = !out_dev && c_begin == 0 && c_end == rows && !upper_only && ld == rows && !getenv("MXA_XPROD_NO_PIPELINE");
+  const size_t out_need = out_dev ? 0 : (ring_ok ? std::min<size_t>(abytes, (size_t)3400 << 20) : abytes);
+  const size_t need = xbytes + out_need + (in_dev ? 0 : std::min<size_t>((size_t)rows * row_bytes, (size_t)256 << 20));
   if (need > free_b) { set_error(12, "snp_multiply_gpu: not enough device memory: required %zu GB, free %zu GB", need >> 30, free_b >> 30); return 1; }
   // a host result in fresh memory (crossproduct.jl:56 `M = zeros(...)`): its pages are populated in the background from now on -- during the
   // staging of X and the kernel -- so that the copies at the end do not pay the first-touch faults (mxa_hostmem.h).  Joined when this returns.
@@ -972,11 +1093,24 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
                                   p.unsupported() ? " (MADV_POPULATE_WRITE not supported by this kernel: first-touch faults stay in the copies)" : "");
     }
   } prefault_report{prefault};
+  // phase clock of a call with a host operand (debug_info under PRINT_LEVEL): where the wall time of the plain ABI goes
+  struct PhaseClock {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    bool on;
+    explicit PhaseClock(bool o) : on(o) {}
+    void mark(const char *what) {
+      if (!on) return;
+      const auto now = std::chrono::steady_clock::now();
+      debug_info("crossproduct call: %-34s %.3f s (at %.3f s)", what, std::chrono::duration<double>(now - last).count(), std::chrono::duration<double>(now - t0).count());
+      last = now;
+    }
+  } clk(!in_dev || !out_dev);
   XStream st;
   if (st.create(hipStreamDefault)) return 1;   // blocking: ordered against the caller's default-stream work
   hipStream_t s = st.s;
   XBuf d_X, bounce, d_out, d_flag, f_tmp;
   if (d_X.alloc(xbytes) || d_flag.alloc(sizeof(int))) return 1;
+  clk.mark("operand buffer allocated");
   MXA_HIP(hipMemsetAsync(d_X.p, 0, xbytes, s));
   MXA_HIP(hipMemsetAsync(d_flag.p, 0, sizeof(int), s));
   if (in_dev) {
@@ -998,6 +1132,7 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
       MXA_HIP(hipStreamSynchronize(s));
     }
   }
+  clk.mark("operand staged (upload + k_xstage)");
   // engine: FP4 while the fp32 accumulator is provably exact (sum z z' < 2^24), int8 beyond (MXA_XPROD_ENGINE=i8 / f4 forces one, for A/B runs)
   int has3 = 1;
   MXA_HIP(hipMemcpyAsync(&has3, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1005,11 +1140,29 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
   bool f4 = has3 ? 9 * k < (1L << 24) : 4 * k < (1L << 24);
   if (const char *e = getenv("MXA_XPROD_ENGINE")) { if (!strcmp(e, "i8")) f4 = false; }
   double *d_ans = ans;
-  if (!out_dev) {
+  const bool whole0 = c_begin == 0 && c_end == rows && !upper_only;
+  const char *e_fused0 = getenv("MXA_XPROD_FUSED_POST");
+  const bool fused_possible = (!e_fused0 || atoi(e_fused0) != 0) && whole0;
+  // host result of the whole matrix: ring of column slabs (no n x n device buffer) where the call is bound by the download anyway -- the ring computes
+  // every off-diagonal tile twice.  Estimates: triangular arithmetic at the measured tile rate against the download at ~55 GB/s of four copiers.
+  // MXA_XPROD_HOST_RING: 0 never, 1 by this estimate (default), 2 always (tests).
+  bool use_ring = false;
+  if (!out_dev && whole0 && ld == rows && !getenv("MXA_XPROD_NO_PIPELINE")) {
+    const char *e_ring = getenv("MXA_XPROD_HOST_RING");
+    const int ring_mode = e_ring ? atoi(e_ring) : 1;
+    const double nbt = (double)((rows + kXT - 1) / kXT), tri_ms = (double)nslabs * (f4 ? 0.66e-3 : 1.0e-3) * nbt * (nbt + 1.0) / 2.0 / 256.0, copy_ms = (double)abytes / 55e9 * 1e3;
+    use_ring = ring_mode >= 2 || (ring_mode == 1 && abytes >= ((size_t)4 << 30) && 2.0 * tri_ms <= 1.15 * copy_ms);
+    if (!use_ring && ring_mode >= 1 && (!post || fused_possible)) {   // a result that does not fit the free device memory can only leave through the ring
+      size_t fb = 0, tb = 0;
+      if (hipMemGetInfo(&fb, &tb) == hipSuccess && abytes + ((size_t)1 << 30) > fb) use_ring = true;
+    }
+  }
+  if (!out_dev && !use_ring) {
     if (d_out.alloc(abytes)) return 1;
     d_ans = (double *)d_out.p;
     if (upper_only) MXA_HIP(hipMemsetAsync(d_ans, 0, abytes, s));   // the untouched part travels back as zeros
-  }
+    clk.mark("device result buffer allocated");
+  } else if (!out_dev) d_ans = nullptr;
   const bool whole = c_begin == 0 && c_end == rows && !upper_only;
   // GRM / LD: the element-wise map is fused into the crossproduct epilogue (whole matrix; MXA_XPROD_FUSED_POST=0 keeps the three extra passes over
   // the result).  What the map needs comes from the staged 2-bit matrix: ~2 passes over rows * k / 4 bytes instead of 3 over 8 * rows^2.
@@ -1025,7 +1178,8 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
   XPost xp;
   int post_kind = 0;
   XBuf st_t, st_raw, st_out;
-  if (post && fused_on && whole) {
+  constexpr long kXFusedMaxRows = 29000000L;   // k_x_rowstats: 16 * 3 * (3 rows) must fit 32 bits; beyond that the three-pass post-processing runs
+  if (post && fused_on && whole && rows < kXFusedMaxRows) {
     const long ntiles = rows_pad / kXT;
     if (st_t.alloc(sizeof(int) * (size_t)nslabs * 128) || st_raw.alloc(sizeof(unsigned long long) * (size_t)rows_pad) || st_out.alloc(sizeof(double) * (size_t)(rows_pad + 4))) return 1;
     MXA_HIP(hipMemsetAsync(st_raw.p, 0, sizeof(unsigned long long) * (size_t)rows_pad, s));
@@ -1050,8 +1204,24 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
     MXA_HIP(hipGetLastError());
     post_kind = post;
   }
-  if (!out_dev && (!post || post_kind) && whole && ld == rows && !getenv("MXA_XPROD_NO_PIPELINE"))
-    return crossprod_to_host((const uint8_t *)d_X.p, k, rows, pitch, d_ans, ans, s, f4, post_kind, &xp);
+  if (use_ring && (!post || post_kind)) {
+    const int rc = crossprod_to_host_ring((const uint8_t *)d_X.p, k, rows, pitch, ans, s, f4, post_kind, &xp);
+    clk.mark("slabs computed and copied out (ring)");
+    d_X.release();
+    clk.mark("device buffers released");
+    return rc;
+  }
+  if (use_ring) {   // unfused post-processing needs the whole matrix on the device after all
+    if (d_out.alloc(abytes)) return 1;
+    d_ans = (double *)d_out.p;
+  }
+  if (!out_dev && (!post || post_kind) && whole && ld == rows && !getenv("MXA_XPROD_NO_PIPELINE")) {
+    const int rc = crossprod_to_host((const uint8_t *)d_X.p, k, rows, pitch, d_ans, ans, s, f4, post_kind, &xp);
+    clk.mark("tiles computed, slabs copied out");
+    d_out.release(); d_X.release();
+    clk.mark("device buffers released");
+    return rc;
+  }
   if (crossprod_device((const uint8_t *)d_X.p, k, rows, pitch, d_ans, s, c_begin, c_end, upper_only, ld, f4, post_kind, &xp)) return 1;
   if (post && !post_kind && postprocess_device(d_ans, rows, k, post, do_scale, d_f, s)) return 1;
   if (!out_dev) MXA_HIP(hipMemcpyAsync(ans, d_ans, abytes, hipMemcpyDeviceToHost, s));

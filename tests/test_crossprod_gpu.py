@@ -135,3 +135,35 @@ def test_crossprod_host_result_is_pipelined_in_slabs(monkeypatch):
     monkeypatch.setenv("MXA_XPROD_NO_PIPELINE", "1")
     M2 = mx.crossproduct.snp_crossprod(X, k, rows, is_snpmajor=False, is_plink_format=True)
     assert np.array_equal(M2, ref)
+
+
+@pytest.mark.parametrize("slab_mb,rows", [("5", 2305), ("9", 2305), ("3", 1290)])
+def test_crossprod_host_result_through_the_slab_ring(monkeypatch, slab_mb, rows):
+    """Host result without an n x n device buffer (round 4: crossprod_to_host_ring): the matrix is produced column slab by column slab into a ring
+    of three device buffers -- every slab the column panel of mxa_snp_multiply_panel -- and copied out while the next slab computes.  Forced here
+    (MXA_XPROD_HOST_RING=2) with small slabs so that the ring wraps several times (10 slabs of one tile column, 5 of two, 6 of one); the default
+    takes it for results of 4 GB and more whose download outlasts twice the triangular arithmetic (tests/test_fullsize_configs_gpu.py runs
+    that at 12.8 GB).  Bit-exact against the integer product, for the plain crossproduct, GRM and LD (fused post-processing in the epilogue)."""
+    import miraculix_amd as mx
+    from _util import pack_plink
+    mx.load_shared_library()
+    rng = np.random.default_rng(6)
+    k = 900
+    Z = rng.integers(0, 3, size=(rows, k)).astype(np.int8)
+    X = np.ascontiguousarray(pack_plink(Z))
+    ref = (Z.astype(np.int64) @ Z.astype(np.int64).T).astype(np.float64)
+    monkeypatch.setenv("MXA_XPROD_SLAB_MB", slab_mb)
+    monkeypatch.setenv("MXA_XPROD_HOST_RING", "0")
+    M0 = mx.crossproduct.snp_crossprod(X, k, rows, is_snpmajor=False, is_plink_format=True)
+    f = Z.astype(np.float64).mean(axis=0) / 2.0
+    G0 = mx.crossproduct.grm(X, k, rows, is_plink_format=True, do_scale=True, allele_freq=f)
+    fr = Z.astype(np.float64).mean(axis=1) / 2.0
+    R0 = mx.crossproduct.ld(X, rows, k, is_plink_format=True, allele_freq=fr)
+    monkeypatch.setenv("MXA_XPROD_HOST_RING", "2")
+    M = np.full((rows, rows), -5.0)
+    mx.crossproduct.snp_crossprod(X, k, rows, is_snpmajor=False, is_plink_format=True, out=M)
+    assert np.array_equal(M, ref) and np.array_equal(M0, ref)
+    G = mx.crossproduct.grm(X, k, rows, is_plink_format=True, do_scale=True, allele_freq=f)
+    assert np.array_equal(G, G0)
+    R = mx.crossproduct.ld(X, rows, k, is_plink_format=True, allele_freq=fr)
+    assert np.array_equal(R, R0, equal_nan=True)
