@@ -515,7 +515,13 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c; geo.path = use_lut ? 1 : 0;
   }
   // MODE 2 / 3 (default): genotype operand as the denormal z * 2^-1074 (one VALU per fragment instead of two); B scaled per column
-  const int mode = gemm_default_mode(p.c);
+  // MXA_GEMM_TR=1 (round 4, A/B of single-orientation storage): the 'N' product is computed from the SNP-major copy by the transposed-operand
+  // instantiation of k_gemm (same plan, same sums: bit-identical to the launch on the individual-major copy); read per call
+  const char *e_tr = getenv("MXA_GEMM_TR");
+  const bool tr = !trans && !use_lut && e_tr && atoi(e_tr) != 0;
+  const PackedMatrix &GL = tr ? h->snp_major : G;
+  int mode = gemm_default_mode(p.c);
+  if (tr && mode == 3) mode = 2;   // the field-in-place variant attaches its scale to the K index; transposed, the field index is the output row
   const int *d_E = nullptr;
   if (!use_lut && (mode == 2 || mode == 3)) {
     if (w.cap_exp < (size_t)n) {
@@ -531,11 +537,11 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   }
   if (!use_lut && launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, d_E, 0, -1, nullptr, mode == 3)) return 1;
   if (prof) MXA_HIP(hipEventRecord(pe0, s));
-  int rc = use_lut ? launch_lut(G, dB, ldb, n, w.d_P, p, s) : launch_gemm(G, w.d_Bp, w.d_P, p, mode, s, next_ctr(w));
+  int rc = use_lut ? launch_lut(G, dB, ldb, n, w.d_P, p, s) : launch_gemm(GL, w.d_Bp, w.d_P, p, mode, s, next_ctr(w), 0, -1, nullptr, tr);
   if (prof && !rc) { MXA_HIP(hipEventRecord(pe1, s)); h->prof_pending[slot] = true; }
   if (!rc && d_E) {   // fallback of the denormal-operand mode, run only when the guard raised the flag: unscaled B, two-instruction conversion
     rc = launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, nullptr, 0, -1, w.d_denflag);
-    if (!rc) rc = launch_gemm(G, w.d_Bp, w.d_P, p, 0, s, next_ctr(w), 0, -1, w.d_denflag);
+    if (!rc) rc = launch_gemm(GL, w.d_Bp, w.d_P, p, 0, s, next_ctr(w), 0, -1, w.d_denflag, tr);
   }
   if (!rc) rc = launch_finish(w.d_P, p, m, n, dC, ldc, fill_rows, trans ? 1 : 0, centered, d_sumB, d_sumfB, h->d_f, s, d_E, 0, 0, nullptr, d_E ? w.d_denflag : nullptr);
   return rc;

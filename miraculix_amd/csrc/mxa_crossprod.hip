@@ -1081,10 +1081,11 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
   const size_t out_need = out_dev ? 0 : (ring_ok ? std::min<size_t>(abytes, (size_t)3400 << 20) : abytes);
   const size_t need = xbytes + out_need + (in_dev ? 0 : std::min<size_t>((size_t)rows * row_bytes, (size_t)256 << 20));
   if (need > free_b) { set_error(12, "snp_multiply_gpu: not enough device memory: required %zu GB, free %zu GB", need >> 30, free_b >> 30); return 1; }
-  // a host result in fresh memory (crossproduct.jl:56 `M = zeros(...)`): its pages are populated in the background from now on -- during the
-  // staging of X and the kernel -- so that the copies at the end do not pay the first-touch faults (mxa_hostmem.h).  Joined when this returns.
+  // a host result in fresh memory (crossproduct.jl:56 `M = zeros(...)`): its pages are populated in the background while the tiles are computed, so that
+  // the copies do not pay the first-touch faults (mxa_hostmem.h).  Joined when this returns.
+  // Started only AFTER the operand has been allocated and staged: twelve threads inside madvise slow a concurrent hipMalloc (12.5 GB: 1.2-1.3 s instead
+  // of < 0.06 s) and the staged pageable upload (1.55 s instead of 0.24 s) by more than the head start is worth (profiles/r04_crossprod_host_abi_c3.txt).
   HostPrefault prefault;
-  if (!out_dev) prefault.start(ans, abytes);
   struct PrefaultReport {
     HostPrefault &p;
     ~PrefaultReport() {
@@ -1133,6 +1134,7 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
     }
   }
   clk.mark("operand staged (upload + k_xstage)");
+  if (!out_dev) prefault.start(ans, abytes);
   // engine: FP4 while the fp32 accumulator is provably exact (sum z z' < 2^24), int8 beyond (MXA_XPROD_ENGINE=i8 / f4 forces one, for A/B runs)
   int has3 = 1;
   MXA_HIP(hipMemcpyAsync(&has3, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -192,8 +192,10 @@ int gemm_default_mode(int c);
 // K splits [split_begin, split_end) only (split_end < 0: all)
 // run_if_set (nullable, device int; MODE 0 only): the kernel does nothing unless *run_if_set != 0 (fallback of the denormal-operand mode)
 // d_ctr: 9 ints of device memory for the work queues of this launch (zeroed here, on s); must not be shared with a launch that may run at the same time
+// tr: transposed operand (k_gemm<..., TR>): the output rows are G's COLUMNS (p planned for m = G.k) and K runs over G's rows -- the 'N' product from the
+// SNP-major copy; modes 0 and 2 only
 int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, int mode, hipStream_t s, int *d_ctr, int split_begin = 0, int split_end = -1,
-                const int *run_if_set = nullptr);
+                const int *run_if_set = nullptr, bool tr = false);
 GemmPlan plan_lut(long m, long k_pad, int n);
 // run_if_set (nullable, device int): the kernel does nothing unless *run_if_set != 0 (fallback of the guarded small-n route)
 int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double *dP, const GemmPlan &p, hipStream_t s, const int *run_if_set = nullptr);

@@ -345,7 +345,13 @@ struct GemmCfg {
 // holds the pieces of XCD x in order, queue 8 the remaining groups in plain order for everybody; a workgroup whose queues are empty steals
 // from the other XCDs' queues.  The XCD of a workgroup is read from the hardware (HW_REG_XCC_ID), not assumed.  ctr: 9 counters, zeroed by
 // the launcher on the same stream.  Every fetch is one returning atomic add by one lane; every wave leaves when the fetch returns "none".
-template <int A, int C, int MODE, bool DIAG = false>
+// TR (round 4, transposed operand): the OUTPUT rows are the packed matrix's COLUMNS and K runs over its ROWS -- the 'N' product C = Z B computed from the
+// SNP-major copy (rows = SNPs, 32-byte slab pieces of 128 individuals), so that one stored orientation can serve both products.  A workgroup then owns
+// kRowsWG individuals = kRowsWG / 128 slabs; a K slab is 128 SNP rows = half a 256-row tile (4 KiB contiguous per slab of individuals); lane (i, kk) reads
+// the wave's 8 / 16 bytes of packed row 16 S + kk (ds_read_b64 / b128; the four lanes of a K index read the same word) and extracts the fields of its
+// individuals 4 g + i: still ONE v_bfe_u32 per fragment, with a per-lane shift 8 (g & 3) + 2 i.  Same K order, same partial sums, same P layout as the
+// untransposed launch on the individual-major copy: bit-identical results.  MODE 0 and 2 only.
+template <int A, int C, int MODE, bool DIAG = false, bool TR = false>
 __global__ void __launch_bounds__(256, 2)
 k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ Bp, int H, double *__restrict__ P,
        long m_pad, int n_pad, int rowblocks, int nchunks, int slabs_total, KSplit ks, int xcd_order,
@@ -384,7 +390,8 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
     // chunk-major B fragments: the column chunk nc is one contiguous array [S_total][C][64]
     u.Bp_u = reinterpret_cast<const char *>(Bp) + (size_t)u.nc * ((size_t)slabs_total * kSlabSteps * C * 512);
     // tiled layout: the rows [row0, row0 + kRowsWG) of slab s are one contiguous run inside tile (row0/256, s)
-    u.G_u = reinterpret_cast<const char *>(G) + (size_t)(row0 / kTileRows) * nslabs_all * kTileBytes + (size_t)(row0 % kTileRows) * kSlabBytes;
+    if (!TR) u.G_u = reinterpret_cast<const char *>(G) + (size_t)(row0 / kTileRows) * nslabs_all * kTileBytes + (size_t)(row0 % kTileRows) * kSlabBytes;
+    else u.G_u = reinterpret_cast<const char *>(G);   // TR: the workgroup's slabs of individuals are addressed per DMA unit (issue)
     return u;
   };
   auto issue = [&](const Unit &u, int slab, int buf) {
@@ -397,11 +404,27 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
       dma16_s(bslab + q * 1024, b_lane, base + q * 1024);
     }
     // packed genotype rows: unit = 32 rows x 32 B = 1 KiB, contiguous in the tiled layout
-    const char *aslab = u.G_u + (size_t)slab * kTileBytes;
+    if (!TR) {
+      const char *aslab = u.G_u + (size_t)slab * kTileBytes;
 #pragma unroll
-    for (int i = 0; i < (Cfg::kAUnits + kWaves - 1) / kWaves; i++) {
-      const int q = wave + i * kWaves;
-      if (Cfg::kAUnits % kWaves == 0 || q < Cfg::kAUnits) dma16_p<MXA_NT_GEMM != 0>(aslab + q * 1024, a_lane, base + Cfg::kBBytes + q * 1024);
+      for (int i = 0; i < (Cfg::kAUnits + kWaves - 1) / kWaves; i++) {
+        const int q = wave + i * kWaves;
+        if (Cfg::kAUnits % kWaves == 0 || q < Cfg::kAUnits) dma16_p<MXA_NT_GEMM != 0>(aslab + q * 1024, a_lane, base + Cfg::kBBytes + q * 1024);
+      }
+    } else {
+      // K slab `slab` = packed rows [128 slab, 128 slab + 128): the half (slab & 1) of tile row slab >> 1; the workgroup's j-th slab of individuals is tile
+      // column u.rb * nsw + j (clamped to the last one: individuals beyond the matrix give rows of P that nobody reads)
+      constexpr int nsw = Cfg::kRowsWG / kSlabK;
+      const char *arow = u.G_u + (size_t)(slab >> 1) * nslabs_all * kTileBytes + (size_t)(slab & 1) * (kTileBytes / 2);
+#pragma unroll
+      for (int i = 0; i < (Cfg::kAUnits + kWaves - 1) / kWaves; i++) {
+        const int q = wave + i * kWaves;
+        if (Cfg::kAUnits % kWaves == 0 || q < Cfg::kAUnits) {
+          size_t sl = (size_t)u.rb * nsw + (q >> 2);
+          if (sl >= nslabs_all) sl = nslabs_all - 1;
+          dma16_p<MXA_NT_GEMM != 0>(arow + sl * kTileBytes + (q & 3) * 1024, a_lane, base + Cfg::kBBytes + q * 1024);
+        }
+      }
     }
   };
 
@@ -417,6 +440,9 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
   const uint32_t fmask = 3u << sh;                                // MODE 3: the field stays where it is
   const int a_off = (wave * Cfg::kRowsWave + (lane & 3)) * kSlabBytes;  // + g*4 rows -> + g*4*32 bytes
   const int b_off = lane * 8;
+  // TR: packed row (lane >> 2) of the K-step, the wave's A bytes of it; field shifts of the lane's individuals 4 g + i, g & 3 = 0..3
+  const int tr_off = ((wave * A) / kSlabBytes) * (kSlabK * kSlabBytes) + (lane >> 2) * kSlabBytes + (wave * A) % kSlabBytes;
+  const int tr_sh[4] = {2 * (lane & 3), 8 + 2 * (lane & 3), 16 + 2 * (lane & 3), 24 + 2 * (lane & 3)};
   const int j = lane & 3, blk = (lane >> 2) & 3, i = lane >> 4;
 
   if (threadIdx.x == 0) s_next = fetch();
@@ -447,6 +473,40 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
       if (slab + 1 < u.slab1) issue(u, slab + 1, buf ^ 1);
       const char *bbase = smem + buf * Cfg::kBufBytes + b_off;
       const char *abase = smem + buf * Cfg::kBufBytes + Cfg::kBBytes + a_off;
+      if (TR) {
+        // LDS image [slab of individuals j][128 packed rows][32 B]; the wave's individuals are bytes [tr_off, tr_off + A) of every row
+        const char *tbase = smem + buf * Cfg::kBufBytes + Cfg::kBBytes + tr_off;
+        constexpr int ND = A / 4;                                    // dwords of a packed row the wave's 4 A individuals occupy
+        uint32_t dn[ND];
+        auto load_row = [&](int kst, uint32_t (&d)[ND]) {
+          if constexpr (ND == 4) { const uint4 t = *reinterpret_cast<const uint4 *>(tbase + kst * 16 * kSlabBytes); d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; }
+          else { const uint2 t = *reinterpret_cast<const uint2 *>(tbase + kst * 16 * kSlabBytes); d[0] = t.x; d[1] = t.y; }
+        };
+        load_row(0, dn);
+#pragma unroll
+        for (int kst = 0; kst < kSlabSteps; kst++) {
+          uint32_t dw[ND];
+#pragma unroll
+          for (int t = 0; t < ND; t++) dw[t] = dn[t];
+          if (kst + 1 < kSlabSteps) load_row(kst + 1, dn);
+          double bf[C];
+#pragma unroll
+          for (int h = 0; h < C; h++) bf[h] = *reinterpret_cast<const double *>(bbase + (kst * C + h) * 512);
+          double af[A];
+#pragma unroll
+          for (int g = 0; g < A; g++) {
+            const uint32_t z = __builtin_amdgcn_ubfe(dw[g >> 2], tr_sh[g & 3], 2);
+            if (MODE == 0) af[g] = (double)z;
+            else { ap[g].x = z; af[g] = __builtin_bit_cast(double, ap[g]); }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int g = 0; g < A; g++)
+#pragma unroll
+            for (int h = 0; h < C; h++) acc[g][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[g], bf[h], acc[g][h], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else
 #pragma unroll
       for (int ks2 = 0; ks2 < kSlabSteps / 2; ks2++) {
         uint2 aw[A];
@@ -641,12 +701,12 @@ GemmPlan plan_gemm(long m, long k_pad, int n, const GemmPlan *ksplits_like) {
   return p;
 }
 
-template <int A, int C, int MODE>
+template <int A, int C, int MODE, bool TR = false>
 static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, hipStream_t s, int split_begin, int split_end, const int *run_if_set,
                          int *d_ctr) {
   using Cfg = GemmCfg<A, C>;
   static unsigned long long attr_mask = 0;   // function attributes are per device
-  if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm<A, C, MODE>), Cfg::kLds, &attr_mask)) return 1;
+  if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm<A, C, MODE, false, TR>), Cfg::kLds, &attr_mask)) return 1;
   const long nunits = (long)p.rowblocks * p.nchunks * (split_end - split_begin);
   if (nunits > 0x3fffffffL) { set_error(3, "launch too large"); return 1; }
   if (nunits <= 0) return 0;
@@ -657,7 +717,7 @@ static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, c
   MXA_HIP(hipGetDevice(&dev));
   if (!per_cu[dev & 63]) {
     int nb = 0;
-    MXA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_gemm<A, C, MODE>), 256, Cfg::kLds));
+    MXA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_gemm<A, C, MODE, false, TR>), 256, Cfg::kLds));
     hipDeviceProp_t prop;
     MXA_HIP(hipGetDeviceProperties(&prop, dev));
     per_cu[dev & 63] = std::max(1, std::min(nb, gemm_wg_per_cu(C))) * prop.multiProcessorCount;
@@ -669,7 +729,7 @@ static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, c
   const int g8 = xcd_order ? (long_groups & ~7) : 0;
   MXA_HIP(hipMemsetAsync(d_ctr, 0, 9 * sizeof(int), s));
   static const bool diag_on = getenv("MXA_DIAG") != nullptr;
-  if (diag_on && ((A == 8 && C == 8) || (A == 16 && C == 1)) && split_begin == 0 && split_end == p.splits && !run_if_set) {   // diagnostic instantiation: in-kernel clock + cycles per slab
+  if (!TR && diag_on && ((A == 8 && C == 8) || (A == 16 && C == 1)) && split_begin == 0 && split_end == p.splits && !run_if_set) {   // diagnostic instantiation: in-kernel clock + cycles per slab
     static unsigned long long attr2 = 0;
     if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm<A, C, MODE, true>), Cfg::kLds, &attr2)) return 1;
     unsigned long long *d_diag = nullptr;
@@ -724,15 +784,31 @@ static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, c
     (void)hipFree(d_diag);
     return 0;
   }
-  hipLaunchKernelGGL((k_gemm<A, C, MODE>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBp, p.n_pad / 4, dP,
+  hipLaunchKernelGGL((k_gemm<A, C, MODE, false, TR>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBp, p.n_pad / 4, dP,
                      p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, ks, xcd_order, (unsigned long long *)nullptr, split_begin, run_if_set, (int)nunits, d_ctr, g8);
   MXA_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, int mode, hipStream_t s, int *d_ctr, int split_begin, int split_end,
-                const int *run_if_set) {
+                const int *run_if_set, bool tr) {
   if (split_end < 0) split_end = p.splits;
+  if (tr) {   // transposed operand: output rows = columns of G (its k individuals), K = rows of G in slabs of 128
+    if ((long)p.slabs_total * kSlabK > G.rows_pad || G.nslabs < 1 || (mode != 0 && mode != 2)) {
+      set_error(4, "internal: transposed launch does not fit the packed matrix (K slabs %d x 128 > %ld rows) or mode %d", p.slabs_total, G.rows_pad, mode);
+      return 1;
+    }
+#define MXA_DISPATCH_TR(AA, CC)                                                                                          \
+    if (p.a == AA && p.c == CC) {                                                                                        \
+      if (mode == 2) return launch_gemm_t<AA, CC, 2, true>(G, dBp, dP, p, s, split_begin, split_end, nullptr, d_ctr);     \
+      return launch_gemm_t<AA, CC, 0, true>(G, dBp, dP, p, s, split_begin, split_end, run_if_set, d_ctr);                 \
+    }
+    MXA_DISPATCH_TR(16, 1) MXA_DISPATCH_TR(16, 2) MXA_DISPATCH_TR(16, 3) MXA_DISPATCH_TR(16, 4)
+    MXA_DISPATCH_TR(8, 5) MXA_DISPATCH_TR(8, 6) MXA_DISPATCH_TR(8, 7) MXA_DISPATCH_TR(8, 8)
+#undef MXA_DISPATCH_TR
+    set_error(5, "internal: no transposed kernel for tile a=%d c=%d", p.a, p.c);
+    return 1;
+  }
   // host-side shape checks: the kernel reads rows [0, m_pad) x [0, slabs_total*32) bytes and Bp[(k_pad/16)][H][64]
   if (p.m_pad > G.rows_pad || (size_t)p.slabs_total * kSlabBytes > G.pitch) {
     set_error(4, "internal: packed matrix smaller than the launch plan (m_pad %ld > %ld or k bytes %ld > pitch %zu)", p.m_pad,
