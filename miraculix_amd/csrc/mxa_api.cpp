@@ -399,6 +399,20 @@ int enable_peer(int cur, int peer) {
   return can;
 }
 
+// Which stored orientation feeds a k_gemm launch (round 4).  Every product can be computed from either copy: in the plain form from the copy whose ROWS
+// are the output rows ('T': SNP-major, 'N': individual-major -- the reference's choice, dgemm_compressed_cuda.cu:270), in the transposed-operand form
+// (k_gemm<..., TR>) from the copy whose rows are the K index.  The two forms give bit-identical results (same plan, same K order).  The transposed form
+// reads the genotype operand with one LDS instruction per K-step instead of A / 2, which makes the widest tile (A = 8, C = 5..8: n >= 17) 2 % faster
+// (C2: 43.1 against 44.0 ms per launch = 0.944 against 0.925 of the fp64 MFMA peak, profiles/r04_gemm_tr_ab.txt); the narrow tiles (A = 16) keep the
+// plain form, whose field-in-place extraction (MODE 3) has no transposed counterpart.  MXA_GEMM_TR: 0 never, 1 wherever a transposed instantiation
+// exists (tests), unset: the A = 8 tiles.  Read per call.
+static bool gemm_use_tr(const GemmPlan &p) {
+  const char *e = getenv("MXA_GEMM_TR");
+  if (e) return atoi(e) != 0;
+  return p.a == 8;
+}
+static const PackedMatrix &gemm_operand(const Handle *h, bool trans, bool tr) { return (trans != tr) ? h->snp_major : h->ind_major; }
+
 // Device operands only; asynchronous on s.  With timing, ev0/ev1 bracket the dominant kernel and harvest_profile() reads them later.
 static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, hipStream_t s, bool timing = true) {
   const PackedMatrix &G = trans ? h->snp_major : h->ind_major;   // reference picks d_plink for 'T' (dgemm_compressed_cuda.cu:270)
@@ -515,11 +529,8 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c; geo.path = use_lut ? 1 : 0;
   }
   // MODE 2 / 3 (default): genotype operand as the denormal z * 2^-1074 (one VALU per fragment instead of two); B scaled per column
-  // MXA_GEMM_TR=1 (round 4, A/B of single-orientation storage): the 'N' product is computed from the SNP-major copy by the transposed-operand
-  // instantiation of k_gemm (same plan, same sums: bit-identical to the launch on the individual-major copy); read per call
-  const char *e_tr = getenv("MXA_GEMM_TR");
-  const bool tr = !trans && !use_lut && e_tr && atoi(e_tr) != 0;
-  const PackedMatrix &GL = tr ? h->snp_major : G;
+  const bool tr = !use_lut && gemm_use_tr(p);   // transposed-operand form: from the OTHER stored orientation (gemm_use_tr)
+  const PackedMatrix &GL = gemm_operand(h, trans, tr);
   int mode = gemm_default_mode(p.c);
   if (tr && mode == 3) mode = 2;   // the field-in-place variant attaches its scale to the K index; transposed, the field index is the output row
   const int *d_E = nullptr;
@@ -629,7 +640,10 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
     else if (rc8 != 2) return 1;
   }
   const GemmPlan p = plan_gemm(m, G.k_pad, n);
-  const int mode = gemm_default_mode(p.c);
+  const bool tr = gemm_use_tr(p) && (kmode || p.a == 8);   // row ranges of a transposed launch are column ranges of the packed matrix: whole slabs only for the 128-row blocks of A = 8
+  const PackedMatrix &GL = gemm_operand(h, trans, tr);
+  int mode = gemm_default_mode(p.c);
+  if (tr && mode == 3) mode = 2;
   if (mode != 2 && mode != 3) return 2;
   if (ensure_partials(w, p, s)) return 1;
   { std::lock_guard<std::mutex> lk(g_prof_mutex); Geometry &geo = last_geometry(); geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c; geo.path = 0; }
@@ -651,7 +665,7 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
       int *d_Ec = w.d_exp + (size_t)c * n;
       if (launch_colexp(dB + k0, dldb, k1 - k0, n, w.d_colpart + (size_t)c * 128 * n, d_Ec, 0, cs, w.d_denflag, kDenMaxSpan, -100000, false)) return 1;
       if (launch_pack_B(dB, dldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, cs, d_Ec, slab0 * kSlabSteps, (slab1 - slab0) * kSlabSteps, nullptr, mode == 3)) return 1;
-      if (launch_gemm(G, w.d_Bp, w.d_P, p, mode, cs, next_ctr(w), sb, se)) return 1;
+      if (launch_gemm(GL, w.d_Bp, w.d_P, p, mode, cs, next_ctr(w), sb, se, nullptr, tr)) return 1;
       MXA_HIP(hipEventRecord(h->pev[10 + c], cs));
     }
     for (int c = 0; c < nch; c++) MXA_HIP(hipStreamWaitEvent(s, h->pev[10 + c], 0));
@@ -682,15 +696,17 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
       const int c = nch;
       const long r1 = std::min(m, r0 + rows_chunk), rows_c = r1 - r0;
       const bool last = r1 == m;
-      PackedMatrix V = G;   // rows [r0, r1): whole 256-row tiles, so the view starts at a tile boundary of the tiled layout
-      V.d = G.d + (size_t)(r0 / kTileRows) * G.nslabs * kTileBytes;
-      V.rows = rows_c; V.rows_pad = last ? G.rows_pad - r0 : rows_chunk;
+      PackedMatrix V = GL;   // output rows [r0, r1): whole 256-row tiles, so the view starts at a tile boundary of the tiled layout
+      if (!tr) {
+        V.d = G.d + (size_t)(r0 / kTileRows) * G.nslabs * kTileBytes;
+        V.rows = rows_c; V.rows_pad = last ? G.rows_pad - r0 : rows_chunk;
+      } else V.d = GL.d + (size_t)(r0 / kSlabK) * kTileBytes;   // transposed: the output rows are the packed COLUMNS -- the view starts at slab r0 / 128 of every tile row (same pitch)
       const GemmPlan pc = plan_gemm(rows_c, G.k_pad, n, &p);   // the one-launch plan's K pieces: identical sums
       const size_t p_need = (size_t)pc.splits * pc.n_pad * pc.m_pad;
       if (p_off + p_need > w.cap_P) { set_error(4, "internal: partial-result workspace too small for the row-range pipeline"); return 1; }
       hipStream_t cs = h->pipe[c & 1];
       MXA_HIP(hipStreamWaitEvent(cs, h->pev[1], 0));
-      if (launch_gemm(V, w.d_Bp, w.d_P + p_off, pc, mode, cs, next_ctr(w))) return 1;
+      if (launch_gemm(V, w.d_Bp, w.d_P + p_off, pc, mode, cs, next_ctr(w), 0, -1, nullptr, tr)) return 1;
       const long fill_c = last ? fill_rows - r0 : rows_c;
       if (launch_finish(w.d_P + p_off, pc, rows_c, n, dC + r0, dldc, fill_c, trans ? 1 : 0, centered, d_sumB, d_sumfB, (h->d_f && trans) ? h->d_f + r0 : h->d_f, cs, w.d_exp)) return 1;
       MXA_HIP(hipEventRecord(h->pev[10 + c], cs));

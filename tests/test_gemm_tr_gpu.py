@@ -1,6 +1,7 @@
-"""Transposed-operand instantiation of k_gemm (round 4; MXA_GEMM_TR=1): the 'N' product C = Zc B computed from the SNP-major copy -- output rows =
-columns of the packed matrix, K = its rows -- as the A/B of single-orientation storage (one packed copy serving both products; VERDICT round 3,
-item 5).  Same launch plan, same K order, same partial sums as the launch on the individual-major copy: the results must be BIT-IDENTICAL, for every
+"""Transposed-operand instantiation of k_gemm (round 4): a product computed from the copy whose ROWS are the K index -- 'N' from the SNP-major copy,
+'T' from the individual-major one; output rows = columns of the packed matrix.  It is the default for the widest tile (A = 8: n >= 17, 2 % faster)
+and the A/B of single-orientation storage (one packed copy serving both products).  MXA_GEMM_TR=0 / 1 force the plain /
+the transposed form.  Same launch plan, same K order, same partial sums: the results must be BIT-IDENTICAL, for every
 tile shape (n = 8 ... 128: C = 2 ... 8, A = 16 / 8; 33 and 10: peeled columns beside it), ragged sizes (individuals not a multiple of the 128-wide
 slab nor of the 256-individual block of the A = 16 tiles: the clamped last slab), centred and not, padded leading dimensions -- and agree with the
 long-double oracle."""
@@ -21,10 +22,10 @@ def mx():
     return m
 
 
-def _n_product(dg, obj, prob, B, tr):
+def _product(dg, obj, prob, trans, B, tr):
     os.environ["MXA_GEMM_TR"] = "1" if tr else "0"
     try:
-        return dg.dgemm_compressed_main(False, obj, np.asfortranarray(B.T), prob["snps"], prob["indiv"])
+        return dg.dgemm_compressed_main(bool(trans), obj, np.asfortranarray(B.T), prob["snps"], prob["indiv"])
     finally:
         os.environ.pop("MXA_GEMM_TR", None)
 
@@ -39,14 +40,17 @@ def test_transposed_operand_is_bit_identical(mx, snps, indiv, n):
     try:
         for centered in (0, 1):
             dg.set_options(use_gpu=True, not_center=not centered, verbose=0)
-            B = make_B(snps, n, seed=7 + centered)
-            C0 = _n_product(dg, obj, prob, B, False)
-            assert dg.last_path() == "k_gemm"
-            C1 = _n_product(dg, obj, prob, B, True)
-            assert dg.last_path() == "k_gemm"
-            assert np.array_equal(C0, C1)
-            ref = o.dgemm_dense(0, prob, B, centered)[:, :indiv]
-            assert np.abs(C1.T - ref).max() <= 1e-11 * np.abs(ref).max()
+            for trans in (0, 1):
+                k, m = (indiv, snps) if trans else (snps, indiv)
+                B = make_B(k, n, seed=7 + centered + 2 * trans)
+                C0 = _product(dg, obj, prob, trans, B, False)
+                assert dg.last_path() == "k_gemm"
+                C1 = _product(dg, obj, prob, trans, B, True)
+                assert dg.last_path() == "k_gemm"
+                assert np.array_equal(C0, C1)
+                assert np.array_equal(C0, dg.dgemm_compressed_main(bool(trans), obj, np.asfortranarray(B.T), snps, indiv))   # the default picks one of the two
+                ref = o.dgemm_dense(trans, prob, B, centered)[:, :m]
+                assert np.abs(C1.T - ref).max() <= 1e-11 * np.abs(ref).max()
     finally:
         dg.free_compressed(obj)
 
