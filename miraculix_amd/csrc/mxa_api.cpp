@@ -402,14 +402,22 @@ int enable_peer(int cur, int peer) {
 // Which stored orientation feeds a k_gemm launch (round 4).  Every product can be computed from either copy: in the plain form from the copy whose ROWS
 // are the output rows ('T': SNP-major, 'N': individual-major -- the reference's choice, dgemm_compressed_cuda.cu:270), in the transposed-operand form
 // (k_gemm<..., TR>) from the copy whose rows are the K index.  The two forms give bit-identical results (same plan, same K order).  The transposed form
-// reads the genotype operand with one LDS instruction per K-step instead of A / 2, which makes the widest tile (A = 8, C = 5..8: n >= 17) 2 % faster
-// (C2: 43.1 against 44.0 ms per launch = 0.944 against 0.925 of the fp64 MFMA peak, profiles/r04_gemm_tr_ab.txt); the narrow tiles (A = 16) keep the
-// plain form, whose field-in-place extraction (MODE 3) has no transposed counterpart.  MXA_GEMM_TR: 0 never, 1 wherever a transposed instantiation
-// exists (tests), unset: the A = 8 tiles.  Read per call.
-static bool gemm_use_tr(const GemmPlan &p) {
+// reads the genotype operand with ONE LDS instruction per K-step instead of A / 2 and extracts every fragment with a two-operand v_and_b32 whose scale
+// belongs to the output row (undone exactly in the epilogue), for every tile.  Measured, same box, alternating (profiles/r04_gemm_tr_ab.txt): C2
+// 42.5 ms per launch against 43.9-44.0 = 75.3 against 72.8 TFLOP/s = 0.957 against 0.925 of the fp64 MFMA peak; config-4 shard 423.6 against 438.0 ms
+// (0.961); n = 20: 13.55 against 13.98; n = 16: 10.87 against 11.03; n = 12: 8.30-8.35 against 8.44-8.47; n = 8: 5.70 against 5.77-5.84.
+// MXA_GEMM_TR: 0 never (the plain form), otherwise / unset: always.  Read per call.
+static bool gemm_use_tr(const GemmPlan &) {
   const char *e = getenv("MXA_GEMM_TR");
-  if (e) return atoi(e) != 0;
-  return p.a == 8;
+  return !e || atoi(e) != 0;
+}
+// conversion variant of a transposed launch: 3 (default) = field masked in place (v_and_b32) with the scale 4^field on the OUTPUT row, undone in the
+// epilogue (no row scaling of B: launch_pack_B gets rowscale = false); 2 = v_bfe_u32.  MXA_GEMM_TR_MODE overrides (A/B).
+static int gemm_tr_mode(int mode) {
+  if (mode != 2 && mode != 3) return mode;
+  const char *e = getenv("MXA_GEMM_TR_MODE");
+  const int m = e ? atoi(e) : 3;
+  return (m == 2 || m == 3) ? m : 3;
 }
 static const PackedMatrix &gemm_operand(const Handle *h, bool trans, bool tr) { return (trans != tr) ? h->snp_major : h->ind_major; }
 
@@ -532,7 +540,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   const bool tr = !use_lut && gemm_use_tr(p);   // transposed-operand form: from the OTHER stored orientation (gemm_use_tr)
   const PackedMatrix &GL = gemm_operand(h, trans, tr);
   int mode = gemm_default_mode(p.c);
-  if (tr && mode == 3) mode = 2;   // the field-in-place variant attaches its scale to the K index; transposed, the field index is the output row
+  if (tr) mode = gemm_tr_mode(mode);
   const int *d_E = nullptr;
   if (!use_lut && (mode == 2 || mode == 3)) {
     if (w.cap_exp < (size_t)n) {
@@ -546,7 +554,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     if (launch_colexp(dB, ldb, k, n, w.d_colpart, w.d_exp, 0, s, w.d_denflag, kDenMaxSpan, -100000)) return 1;
     d_E = w.d_exp;
   }
-  if (!use_lut && launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, d_E, 0, -1, nullptr, mode == 3)) return 1;
+  if (!use_lut && launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, d_E, 0, -1, nullptr, mode == 3 && !tr)) return 1;
   if (prof) MXA_HIP(hipEventRecord(pe0, s));
   int rc = use_lut ? launch_lut(G, dB, ldb, n, w.d_P, p, s) : launch_gemm(GL, w.d_Bp, w.d_P, p, mode, s, next_ctr(w), 0, -1, nullptr, tr);
   if (prof && !rc) { MXA_HIP(hipEventRecord(pe1, s)); h->prof_pending[slot] = true; }
@@ -643,7 +651,7 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
   const bool tr = gemm_use_tr(p) && (kmode || p.a == 8);   // row ranges of a transposed launch are column ranges of the packed matrix: whole slabs only for the 128-row blocks of A = 8
   const PackedMatrix &GL = gemm_operand(h, trans, tr);
   int mode = gemm_default_mode(p.c);
-  if (tr && mode == 3) mode = 2;
+  if (tr) mode = gemm_tr_mode(mode);
   if (mode != 2 && mode != 3) return 2;
   if (ensure_partials(w, p, s)) return 1;
   { std::lock_guard<std::mutex> lk(g_prof_mutex); Geometry &geo = last_geometry(); geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c; geo.path = 0; }
@@ -664,7 +672,7 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
       MXA_HIP(hipStreamWaitEvent(cs, h->pev[2 + c], 0));
       int *d_Ec = w.d_exp + (size_t)c * n;
       if (launch_colexp(dB + k0, dldb, k1 - k0, n, w.d_colpart + (size_t)c * 128 * n, d_Ec, 0, cs, w.d_denflag, kDenMaxSpan, -100000, false)) return 1;
-      if (launch_pack_B(dB, dldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, cs, d_Ec, slab0 * kSlabSteps, (slab1 - slab0) * kSlabSteps, nullptr, mode == 3)) return 1;
+      if (launch_pack_B(dB, dldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, cs, d_Ec, slab0 * kSlabSteps, (slab1 - slab0) * kSlabSteps, nullptr, mode == 3 && !tr)) return 1;
       if (launch_gemm(GL, w.d_Bp, w.d_P, p, mode, cs, next_ctr(w), sb, se, nullptr, tr)) return 1;
       MXA_HIP(hipEventRecord(h->pev[10 + c], cs));
     }
@@ -681,7 +689,7 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
       else MXA_HIP(copy_columns(w.d_Bstage, sizeof(double) * k, B, sizeof(double) * ldb, sizeof(double) * k, n, s));
     }
     if (launch_colexp(dB, dldb, k, n, w.d_colpart, w.d_exp, 0, s, w.d_denflag, kDenMaxSpan, -100000, false)) return 1;
-    if (launch_pack_B(dB, dldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, w.d_exp, 0, -1, nullptr, mode == 3)) return 1;
+    if (launch_pack_B(dB, dldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, w.d_exp, 0, -1, nullptr, mode == 3 && !tr)) return 1;
     if (centered && launch_colsums(dB, dldb, k, n, trans ? nullptr : h->d_f, d_sumscratch, d_sumB, d_sumfB, s)) return 1;
     MXA_HIP(hipEventRecord(h->pev[1], s));
     const long rows_chunk = ((m + want_chunks - 1) / want_chunks + kRowAlign - 1) / kRowAlign * kRowAlign;

@@ -350,7 +350,8 @@ struct GemmCfg {
 // kRowsWG individuals = kRowsWG / 128 slabs; a K slab is 128 SNP rows = half a 256-row tile (4 KiB contiguous per slab of individuals); lane (i, kk) reads
 // the wave's 8 / 16 bytes of packed row 16 S + kk (ds_read_b64 / b128; the four lanes of a K index read the same word) and extracts the fields of its
 // individuals 4 g + i: still ONE v_bfe_u32 per fragment, with a per-lane shift 8 (g & 3) + 2 i.  Same K order, same partial sums, same P layout as the
-// untransposed launch on the individual-major copy: bit-identical results.  MODE 0 and 2 only.
+// untransposed launch on the individual-major copy: bit-identical results.  MODE 3 here: the field is masked where it stands (v_and_b32) and the scale
+// 4^(field) belongs to the OUTPUT row, undone exactly in the epilogue (no row scaling of B).
 template <int A, int C, int MODE, bool DIAG = false, bool TR = false>
 __global__ void __launch_bounds__(256, 2)
 k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ Bp, int H, double *__restrict__ P,
@@ -443,6 +444,7 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
   // TR: packed row (lane >> 2) of the K-step, the wave's A bytes of it; field shifts of the lane's individuals 4 g + i, g & 3 = 0..3
   const int tr_off = ((wave * A) / kSlabBytes) * (kSlabK * kSlabBytes) + (lane >> 2) * kSlabBytes + (wave * A) % kSlabBytes;
   const int tr_sh[4] = {2 * (lane & 3), 8 + 2 * (lane & 3), 16 + 2 * (lane & 3), 24 + 2 * (lane & 3)};
+  const uint32_t tr_mask[4] = {3u << tr_sh[0], 3u << tr_sh[1], 3u << tr_sh[2], 3u << tr_sh[3]};
   const int j = lane & 3, blk = (lane >> 2) & 3, i = lane >> 4;
 
   if (threadIdx.x == 0) s_next = fetch();
@@ -495,9 +497,14 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
           double af[A];
 #pragma unroll
           for (int g = 0; g < A; g++) {
-            const uint32_t z = __builtin_amdgcn_ubfe(dw[g >> 2], tr_sh[g & 3], 2);
-            if (MODE == 0) af[g] = (double)z;
-            else { ap[g].x = z; af[g] = __builtin_bit_cast(double, ap[g]); }
+            if (MODE == 3) {   // field masked where it stands: the operand is z * 4^(4 (g & 3) + i) * 2^-1074; the epilogue scales row (g, i) back (exact)
+              asm volatile("v_and_b32 %0, %1, %2" : "=v"(ap[g].x) : "v"(tr_mask[g & 3]), "v"(dw[g >> 2]));
+              af[g] = __builtin_bit_cast(double, ap[g]);
+            } else {
+              const uint32_t z = __builtin_amdgcn_ubfe(dw[g >> 2], tr_sh[g & 3], 2);
+              if (MODE == 0) af[g] = (double)z;
+              else { ap[g].x = z; af[g] = __builtin_bit_cast(double, ap[g]); }
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -599,7 +606,8 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
           for (int hq = 0; hq < C; hq += 4) {
             if (hq + blk < C) {
               const double *q = scr + (gg * C + hq + blk) * kPitch + j + 16 * i;
-              const double out = (q[0] + q[4]) + (q[8] + q[12]);
+              double out = (q[0] + q[4]) + (q[8] + q[12]);
+              if (TR && MODE == 3) out = ldexp(out, -(8 * ((g0 + gg) & 3) + 2 * i));   // undo the in-place field scale of output row (g, i): a power of two, exact
               const int col = 4 * (u.nc * C + hq + blk) + j;
               Pbase[(size_t)col * Cfg::kRowsWG + row] = out;   // (a non-temporal store here more than doubles WRITE_SIZE: the 32-byte runs of a wave are no longer merged in the L2)
             }
@@ -794,13 +802,14 @@ int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const Gemm
                 const int *run_if_set, bool tr) {
   if (split_end < 0) split_end = p.splits;
   if (tr) {   // transposed operand: output rows = columns of G (its k individuals), K = rows of G in slabs of 128
-    if ((long)p.slabs_total * kSlabK > G.rows_pad || G.nslabs < 1 || (mode != 0 && mode != 2)) {
+    if ((long)p.slabs_total * kSlabK > G.rows_pad || G.nslabs < 1 || (mode != 0 && mode != 2 && mode != 3)) {
       set_error(4, "internal: transposed launch does not fit the packed matrix (K slabs %d x 128 > %ld rows) or mode %d", p.slabs_total, G.rows_pad, mode);
       return 1;
     }
 #define MXA_DISPATCH_TR(AA, CC)                                                                                          \
     if (p.a == AA && p.c == CC) {                                                                                        \
       if (mode == 2) return launch_gemm_t<AA, CC, 2, true>(G, dBp, dP, p, s, split_begin, split_end, nullptr, d_ctr);     \
+      if (mode == 3) return launch_gemm_t<AA, CC, 3, true>(G, dBp, dP, p, s, split_begin, split_end, nullptr, d_ctr);     \
       return launch_gemm_t<AA, CC, 0, true>(G, dBp, dP, p, s, split_begin, split_end, run_if_set, d_ctr);                 \
     }
     MXA_DISPATCH_TR(16, 1) MXA_DISPATCH_TR(16, 2) MXA_DISPATCH_TR(16, 3) MXA_DISPATCH_TR(16, 4)

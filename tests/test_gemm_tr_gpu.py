@@ -22,12 +22,15 @@ def mx():
     return m
 
 
-def _product(dg, obj, prob, trans, B, tr):
+def _product(dg, obj, prob, trans, B, tr, tr_mode=None):
     os.environ["MXA_GEMM_TR"] = "1" if tr else "0"
+    if tr_mode is not None:
+        os.environ["MXA_GEMM_TR_MODE"] = str(tr_mode)
     try:
         return dg.dgemm_compressed_main(bool(trans), obj, np.asfortranarray(B.T), prob["snps"], prob["indiv"])
     finally:
         os.environ.pop("MXA_GEMM_TR", None)
+        os.environ.pop("MXA_GEMM_TR_MODE", None)
 
 
 @pytest.mark.parametrize("snps,indiv", [(2051, 777), (1003, 130), (4100, 1290), (700, 3001)])
@@ -45,9 +48,11 @@ def test_transposed_operand_is_bit_identical(mx, snps, indiv, n):
                 B = make_B(k, n, seed=7 + centered + 2 * trans)
                 C0 = _product(dg, obj, prob, trans, B, False)
                 assert dg.last_path() == "k_gemm"
-                C1 = _product(dg, obj, prob, trans, B, True)
+                C1 = _product(dg, obj, prob, trans, B, True, tr_mode=2)
                 assert dg.last_path() == "k_gemm"
                 assert np.array_equal(C0, C1)
+                C3 = _product(dg, obj, prob, trans, B, True, tr_mode=3)        # field masked in place, row scale undone in the epilogue: exact powers of two
+                assert np.array_equal(C0, C3)
                 assert np.array_equal(C0, dg.dgemm_compressed_main(bool(trans), obj, np.asfortranarray(B.T), snps, indiv))   # the default picks one of the two
                 ref = o.dgemm_dense(trans, prob, B, centered)[:, :m]
                 assert np.abs(C1.T - ref).max() <= 1e-11 * np.abs(ref).max()
