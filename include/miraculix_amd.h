@@ -132,6 +132,10 @@ void mxa_plink2compressed_shard(char *plink, char *plink_transposed, int snps_to
 
 /* dgemm_compressed with 64-bit leading dimensions on an explicit HIP stream (NULL = the object's own stream),
  * device pointers only, asynchronous when sync == 0.  Returns 0 / 1.
+ * (Asynchronous with one exception, here and in mxa_dgemm_compressed_multi: under the default engine a product with 3 <= n <= 6, or with
+ * n = 4q + 3 > 6 peeled columns, and every product of engine `i8-exact`, chooses its digit count from three integers read back from the device:
+ * the calling thread -- in a multi-device object each shard's worker -- then waits for the work enqueued before it.  n <= 2 and the fp64 MFMA
+ * products n = 4q, 4q + 1, 4q + 2 >= 7 never wait.)
  * ONE CALL IN FLIGHT PER OBJECT: every multiply on an object uses that object's workspace (fragment-ordered B, split-K
  * partials, column sums).  Calls on the same object must therefore be serialised on ONE stream (or the caller must wait
  * for the previous call before issuing the next on another stream); this includes mxa_gram_matvec and dgemm_compressed.
@@ -211,7 +215,9 @@ int mxa_shard_bounds(long snps, int shards, int g, long *begin, long *end);
  * sync == 0: the call returns when the work is enqueued (device operands only; a host operand makes the call synchronous).  Products
  * issued back to back on one object are ordered like calls on one stream, but the transfers of an 'N' product's partial sums and their
  * addition on the first device run BESIDE the next product ('T' of the same step) on copy streams.  mxa_multi_synchronize() waits for
- * everything issued on the object.  Results are those of dgemm_compressed on the same object (same kernels, same fixed-order reduction).
+ * everything issued on the object (a later product that READS or overwrites the memory the previous 'N' product delivered its result to is
+ * ordered behind that delivery; products on unrelated memory are not held up).  Results are those of dgemm_compressed on the same object (same
+ * kernels, same fixed-order reduction).
  * Reference counterpart of the need: src/cuda/dgemm_compressed_cuda.cu:251-252 (operands cross PCIe on every call).  Returns 0 / 1. */
 int mxa_dgemm_compressed_multi(char trans, void *compressed, int n, const double *const *B_per_shard, long ldb,
                                double *const *C_per_shard, long ldc, int sync);

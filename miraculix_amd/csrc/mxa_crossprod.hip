@@ -528,6 +528,7 @@ static bool gang_order_tiles(std::vector<int4> &tiles) {
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
+static thread_local bool tl_xprod_shared_device = false;   // set by the panel workers of snp_multiply_gpu when several panels share a device
 static std::mutex g_xprof_mutex;   // panels of one call run in several threads (MIRACULIX_NUM_GPUS): the profile counters are shared
 namespace {
 struct XEvent {   // RAII: events, streams and device buffers are released on every exit path
@@ -559,7 +560,9 @@ static int launch_tiles(bool f4, size_t ntiles, hipStream_t s, const uint8_t *d_
   // 500k -3.4 %, but K = 50 000 (0.26 ms per tile) +2 ... +8 % at 8 192 - 40 000 rows.  MXA_XPROD_GANG: 0 never, 1 (default) by this estimate, 2 whenever possible.
   static const int gang_on = [] { const char *e = getenv("MXA_XPROD_GANG"); return e ? atoi(e) : 1; }();
   int dev = 0, cus = 0;
-  if (gang_on && d_gang && !d_diag && ntiles % 8 == 0) {
+  // not when this call is one of several panels computed side by side on ONE device (MIRACULIX_NUM_GPUS above the device count): the gang form wants one
+  // workgroup per CU resident at once and would spend its 2 ms start-up wait on workgroups that cannot become resident beside the other panel's kernel
+  if (gang_on && d_gang && !d_diag && ntiles % 8 == 0 && !(tl_xprod_shared_device && gang_on < 2)) {
     MXA_HIP(hipGetDevice(&dev));
     MXA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   }
@@ -1246,7 +1249,9 @@ extern "C" int snp_multiply_gpu(unsigned char *snp_matrix, int snps, int indiv, 
   if (G > 1 && snp_matrix && ans && snps > 0 && indiv > 0 && mxa::ptr_location(snp_matrix, nullptr) == 0 && mxa::ptr_location(ans, nullptr) == 0) {
     const long nb = ((long)indiv + mxa::kXT - 1) / mxa::kXT;
     const int parts = (int)std::min<long>(G, nb);
+    const int ndev = mxa_device_count();
     return mxa::run_on_devices(parts, [&](int g, int dev) {
+      mxa::tl_xprod_shared_device = ndev > 0 && parts > ndev;   // worker threads are pooled: set on every job
       const long c0 = std::min<long>(indiv, nb * g / parts * mxa::kXT), c1 = std::min<long>(indiv, nb * (g + 1) / parts * mxa::kXT);
       if (c1 <= c0) return 0;
       return mxa::crossprod_any(snp_matrix, snps, indiv, ans + (size_t)c0 * indiv, is_plink_format, 0, 0, nullptr, c0, c1, false, indiv, dev);

@@ -193,10 +193,12 @@ void oracle5_free(void *hh) {
   free(h->code_T); free(h->code_N); free(h->f); free(h);
 }
 
-/* genoVector kernel for ONE right-hand side column (the reference interleaves VatOnce=4 columns in
- * one AVX2 register; each column's arithmetic is independent and identical to this scalar form). */
-static void gv5_kernel(const uint8_t *code, long rows, long cols, long groups_padded, const double *v, int cores,
-                       double *ans) {
+/* genoVector kernel for up to VATONCE = 4 right-hand side columns per pass over the code matrix (the reference interleaves VatOnce = 4 columns in
+ * one AVX2 register, 5codesIntern.h:130-266; each column's arithmetic is independent and identical to the one-column scalar form, so the
+ * results do not depend on how the columns are grouped -- checked bit for bit against the reference library in tests/test_oracle.py). */
+#define GV5_VATONCE 4
+static void gv5_kernel(const uint8_t *code, long rows, long cols, long groups_padded, const double *const *v, int nv, int cores,
+                       double *const *ans) {
   const long colsCpB = div_geq(cols, 5);
   const long colBlocks = div_geq(colsCpB, 4);
   long blockSliceLen = div_geq(colBlocks, (long)cores * 5); /* coreFactor 5: 5codesIntern.h:54 */
@@ -206,35 +208,39 @@ static void gv5_kernel(const uint8_t *code, long rows, long cols, long groups_pa
   const long sliceLen = blockSliceLen * 4;
   const long rest = (colBlocks - blockSliceLen * (blocks - 1)) * 4;
   (void)groups_padded;
-  /* hash tables */
-  double *F = (double *)calloc((size_t)colBlocks * 4 * 243, sizeof(double));
+  /* hash tables: [group][column q][243] so that the nv tables of a group are neighbours */
+  const size_t fstride = (size_t)nv * 243;
+  double *F = (double *)calloc((size_t)colBlocks * 4 * fstride, sizeof(double));
 #pragma omp parallel for schedule(static) num_threads(cores)
   for (long i = 0; i < colsCpB; i++) {
-    long double x[5] = {0, 0, 0, 0, 0};
-    long have = (i < colsCpB - 1) ? 5 : cols - (colsCpB - 1) * 5;
-    for (long k = 0; k < have; k++) x[k] = (long double)v[i * 5 + k];
-    double *hash = F + i * 243;
-    for (int i4 = 0; i4 < 3; i4++) {
-      long double f4 = (long double)i4 * x[4];
-      for (int i3 = 0; i3 < 3; i3++) {
-        long double f3 = f4 + (long double)i3 * x[3];
-        for (int i2 = 0; i2 < 3; i2++) {
-          long double f2 = f3 + (long double)i2 * x[2];
-          for (int i1 = 0; i1 < 3; i1++) {
-            long double f1 = f2 + (long double)i1 * x[1];
-            int V0 = 3 * (3 * (3 * (3 * i4 + i3) + i2) + i1);
-            long double f0 = f1;
-            hash[V0] = (double)f0;
-            f0 += x[0];
-            hash[V0 + 1] = (double)f0;
-            hash[V0 + 2] = (double)(f0 + x[0]);
+    for (int q = 0; q < nv; q++) {
+      long double x[5] = {0, 0, 0, 0, 0};
+      long have = (i < colsCpB - 1) ? 5 : cols - (colsCpB - 1) * 5;
+      for (long k = 0; k < have; k++) x[k] = (long double)v[q][i * 5 + k];
+      double *hash = F + (size_t)i * fstride + (size_t)q * 243;
+      for (int i4 = 0; i4 < 3; i4++) {
+        long double f4 = (long double)i4 * x[4];
+        for (int i3 = 0; i3 < 3; i3++) {
+          long double f3 = f4 + (long double)i3 * x[3];
+          for (int i2 = 0; i2 < 3; i2++) {
+            long double f2 = f3 + (long double)i2 * x[2];
+            for (int i1 = 0; i1 < 3; i1++) {
+              long double f1 = f2 + (long double)i1 * x[1];
+              int V0 = 3 * (3 * (3 * (3 * i4 + i3) + i2) + i1);
+              long double f0 = f1;
+              hash[V0] = (double)f0;
+              f0 += x[0];
+              hash[V0 + 1] = (double)f0;
+              hash[V0 + 2] = (double)(f0 + x[0]);
+            }
           }
         }
       }
     }
   }
-  /* main loop: one partial vector per slice (+1 zero slab used by the tree) */
-  double *Tmp = (double *)calloc((size_t)(blocks + 1) * rows, sizeof(double));
+  /* main loop: one partial vector per slice and column (+1 zero slab per column used by the tree) */
+  const size_t tstride = (size_t)(blocks + 1) * rows;
+  double *Tmp = (double *)calloc((size_t)nv * tstride, sizeof(double));
   const long RoughRowChunk = 35000;
   long rowBlocks = rows / RoughRowChunk; if (rowBlocks < 1) rowBlocks = 1;
   const long RowChunk = div_geq(rows, rowBlocks);
@@ -242,19 +248,34 @@ static void gv5_kernel(const uint8_t *code, long rows, long cols, long groups_pa
     long bEnd = bStart + RowChunk < rows ? bStart + RowChunk : rows;
 #pragma omp parallel for schedule(static) num_threads(cores)
     for (long Cb = 0; Cb < blocks; Cb++) {
-      const double *ff = F + sliceLen * Cb * 243;
-      double *t = Tmp + rows * Cb;
+      const double *ff = F + (size_t)sliceLen * Cb * fstride;
       const uint8_t *c = code + rows * sliceLen * Cb;
       long nrCols = Cb == blocks - 1 ? rest : sliceLen;
       for (long i = 0; i < nrCols; i += 4) {
         const uint8_t *p0 = c + (i + 0) * rows, *p1 = c + (i + 1) * rows, *p2 = c + (i + 2) * rows, *p3 = c + (i + 3) * rows;
-        const double *f0 = ff + (i + 0) * 243, *f1 = ff + (i + 1) * 243, *f2 = ff + (i + 2) * 243, *f3 = ff + (i + 3) * 243;
-        for (long b = bStart; b < bEnd; b++) t[b] += (f0[p0[b]] + f1[p1[b]]) + (f2[p2[b]] + f3[p3[b]]);
+        const double *g0 = ff + (size_t)(i + 0) * fstride, *g1 = ff + (size_t)(i + 1) * fstride, *g2 = ff + (size_t)(i + 2) * fstride, *g3 = ff + (size_t)(i + 3) * fstride;
+        if (nv == GV5_VATONCE) {   /* the code bytes are loaded once for the four columns */
+          double *t0 = Tmp + rows * Cb, *t1 = t0 + tstride, *t2 = t1 + tstride, *t3 = t2 + tstride;
+          for (long b = bStart; b < bEnd; b++) {
+            const int c0 = p0[b], c1 = p1[b], c2 = p2[b], c3 = p3[b];
+            t0[b] += (g0[c0] + g1[c1]) + (g2[c2] + g3[c3]);
+            t1[b] += (g0[243 + c0] + g1[243 + c1]) + (g2[243 + c2] + g3[243 + c3]);
+            t2[b] += (g0[486 + c0] + g1[486 + c1]) + (g2[486 + c2] + g3[486 + c3]);
+            t3[b] += (g0[729 + c0] + g1[729 + c1]) + (g2[729 + c2] + g3[729 + c3]);
+          }
+        } else {
+          for (int q = 0; q < nv; q++) {
+            double *t = Tmp + (size_t)q * tstride + rows * Cb;
+            const double *f0 = g0 + q * 243, *f1 = g1 + q * 243, *f2 = g2 + q * 243, *f3 = g3 + q * 243;
+            for (long b = bStart; b < bEnd; b++) t[b] += (f0[p0[b]] + f1[p1[b]]) + (f2[p2[b]] + f3[p3[b]]);
+          }
+        }
       }
     }
   }
-  /* 4-way tree sum of the slices */
-  {
+  /* 4-way tree sum of the slices, per column */
+  for (int q = 0; q < nv; q++) {
+    double *T = Tmp + (size_t)q * tstride;
     const long blocksXrows = blocks * rows;
     long level = rows, tmpCols = blocks;
     while (tmpCols > 1) {
@@ -262,15 +283,15 @@ static void gv5_kernel(const uint8_t *code, long rows, long cols, long groups_pa
       for (long k = 0; k < tmpC4; k++) {
         long kS = k * 4;
         long o0 = (kS + 0) * level, o1 = (kS + 1) * level, o2 = (kS + 2) * level, o3 = (kS + 3) * level;
-        double *t0 = Tmp + (o0 < blocksXrows ? o0 : blocksXrows), *t1 = Tmp + (o1 < blocksXrows ? o1 : blocksXrows);
-        double *t2 = Tmp + (o2 < blocksXrows ? o2 : blocksXrows), *t3 = Tmp + (o3 < blocksXrows ? o3 : blocksXrows);
+        double *t0 = T + (o0 < blocksXrows ? o0 : blocksXrows), *t1 = T + (o1 < blocksXrows ? o1 : blocksXrows);
+        double *t2 = T + (o2 < blocksXrows ? o2 : blocksXrows), *t3 = T + (o3 < blocksXrows ? o3 : blocksXrows);
         for (long j = 0; j < rows; j++) t0[j] = (t0[j] + t1[j]) + (t2[j] + t3[j]);
       }
       level *= 4;
       tmpCols = div_geq(tmpCols, 4);
     }
+    for (long bb = 0; bb < rows; bb++) ans[q][bb] = T[bb];
   }
-  for (long b = 0; b < rows; b++) ans[b] = Tmp[b];
   free(F); free(Tmp);
 }
 
@@ -280,10 +301,16 @@ void oracle5_dgemm(void *hh, int trans, int centered, long n, const double *B, l
   const uint8_t *code = trans ? h->code_T : h->code_N;
   const long groups = trans ? h->groups_T : h->groups_N;
   memset(C, 0, (size_t)ldc * n * sizeof(double)); /* 5codesIntern.h:67 */
+  for (long j0 = 0; j0 < n; j0 += GV5_VATONCE) {
+    const int nv = (int)(n - j0 < GV5_VATONCE ? n - j0 : GV5_VATONCE);
+    const double *vv[GV5_VATONCE];
+    double *aa[GV5_VATONCE];
+    for (int q = 0; q < nv; q++) { vv[q] = B + (j0 + q) * ldb; aa[q] = C + (j0 + q) * ldc; }
+    gv5_kernel(code, rows, cols, groups, vv, nv, h->cores, aa);
+  }
   for (long j = 0; j < n; j++) {
     const double *v = B + j * ldb;
     double *a = C + j * ldc;
-    gv5_kernel(code, rows, cols, groups, v, h->cores, a);
     if (centered) { /* Vector.matrix.D.cc:101-114 and :145-175 with meanV=meanSxI=false, RowMeans */
       if (trans) {
         long double s = 0.0L;
