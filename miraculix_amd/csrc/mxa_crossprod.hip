@@ -239,9 +239,12 @@ struct FragI8 { v4i lo, hi; };
 template <bool I8> struct XFrag { using type = v4i; using acc = v16f; };
 template <> struct XFrag<true> { using type = FragI8; using acc = v16i; };
 
+// second meeting point of a gang (round 4 experiment, MXA_XPROD_GANG_MID=1): the tiles of a gang start together but drift apart inside a 2.6 ms tile;
+// half way through the K range every member adds to the gang's counter and waits (bounded) for the others, so that the second half streams in step again
+struct GangMid { int *ctr; int target; unsigned ticks; int parts; int stride; };   // parts - 1 meetings inside a tile, meeting q uses ctr[(q - 1) * stride]
 template <bool DIAG, int EXP, bool I8, int POST>
 __device__ __forceinline__ void xprod_tile(const uint8_t *__restrict__ X, long nslabs, int stages, const int4 t, size_t tile_index, long n, double *__restrict__ ans,
-                                           long ld, long c0, unsigned long long *__restrict__ diag, const XPost &post) {
+                                           long ld, long c0, unsigned long long *__restrict__ diag, const XPost &post, const GangMid gm = GangMid{nullptr, 0, 0, 1, 0}) {
   using FragT = typename XFrag<I8>::type;
   using AccT = typename XFrag<I8>::acc;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -351,7 +354,20 @@ __device__ __forceinline__ void xprod_tile(const uint8_t *__restrict__ X, long n
       __builtin_amdgcn_sched_barrier(0);                                                                                                   \
     }                                                                                                                                      \
   }
-  for (int s = 0; s < stages; s++) {
+  // two halves of the K range with the gang's second meeting between them (gm.ctr == nullptr: one pass); the stage loop itself stays one basic block
+  const int nparts = gm.ctr ? gm.parts : 1;
+  for (int part = 0; part < nparts; part++) {
+  if (part > 0) {
+    if (threadIdx.x == 0) {
+      int *c = gm.ctr + (size_t)(part - 1) * gm.stride;
+      __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long tm = __builtin_amdgcn_s_memrealtime();
+      while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gm.target && __builtin_amdgcn_s_memrealtime() - tm < gm.ticks) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+  }
+  const int s_lo = (int)((long)stages * part / nparts), s_hi = (int)((long)stages * (part + 1) / nparts);
+  for (int s = s_lo; s < s_hi; s++) {
     // stage start: stage s+1 must have landed -- exactly (NB-2) stages' DMAs may stay in flight (one stage's 4 units are issued per stage,
     // always); this wave's reads of buffer s%NB were issued a K-step ago and are complete; after the barrier that buffer is refilled
     if (EXP != 2) {
@@ -366,6 +382,7 @@ __device__ __forceinline__ void xprod_tile(const uint8_t *__restrict__ X, long n
     MXA_F4_KSTEP(fa0, fb0, wa1, wb1, fa1, fb1, wa0, wb0, nxt, true)
     // t = 2s+1: MFMAs F[1]; unpack W[0] (K-step 0 of stage s+1) -> F[0]; read K-step 1 of stage s+1 -> W[1]
     MXA_F4_KSTEP(fa1, fb1, wa0, wb0, fa0, fb0, wa1, wb1, nxt + 8, false)
+  }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant refills of the last stages have landed before the ring becomes scratch
 #undef MXA_F4_KSTEP
@@ -411,7 +428,7 @@ constexpr unsigned long long kGangStartTicks = 200000;    // 2 ms for the whole 
 template <bool I8, int POST>
 __global__ void __launch_bounds__(256, 1)
 k_crossprod_gang(const uint8_t *__restrict__ X, long nslabs, int stages, const int4 *__restrict__ tiles, int slots_per_xcd, long n, double *__restrict__ ans,
-                 long ld, long c0, XPost post, int *__restrict__ gang, unsigned join_ticks, int xcc_mask) {
+                 long ld, long c0, XPost post, int *__restrict__ gang, unsigned join_ticks, int xcc_mask, int *__restrict__ mid, int mid_parts) {
   __shared__ int sh_val;
   const int xcc = hw_xcc_id() & xcc_mask;             // mask 7; the tests narrow it to emulate a chip that populates fewer XCDs (the other lists are then stolen)
   if (threadIdx.x == 0) {
@@ -425,7 +442,7 @@ k_crossprod_gang(const uint8_t *__restrict__ X, long nslabs, int stages, const i
   __syncthreads();
   const int P = max(1, sh_val);                       // workgroups of this XCD = gang size
   __syncthreads();
-  __shared__ int sh_list;
+  __shared__ int sh_list, sh_own;
   int phase = 0;                                      // lane 0 only: 0 = the own XCD's list (in gangs), 1..7 = the other XCDs' lists once the own one is empty
   for (;;) {                                          // (no waiting there: correctness must not depend on which XCDs the hardware populated, e.g. a partitioned chip)
     if (threadIdx.x == 0) {
@@ -442,14 +459,24 @@ k_crossprod_gang(const uint8_t *__restrict__ X, long nslabs, int stages, const i
         while (__hip_atomic_load(gang + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && __builtin_amdgcn_s_memrealtime() - t0 < join_ticks)
           __builtin_amdgcn_s_sleep(4);
       }
-      sh_val = slot; sh_list = y;
+      sh_val = slot; sh_list = y; sh_own = (slot >= 0 && phase == 0) ? 1 : 0;
     }
     __syncthreads();
     const int slot = __builtin_amdgcn_readfirstlane(sh_val), list = __builtin_amdgcn_readfirstlane(sh_list);
     if (slot < 0) break;                               // wave-uniform: every list is empty, the whole workgroup leaves
     const int4 tv = tiles[(size_t)8 * slot + list];
     const int4 t = make_int4(__builtin_amdgcn_readfirstlane(tv.x), __builtin_amdgcn_readfirstlane(tv.y), __builtin_amdgcn_readfirstlane(tv.z), 0);   // scalar: the DMA bases live in SGPRs
-    if (t.z) xprod_tile<false, 0, I8, POST>(X, nslabs, stages, t, 0, n, ans, ld, c0, nullptr, post);
+    // second meeting point (mid != nullptr): the members of a gang of the own list meet again half way through the tile
+    GangMid gm{nullptr, 0, 0, 1, 0};
+    if (mid && __builtin_amdgcn_readfirstlane(sh_own)) {
+      // (everything the stage loop's bounds depend on must be provably wave-uniform: the DMA bases and LDS addresses live in SGPRs)
+      const int Pu = __builtin_amdgcn_readfirstlane(P), g = slot / Pu, members = __builtin_amdgcn_readfirstlane(min((g + 1) * Pu, slots_per_xcd) - g * Pu);
+      const int idx = __builtin_amdgcn_readfirstlane(xcc * slots_per_xcd + g);
+      gm = GangMid{mid + idx, members, join_ticks, mid_parts, 8 * slots_per_xcd};
+      if (!t.z && threadIdx.x == 0)   // a padding entry never reaches the meetings: counted here
+        for (int q = 0; q + 1 < mid_parts; q++) __hip_atomic_fetch_add(gm.ctr + (size_t)q * gm.stride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (t.z) xprod_tile<false, 0, I8, POST>(X, nslabs, stages, t, 0, n, ans, ld, c0, nullptr, post, gm);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores of the epilogue: the DMA bookkeeping of the next tile starts from an empty counter
     __syncthreads();                                   // ... and the LDS scratch of the epilogue is free (sh_val / sh_list are rewritten only after this barrier)
   }
@@ -550,8 +577,9 @@ struct XBuf {
 }  // namespace
 
 // one launch over a tile list with either engine (f4: FP4 MFMA, else int8 MFMA); diag_out: in-kernel clocks of the DIAG instantiation
+// gang_mid_capacity: ints available behind d_gang[32] for the per-gang counters of the second meeting point (0: none)
 static int launch_tiles(bool f4, size_t ntiles, hipStream_t s, const uint8_t *d_X, long nslabs, int stages, const int4 *d_tiles, long rows, double *d_ans, long ld,
-                        long c0, unsigned long long *d_diag, int post_kind = 0, const XPost &post = XPost(), int *d_gang = nullptr) {
+                        long c0, unsigned long long *d_diag, int post_kind = 0, const XPost &post = XPost(), int *d_gang = nullptr, size_t gang_mid_capacity = 0) {
   static unsigned long long m2 = 0, m3 = 0;   // per-device function attributes
   if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<false>), kF4Lds, &m2) || ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true>), kF4Lds, &m3)) return 1;
   const dim3 grid((unsigned)ntiles), block(256);
@@ -571,13 +599,22 @@ static int launch_tiles(bool f4, size_t ntiles, hipStream_t s, const uint8_t *d_
     const int slots = (int)(ntiles / 8);
     const dim3 pgrid((unsigned)std::max(8, std::min<int>(cus, (int)ntiles)));
     MXA_HIP(hipMemsetAsync(d_gang, 0, sizeof(int) * kGangCtrs, s));
+    // second meeting point (experiment): one counter per gang and XCD list, behind the 17 control counters when the caller's buffer has room for them
+    // MXA_XPROD_GANG_MID = number of parts a tile's K range is cut into (meetings = parts - 1): 0 / 1 none, 2 (default) one meeting half way through
+    const char *e_mid = getenv("MXA_XPROD_GANG_MID");
+    const int mid_parts = std::max(1, std::min(8, e_mid ? atoi(e_mid) : 2));
+    int *d_mid = nullptr;
+    if (mid_parts > 1 && gang_mid_capacity >= (size_t)8 * slots * (mid_parts - 1)) {
+      d_mid = d_gang + 32;
+      MXA_HIP(hipMemsetAsync(d_mid, 0, sizeof(int) * (size_t)8 * slots * (mid_parts - 1), s));
+    }
     static unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0;
     static const int xcc_mask = [] { const char *e = getenv("MXA_XPROD_GANG_XCC_MASK"); return e ? atoi(e) & 7 : 7; }();
     static const unsigned join_ticks = [] { const char *e = getenv("MXA_XPROD_GANG_US"); return e ? (unsigned)std::max(0, atoi(e)) * 100u : (unsigned)kGangJoinTicks; }();
 #define MXA_GANG_LAUNCH(I8, POST, MASK)                                                                                                          \
     {                                                                                                                                            \
       if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_gang<I8, POST>), kF4Lds, &MASK)) return 1;                                   \
-      hipLaunchKernelGGL((k_crossprod_gang<I8, POST>), pgrid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, slots, rows, d_ans, ld, c0, post, d_gang, join_ticks, xcc_mask); \
+      hipLaunchKernelGGL((k_crossprod_gang<I8, POST>), pgrid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, slots, rows, d_ans, ld, c0, post, d_gang, join_ticks, xcc_mask, d_mid, mid_parts); \
     }
     if (f4) { if (post_kind == 1) MXA_GANG_LAUNCH(false, 1, g1) else if (post_kind == 2) MXA_GANG_LAUNCH(false, 2, g2) else MXA_GANG_LAUNCH(false, 0, g0) }
     else { if (post_kind == 1) MXA_GANG_LAUNCH(true, 1, g4) else if (post_kind == 2) MXA_GANG_LAUNCH(true, 2, g5) else MXA_GANG_LAUNCH(true, 0, g3) }
@@ -662,7 +699,8 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
   static const int gang_order = [] { const char *e = getenv("MXA_XPROD_GANG_ORDER"); return e ? atoi(e) : 1; }();   // 0: the 8 x 8 super-tiles (A/B)
   const bool xcd_lists = gang_order ? gang_order_tiles(tiles) : xcd_order_tiles(tiles, nb, 8);
   XBuf d_tiles, d_diag, d_gang;
-  if (d_gang.alloc(sizeof(int) * kGangCtrs)) return 1;
+  const size_t mid_cap = 7 * (tiles.size() + 64);      // >= 8 lists x slots per list x up to 7 meetings per tile
+  if (d_gang.alloc(sizeof(int) * (32 + mid_cap))) return 1;
   if (d_tiles.alloc(tiles.size() * sizeof(int4))) return 1;
   MXA_HIP(hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, s));
   XEvent e0, e1;
@@ -671,7 +709,7 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
   if (diag_on && d_diag.alloc(16 * tiles.size())) return 1;
   MXA_HIP(hipEventRecord(e0.e, s));
   if (launch_tiles(f4, tiles.size(), s, d_X, nslabs, stages, (const int4 *)d_tiles.p, rows, d_ans, ld, c_begin, (unsigned long long *)d_diag.p, post ? post_kind : 0, post ? *post : XPost(),
-                   xcd_lists ? (int *)d_gang.p : nullptr)) return 1;
+                   xcd_lists ? (int *)d_gang.p : nullptr, mid_cap)) return 1;
   MXA_HIP(hipEventRecord(e1.e, s));
   MXA_HIP(hipStreamSynchronize(s));   // tiles vector / d_tiles lifetime
   if (diag_on) {   // diagnostic instantiation: in-kernel clock and cycles per stage
@@ -718,7 +756,9 @@ static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch
   }
   first[(size_t)nchunks] = tiles.size();
   XBuf d_tiles, d_gang;
-  if (d_tiles.alloc(tiles.size() * sizeof(int4)) || d_gang.alloc(sizeof(int) * kGangCtrs)) return 1;
+  size_t mid_cap = 0;   // counters of the gangs' meetings inside a tile: sized for the longest slab list
+  for (int c = 0; c < nchunks; c++) mid_cap = std::max(mid_cap, 7 * (first[(size_t)c + 1] - first[(size_t)c] + 64));
+  if (d_tiles.alloc(tiles.size() * sizeof(int4)) || d_gang.alloc(sizeof(int) * (32 + mid_cap))) return 1;
   MXA_HIP(hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, s));
   std::vector<XEvent> ev((size_t)nchunks);
   int dev = 0;
@@ -763,7 +803,7 @@ static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch
   if (hipEventRecord(e0.e, s) != hipSuccess) rc = 1;
   for (int c = 0; c < nchunks && !rc; c++) {
     const size_t cnt = first[(size_t)c + 1] - first[(size_t)c];
-    if (launch_tiles(f4, cnt, s, d_X, nslabs, stages, (const int4 *)d_tiles.p + first[(size_t)c], rows, d_ans, rows, 0L, nullptr, post ? post_kind : 0, post ? *post : XPost(), chunk_xcd[(size_t)c] ? (int *)d_gang.p : nullptr) || hipEventRecord(ev[c].e, s) != hipSuccess) { rc = 1; break; }
+    if (launch_tiles(f4, cnt, s, d_X, nslabs, stages, (const int4 *)d_tiles.p + first[(size_t)c], rows, d_ans, rows, 0L, nullptr, post ? post_kind : 0, post ? *post : XPost(), chunk_xcd[(size_t)c] ? (int *)d_gang.p : nullptr, mid_cap) || hipEventRecord(ev[c].e, s) != hipSuccess) { rc = 1; break; }
     launched.store(c + 1);
   }
   if (rc) abort_copy = true;
@@ -823,7 +863,9 @@ static int crossprod_to_host_ring(const uint8_t *d_X, long k, long rows, size_t 
     tiles.insert(tiles.end(), part.begin(), part.end());
   }
   first[(size_t)nchunks] = tiles.size();
-  if (d_tiles.alloc(tiles.size() * sizeof(int4)) || d_gang.alloc(sizeof(int) * kGangCtrs)) return 1;
+  size_t mid_cap = 0;   // counters of the gangs' meetings inside a tile: sized for the longest slab list
+  for (int c = 0; c < nchunks; c++) mid_cap = std::max(mid_cap, 7 * (first[(size_t)c + 1] - first[(size_t)c] + 64));
+  if (d_tiles.alloc(tiles.size() * sizeof(int4)) || d_gang.alloc(sizeof(int) * (32 + mid_cap))) return 1;
   MXA_HIP(hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, s));
   std::vector<XEvent> ev((size_t)nchunks);
   int dev = 0;
@@ -877,7 +919,7 @@ static int crossprod_to_host_ring(const uint8_t *d_X, long k, long rows, size_t 
     const size_t cnt = first[(size_t)c + 1] - first[(size_t)c];
     const long col0 = (long)c * tcols * kXT;
     if (launch_tiles(f4, cnt, s, d_X, nslabs, stages, (const int4 *)d_tiles.p + first[(size_t)c], rows, (double *)ring[c % kRing].p, rows, col0, nullptr, post ? post_kind : 0, post ? *post : XPost(),
-                     chunk_xcd[(size_t)c] ? (int *)d_gang.p : nullptr) || hipEventRecord(ev[c].e, s) != hipSuccess) { rc = 1; break; }
+                     chunk_xcd[(size_t)c] ? (int *)d_gang.p : nullptr, mid_cap) || hipEventRecord(ev[c].e, s) != hipSuccess) { rc = 1; break; }
     launched.store(c + 1);
   }
   if (rc) abort_copy = true;

@@ -109,11 +109,13 @@ def test_fp4_threshold_boundaries_bit_exact(plink, k_below, k_above):
 
 
 @pytest.mark.parametrize("env", [{"MXA_XPROD_GANG": "0"}, {"MXA_XPROD_GANG": "2"}, {"MXA_XPROD_GANG": "2", "MXA_XPROD_GANG_XCC_MASK": "0"}, {"MXA_XPROD_GANG": "2", "MXA_XPROD_GANG_XCC_MASK": "1"},
-                                 {"MXA_XPROD_GANG": "2", "MXA_XPROD_GANG_US": "0"}])
+                                 {"MXA_XPROD_GANG": "2", "MXA_XPROD_GANG_US": "0"}, {"MXA_XPROD_GANG": "2", "MXA_XPROD_GANG_MID": "1"},
+                                 {"MXA_XPROD_GANG": "2", "MXA_XPROD_GANG_MID": "1", "MXA_XPROD_GANG_XCC_MASK": "1"}, {"MXA_XPROD_GANG": "2", "MXA_XPROD_GANG_MID": "1", "MXA_XPROD_GANG_US": "0"}])
 def test_gang_synchronised_kernel_does_not_depend_on_the_xcd_population(env):
     """k_crossprod_gang (one resident workgroup per CU, the workgroups of an XCD advance through that XCD's tile list in step): the result must not
     depend on which XCDs the hardware populated -- with the XCD id masked to one or two values the other lists are stolen --, on the join timeout,
-    or on the kernel form at all (MXA_XPROD_GANG=0: one workgroup per tile; 2: the gang form also for launches too short for it to pay, like this one).  The knobs are read once per process: a child process per setting;
+    or on the kernel form at all (MXA_XPROD_GANG=0: one workgroup per tile; 2: the gang form also for launches too short for it to pay, like this one;
+    MXA_XPROD_GANG_MID=1: the round-4 experiment of a second meeting point half way through every tile).  The knobs are read once per process: a child process per setting;
     2304 rows = 45 upper tiles... too few for the per-XCD lists, so 6000 rows (300 tiles, lists of 64 slots) and both engines."""
     import os
     import subprocess

@@ -85,13 +85,14 @@ __global__ void __launch_bounds__(256, 1) k_probe(const char *__restrict__ src, 
           wait_ticks += __builtin_amdgcn_s_memrealtime() - t0;
           // all partials of the XCD for group h: P x 32 doubles; lane l < 32 sums element l over the members in fixed order
           if (lane < 32) {
-            double s = 0.0;
+            // 32 independent agent-scope loads (global_load_dwordx2 sc1), all in flight before the first use; fixed summation order
             const double *p0 = part + (((size_t)xcd * 8 + (size_t)(h & 7)) * 64) * 32 + lane;
-            for (int m = 0; m < P; m++) {
-              double v;
-              asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p0 + (size_t)m * 32) : "memory");
-              s += v;
-            }
+            double v[32];
+#pragma unroll
+            for (int m = 0; m < 32; m++) v[m] = __hip_atomic_load(p0 + (size_t)(m < P ? m : 0) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < 32; m++) s += m < P ? v[m] : 0.0;
             s_sum[lane] = s;
           }
         }
