@@ -732,7 +732,7 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
 // [0, 256*i1) of M are final: a helper thread copies each finished column slab to the host on its own non-blocking stream while
 // the next chunk computes (at config 3 the 80 GB device-to-host copy is as long as the compute).
 static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch, double *d_ans, double *h_ans, hipStream_t s, bool f4, int post_kind = 0,
-                             const XPost *post = nullptr) {
+                             const XPost *post = nullptr, const HostPrefault *pf = nullptr) {
   const int nb = (int)((rows + kXT - 1) / kXT);
   const int stages = (int)((k + kXStageK - 1) / kXStageK);
   const long nslabs = (long)(pitch / kXStageBytes);
@@ -790,6 +790,7 @@ static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch
       const long w = col1 - col0, a = col0 + w * t / kCopiers, b = col0 + w * (t + 1) / kCopiers;
       if (b <= a) continue;
       const size_t off = (size_t)a * rows, cnt = (size_t)(b - a) * rows;
+      if (pf) { const auto tp = std::chrono::steady_clock::now(); pf->wait_for(h_ans + off + cnt); clog[t].wait_s += since(tp); }
       const auto tc = std::chrono::steady_clock::now();
       if (hipMemcpyAsync(h_ans + off, d_ans + off, cnt * sizeof(double), hipMemcpyDeviceToHost, cs[t].s) != hipSuccess || hipStreamSynchronize(cs[t].s) != hipSuccess) { copy_err = 1; return; }
       const double dt = since(tc);
@@ -830,7 +831,8 @@ static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch
 // tile (i, j >= i) that touches it: its direct image when i lies in the panel, its mirror image when j does), computed by the same kernels, and leaves
 // through the four copier threads while the next slab is computed.  Every off-diagonal tile is computed twice (once per image): twice the arithmetic of
 // the triangular launch -- taken only where the call is bound by the copy anyway (the caller compares the two estimates).
-static int crossprod_to_host_ring(const uint8_t *d_X, long k, long rows, size_t pitch, double *h_ans, hipStream_t s, bool f4, int post_kind, const XPost *post) {
+static int crossprod_to_host_ring(const uint8_t *d_X, long k, long rows, size_t pitch, double *h_ans, hipStream_t s, bool f4, int post_kind, const XPost *post,
+                                  const std::function<void()> &all_allocated, const HostPrefault *pf) {
   const int nb = (int)((rows + kXT - 1) / kXT);
   const int stages = (int)((k + kXStageK - 1) / kXStageK);
   const long nslabs = (long)(pitch / kXStageBytes);
@@ -895,6 +897,7 @@ static int crossprod_to_host_ring(const uint8_t *d_X, long k, long rows, size_t 
       if (b > a) {
         const double *src = (const double *)ring[c % kRing].p + (size_t)a * rows;
         const size_t cnt = (size_t)(b - a) * rows;
+        if (pf) { const auto tp = std::chrono::steady_clock::now(); pf->wait_for(h_ans + (size_t)(col0 + a) * rows + cnt); clog[t].wait_s += since(tp); }   // the destination pages exist: no faults inside the copy
         const auto tc = std::chrono::steady_clock::now();
         if (hipMemcpyAsync(h_ans + (size_t)(col0 + a) * rows, src, cnt * sizeof(double), hipMemcpyDeviceToHost, cs[t].s) != hipSuccess || hipStreamSynchronize(cs[t].s) != hipSuccess) { copy_err = 1; abort_copy = true; return; }
         const double dt = since(tc);
@@ -904,6 +907,7 @@ static int crossprod_to_host_ring(const uint8_t *d_X, long k, long rows, size_t 
       copied[(size_t)c].fetch_add(1);
     }
   };
+  all_allocated();   // every device buffer, stream and event of this call exists: the background population of the destination pages may start (mxa_hostmem.h)
   std::vector<std::thread> copiers;
   for (int t = 0; t < kCopiers; t++) copiers.emplace_back(copy_loop, t);
   int rc = 0;
@@ -1128,8 +1132,9 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
   if (need > free_b) { set_error(12, "snp_multiply_gpu: not enough device memory: required %zu GB, free %zu GB", need >> 30, free_b >> 30); return 1; }
   // a host result in fresh memory (crossproduct.jl:56 `M = zeros(...)`): its pages are populated in the background while the tiles are computed, so that
   // the copies do not pay the first-touch faults (mxa_hostmem.h).  Joined when this returns.
-  // Started only AFTER the operand has been allocated and staged: twelve threads inside madvise slow a concurrent hipMalloc (12.5 GB: 1.2-1.3 s instead
-  // of < 0.06 s) and the staged pageable upload (1.55 s instead of 0.24 s) by more than the head start is worth (profiles/r04_crossprod_host_abi_c3.txt).
+  // Started only AFTER the operand has been staged and EVERY device buffer of the call has been allocated: twelve threads inside madvise slow a concurrent
+  // hipMalloc (12.5 GB: 1.2-1.3 s instead of < 0.06 s; the 3 GiB ring: 1.7 s) and the staged pageable upload (1.55 s instead of 0.24 s) by far more than
+  // the head start is worth (profiles/r04_crossprod_host_abi_c3.txt).
   HostPrefault prefault;
   struct PrefaultReport {
     HostPrefault &p;
@@ -1179,7 +1184,8 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
     }
   }
   clk.mark("operand staged (upload + k_xstage)");
-  if (!out_dev) prefault.start(ans, abytes);
+  bool prefault_started = false;
+  auto start_prefault = [&]() { if (!out_dev && !prefault_started) { prefault_started = true; prefault.start(ans, abytes); } };
   // engine: FP4 while the fp32 accumulator is provably exact (sum z z' < 2^24), int8 beyond (MXA_XPROD_ENGINE=i8 / f4 forces one, for A/B runs)
   int has3 = 1;
   MXA_HIP(hipMemcpyAsync(&has3, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1209,6 +1215,7 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
     d_ans = (double *)d_out.p;
     if (upper_only) MXA_HIP(hipMemsetAsync(d_ans, 0, abytes, s));   // the untouched part travels back as zeros
     clk.mark("device result buffer allocated");
+    start_prefault();
   } else if (!out_dev) d_ans = nullptr;
   const bool whole = c_begin == 0 && c_end == rows && !upper_only;
   // GRM / LD: the element-wise map is fused into the crossproduct epilogue (whole matrix; MXA_XPROD_FUSED_POST=0 keeps the three extra passes over
@@ -1252,7 +1259,7 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
     post_kind = post;
   }
   if (use_ring && (!post || post_kind)) {
-    const int rc = crossprod_to_host_ring((const uint8_t *)d_X.p, k, rows, pitch, ans, s, f4, post_kind, &xp);
+    const int rc = crossprod_to_host_ring((const uint8_t *)d_X.p, k, rows, pitch, ans, s, f4, post_kind, &xp, start_prefault, &prefault);
     clk.mark("slabs computed and copied out (ring)");
     d_X.release();
     clk.mark("device buffers released");
@@ -1261,9 +1268,10 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
   if (use_ring) {   // unfused post-processing needs the whole matrix on the device after all
     if (d_out.alloc(abytes)) return 1;
     d_ans = (double *)d_out.p;
+    start_prefault();
   }
   if (!out_dev && (!post || post_kind) && whole && ld == rows && !getenv("MXA_XPROD_NO_PIPELINE")) {
-    const int rc = crossprod_to_host((const uint8_t *)d_X.p, k, rows, pitch, d_ans, ans, s, f4, post_kind, &xp);
+    const int rc = crossprod_to_host((const uint8_t *)d_X.p, k, rows, pitch, d_ans, ans, s, f4, post_kind, &xp, &prefault);
     clk.mark("tiles computed, slabs copied out");
     d_out.release(); d_X.release();
     clk.mark("device buffers released");

@@ -47,8 +47,9 @@ class HostPrefault {
     next_.store(0);
     const int hw = (int)std::thread::hardware_concurrency();
     const int n = std::max(1, std::min(want, hw > 6 ? hw - 5 : 1));   // leave room for the copier threads and the caller
-    for (int t = 0; t < n; t++) th_.emplace_back([this] { work(); });
     threads_ = n;
+    finished_.store(0);
+    for (int t = 0; t < n; t++) th_.emplace_back([this] { work(); });
 #else
     (void)p; (void)bytes;
 #endif
@@ -56,6 +57,20 @@ class HostPrefault {
   void join() {
     for (auto &t : th_) if (t.joinable()) t.join();
     if (!th_.empty()) { seconds_ = std::chrono::duration<double>(t_done_ - t0_).count(); th_.clear(); }
+  }
+  // Blocks until every page below `end` has been populated (or nothing more will be: not started, finished, unsupported kernel).  A copier calls it before it
+  // writes a range: a memcpy that faults pages INSIDE the region the populating threads are working on crawls (the first 1 GiB slab of config 3 took 1.0-1.2 s
+  // that way, profiles/r04_crossprod_host_abi_c3.txt); behind them it runs at full speed.  Blocks are handed out in ascending order and a thread takes its
+  // next block only after finishing the current one, so everything below (next_ - threads) blocks is complete.
+  void wait_for(const void *end) const {
+    if (!threads_ || unsupported_.load()) return;
+    const uintptr_t e = std::min((uintptr_t)end, hi_);
+    for (;;) {
+      const size_t taken = next_.load();
+      const uintptr_t done = taken > (size_t)threads_ ? lo_ + (taken - (size_t)threads_) * kBlock : lo_;
+      if (done >= e || finished_.load() >= threads_ || unsupported_.load()) return;
+      std::this_thread::yield();
+    }
   }
   // after join(): seconds from start to the last populated block (0 when nothing ran), bytes populated, threads used, 1 if the kernel lacks the call
   double seconds() const { return seconds_; }
@@ -78,11 +93,13 @@ class HostPrefault {
       } else done_bytes_.fetch_add(len);
     }
     t_done_ = std::chrono::steady_clock::now();   // the last thread to finish leaves the latest stamp (benign race: timing only)
+    finished_.fetch_add(1);
 #endif
   }
   uintptr_t lo_ = 0, hi_ = 0;
   std::atomic<size_t> next_{0}, done_bytes_{0};
   std::atomic<bool> unsupported_{false};
+  std::atomic<int> finished_{0};
   std::vector<std::thread> th_;
   std::chrono::steady_clock::time_point t0_, t_done_;
   double seconds_ = 0.0;
