@@ -233,8 +233,8 @@ def measure_traffic(args):
                 return None, {"skipped": f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"}
             agg = collections.OrderedDict()
             for row in csv.DictReader(open(src[0])):
-                # the shipped instantiation only (MODE 2); the MODE 0 launch behind it is the range-guard fallback and returns at once
-                if re.search(r"k_gemm<\d+, ?\d+, ?2,", row["Kernel_Name"]) and row.get("Counter_Name", ctr) == ctr:
+                # the shipped instantiations only (MODE 2 / 3); the MODE 0 launch behind it is the range-guard fallback and returns at once
+                if re.search(r"k_gemm<\d+, ?\d+, ?[23],", row["Kernel_Name"]) and row.get("Counter_Name", ctr) == ctr:
                     agg[row["Dispatch_Id"]] = agg.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
             vals[ctr] = list(agg.values())
     except Exception as e:   # a profiler problem must not take the benchmark down
@@ -1040,7 +1040,7 @@ def main():
                          "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "GB per launch, measured by this run (two rocprofv3 --pmc child passes of the same workload)", "traffic_detail": traffic_detail,
                          "algorithmic_bytes_per_launch_GB": round((W.snps_loc / W.n_shards * ((indiv + 3) // 4) + 8.0 * (W.snps_loc / W.n_shards + indiv) * n) / 1e9, 3),
-                         "kernel": "k_gemm<8,8> (v_mfma_f64_4x4x4_4b_f64)", "launches": launches, "avg_launch_ms": round(avg_ms, 3)},
+                         "kernel": "k_gemm<8,8,3,TR> (v_mfma_f64_4x4x4_4b_f64; transposed-operand form: each product reads the copy whose rows are its K index)", "launches": launches, "avg_launch_ms": round(avg_ms, 3)},
         }
         if W.n_gpus > 1:
             slowest = max(per_rank["avg_k_gemm_launch_ms"]) if per_rank is not None else avg_ms
