@@ -196,7 +196,11 @@ void oracle5_free(void *hh) {
 /* genoVector kernel for up to VATONCE = 4 right-hand side columns per pass over the code matrix (the reference interleaves VatOnce = 4 columns in
  * one AVX2 register, 5codesIntern.h:130-266; each column's arithmetic is independent and identical to the one-column scalar form, so the
  * results do not depend on how the columns are grouped -- checked bit for bit against the reference library in tests/test_oracle.py). */
-#define GV5_VATONCE 4
+/* Columns per pass: 1.  Four per pass (the reference's VatOnce) is 1.5x faster on the build container's Xeon but 1.5x SLOWER for 'N' on the GPU
+ * hosts' EPYC 9575F (16 cores: N 1.22 s against 0.79 s on the 100k x 50k x 32 sample; T 1.80 s either way), where the baseline is timed. */
+#ifndef GV5_VATONCE
+#define GV5_VATONCE 1
+#endif
 static void gv5_kernel(const uint8_t *code, long rows, long cols, long groups_padded, const double *const *v, int nv, int cores,
                        double *const *ans) {
   const long colsCpB = div_geq(cols, 5);
@@ -254,7 +258,7 @@ static void gv5_kernel(const uint8_t *code, long rows, long cols, long groups_pa
       for (long i = 0; i < nrCols; i += 4) {
         const uint8_t *p0 = c + (i + 0) * rows, *p1 = c + (i + 1) * rows, *p2 = c + (i + 2) * rows, *p3 = c + (i + 3) * rows;
         const double *g0 = ff + (size_t)(i + 0) * fstride, *g1 = ff + (size_t)(i + 1) * fstride, *g2 = ff + (size_t)(i + 2) * fstride, *g3 = ff + (size_t)(i + 3) * fstride;
-        if (nv == GV5_VATONCE) {   /* the code bytes are loaded once for the four columns */
+        if (GV5_VATONCE == 4 && nv == 4) {   /* the code bytes are loaded once for the four columns */
           double *t0 = Tmp + rows * Cb, *t1 = t0 + tstride, *t2 = t1 + tstride, *t3 = t2 + tstride;
           for (long b = bStart; b < bEnd; b++) {
             const int c0 = p0[b], c1 = p1[b], c2 = p2[b], c3 = p3[b];
