@@ -490,8 +490,11 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     const int *d_flag = nullptr;
     // auto_i8: the verdict of the exactness check stays on the device (guard = 2) -- the int8 chain and the fp64 fallback are both enqueued and
     // test the flag themselves, so the product has no host round trip in its middle (44 us of a 1.2 ms product in the kernel timeline)
+    // MXA_I8_TN=1 (round 4, A/B of single-orientation storage for the CG step): n <= 2 from the copy whose rows are the K index (k_gemm_i8_tn)
+    const char *e_tn = getenv("MXA_I8_TN");
+    const PackedMatrix *G_tn = (auto_i8 && e_tn && atoi(e_tn) != 0) ? &gemm_operand(h, trans, true) : nullptr;
     const int rc8 = gemm_i8_device(G, trans, n, dB, ldb, dC, ldc, fill_rows, centered, d_sumB, d_sumfB, h->d_f, w, s, pe0, pe1,
-                                   &splits8, auto_i8 ? 2 : 0, &d_flag, auto_i8 ? w.d_colpart : nullptr);
+                                   &splits8, auto_i8 ? 2 : 0, &d_flag, auto_i8 ? w.d_colpart : nullptr, 0, G_tn);
     if (rc8 == 0 || rc8 == 3) {
       if (rc8 == 3) {   // fp64 pair tables, run only if the flag is set
         const GemmPlan pl = plan_lut(m, G.k_pad, n);

@@ -131,9 +131,10 @@ struct SliceFused {
   int bias, max_span, min_emax, want_sums;
 };
 
+// tn_map (k_gemm_i8_tn): K-step T covers 32 consecutive K indices, byte 4q+i of lane (h, col) = digit of B[32 T + 16 h + 4 i + q]
 __global__ void __launch_bounds__(256) k_slice_B(const double *__restrict__ B, long ldb, long k, int n, const int *__restrict__ E, int S, int nc, int NT,
                                                  long T_total, int ncols, uint32_t *__restrict__ Bs, long total, const int *__restrict__ skip_if_set,
-                                                 SliceFused fu) {
+                                                 SliceFused fu, int tn_map) {
   __shared__ int sE[2], sflag;
   if (fu.part) {   // n <= 2
     if (threadIdx.x < 64) {
@@ -173,7 +174,7 @@ __global__ void __launch_bounds__(256) k_slice_B(const double *__restrict__ B, l
     Digits9 d[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const long kk = 128 * (T >> 2) + 64 * h + 16 * (T & 3) + 4 * i + q;   // K order of the A operand: see k_gemm_i8
+      const long kk = tn_map ? 32 * T + 16 * h + 4 * i + q : 128 * (T >> 2) + 64 * h + 16 * (T & 3) + 4 * i + q;   // K order of the A operand: see k_gemm_i8 / k_gemm_i8_tn
       d[i] = (kk < k && cj < n) ? balanced_digits(B[kk + (long)cj * ldb], E[cj], S) : Digits9{0ull, 0u, 0};
     }
     for (int s = 0; s < S; s++) {
@@ -419,6 +420,132 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
         const long row = (long)rb * kTileRows + wr * (MT * 32) + a * 32 + (r & 3) + 8 * (r >> 2) + rq;
         Pb[(size_t)row * e_pad + (size_t)nc * (NT * 32) + (wc * NTW + b) * 32 + col] = acc[a][b][r];
       }
+}
+
+// ---- transposed-operand form for n <= 2 (round 4): C (indiv x n) = Zc B computed from the SNP-MAJOR copy, i.e. K runs over the packed matrix's ROWS and the
+// output runs along its packed direction -- the kernel single-orientation storage needs for the 'N' product of the CG step.
+// MFMA roles: A = the digits (M = the 32 expanded columns e = s * nc + jj, K = 32 SNPs), B = genotypes (N = 32 individuals, K = 32 SNPs); D[e][individual].
+// The B operand needs, per lane, 16 consecutive SNPs of ONE individual as bytes, while a packed dword holds 16 individuals of one SNP: lane (cg, khalf)
+// loads the 16 dwords W[r] = column group cg (16 individuals) of SNP rows 16 khalf + r, gathers bytes with 8 v_perm_b32 per four rows (P[q][b]: byte i =
+// byte b of W[4 i + q]) and masks the four 2-bit fields of every byte WHERE THEY STAND (field g of byte b = individual 4 b + g, scaled by 4^g; the top
+// field is shifted down by 2, scale 16): R[f][q] is the operand of individual 16 cg + f, and MFMA number f of the K-step multiplies the 32 individuals
+// {16 cg + f}.  112 VALU per 16 MFMAs and 256 genotypes per lane -- 0.44 per genotype, what the plain unpack costs.  The accumulator of MFMA f carries
+// the scale 4^min(f & 3, 2) * (f & 3 == 3 ? 4 : 1); it is divided out (exact shift) when the partial sums are stored.
+// Workgroup = a strip of 512 individuals (4 slabs) x a range of row blocks (256 SNPs each); the 4 waves split the 8 K-steps of a row block and add their
+// accumulators at the end through LDS.  LDS image of a stage: [slab j][K-step][32 rows x 32 B], slab regions 64 B apart modulo the bank period and rows
+// 16..31 of every unit rotated by one row (done on the GLOBAL side of the lane-linear DMA), so that the 64 lanes of a W load hit 64 different banks
+// (bank = dword of the column group (8) + 8 * khalf + 16 * slab).
+// Partial sums go to P[split][e][individual] like the operand-swapped plain instantiations: k_finish_i8_t finishes them (exact int64 over the splits).
+constexpr int kTnSlabs = 4;                                   // slabs (128 individuals) per workgroup strip
+constexpr int kTnSlabStride = kTileBytes + 64;                // LDS bytes between the slab regions of a stage
+constexpr int kTnDigitOff = kTnSlabs * kTnSlabStride;         // digit fragments of the stage's 8 K-steps (8 KiB) behind them
+constexpr int kTnBufBytes = kTnDigitOff + 8 * 1024;
+constexpr int kTnBufs = 3;
+constexpr int kTnLds = kTnBufs * kTnBufBytes;                 // 123 648 B
+constexpr int kTnUnitsPerWave = (kTnSlabs * 8 + 8) / kI8Waves;   // 10 DMA units per wave and stage
+
+__global__ void __launch_bounds__(256, 1)
+k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__restrict__ Ad, int *__restrict__ P, long m_pad, int strips, int stages_total,
+             int stages_per_split, const int *__restrict__ skip_if_set) {
+  if (skip_if_set && *skip_if_set) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int strip = blockIdx.x % strips, sp = blockIdx.x / strips;
+  const int st0 = sp * stages_per_split, st1 = min(st0 + stages_per_split, stages_total);
+  const int stages = st1 - st0;
+  const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
+  // DMA: LDS granule `lane` of a packed unit takes the global granule sigma(lane): rows 16..31 land rotated by one row
+  const int rho = (lane - 32) >> 1;
+  const uint32_t v_pack = lane < 32 ? (uint32_t)lane * 16 : (uint32_t)(2 * (16 + ((rho + 15) & 15)) + (lane & 1)) * 16;
+  const uint32_t v_lin = (uint32_t)lane * 16;
+  auto issue = [&](int stage, int buf) {   // stage relative to st0
+    const uint32_t base = lds0 + buf * kTnBufBytes;
+    const size_t rb = (size_t)(st0 + stage);
+#pragma unroll
+    for (int i = 0; i < kTnUnitsPerWave; i++) {
+      const int u = wave + i * kI8Waves;                     // 0..31: packed units (slab j = u >> 3, K-step u & 7); 32..39: digit units
+      if (u < kTnSlabs * 8) {
+        long sl = (long)strip * kTnSlabs + (u >> 3);
+        if (sl >= nslabs_all) sl = nslabs_all - 1;           // individuals beyond the matrix: rows of P nobody reads
+        idma16_stream(reinterpret_cast<const char *>(G) + (rb * (size_t)nslabs_all + (size_t)sl) * kTileBytes + (u & 7) * 1024, v_pack, base + (u >> 3) * kTnSlabStride + (u & 7) * 1024);
+      } else {
+        idma16_s(reinterpret_cast<const char *>(Ad) + (rb * 8 + (size_t)(u - kTnSlabs * 8)) * 1024, v_lin, base + kTnDigitOff + (u - kTnSlabs * 8) * 1024);
+      }
+    }
+  };
+  v16i acc[16];
+#pragma unroll
+  for (int f = 0; f < 16; f++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[f][r] = 0;
+  const int cg = lane & 31, khalf = lane >> 5;
+  // byte offset of W[r] inside a packed unit: slab region + row position (rotated for the upper half) * 32 + dword of the column group
+  int w_off[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) w_off[r] = (cg >> 3) * kTnSlabStride + (khalf ? 16 + ((r + 1) & 15) : r) * kSlabBytes + (cg & 7) * 4;
+
+  if (stages > 0) issue(0, 0);
+  if (stages > 1) issue(1, 1);
+  for (int s = 0; s < stages; s++) {
+    if (s + 1 < stages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kTnUnitsPerWave) : "memory");   // stage s has landed (stage s + 1 may be in flight)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                         // ... for every wave; and everybody is done with stage s - 1, whose buffer is refilled now
+    if (s + 2 < stages) issue(s + 2, (s + 2) % kTnBufs);
+    const char *bufp = smem + (s % kTnBufs) * kTnBufBytes;
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      const int T = 2 * wave + kk;                           // K-step of this wave inside the row block
+      const v4i af = *reinterpret_cast<const v4i *>(bufp + kTnDigitOff + T * 1024 + lane * 16);
+      uint32_t W[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) W[r] = *reinterpret_cast<const uint32_t *>(bufp + T * 1024 + w_off[r]);
+      // byte gather: P[q][b] byte i = byte b of W[4 i + q]
+      uint32_t Pq[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t a = W[q], b = W[4 + q], c = W[8 + q], d = W[12 + q];
+        const uint32_t t0 = __builtin_amdgcn_perm(b, a, 0x05010400u), t1 = __builtin_amdgcn_perm(b, a, 0x07030602u);
+        const uint32_t u0 = __builtin_amdgcn_perm(d, c, 0x05010400u), u1 = __builtin_amdgcn_perm(d, c, 0x07030602u);
+        Pq[q][0] = __builtin_amdgcn_perm(u0, t0, 0x05040100u); Pq[q][1] = __builtin_amdgcn_perm(u0, t0, 0x07060302u);
+        Pq[q][2] = __builtin_amdgcn_perm(u1, t1, 0x05040100u); Pq[q][3] = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
+      }
+#pragma unroll
+      for (int f = 0; f < 16; f++) {
+        const int b = f >> 2, g = f & 3;
+        v4i bf;
+#pragma unroll
+        for (int q = 0; q < 4; q++) bf[q] = (int)(g < 3 ? (Pq[q][b] & (0x03030303u << (2 * g))) : ((Pq[q][b] >> 2) & 0x30303030u));
+        acc[f] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[f], 0, 0, 0);
+      }
+    }
+  }
+  // ---- add the four waves' accumulators (disjoint K-steps) through LDS, four MFMA groups per pass, and store P[split][e][individual]
+  __syncthreads();
+  int *red = reinterpret_cast<int *>(smem);                  // [wave][group in pass (4)][reg (16)][lane (64)] ints = 64 KiB
+  int *Pb = P + (size_t)sp * 32 * m_pad;
+#pragma unroll
+  for (int pass = 0; pass < 4; pass++) {
+#pragma unroll
+    for (int gq = 0; gq < 4; gq++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) red[((wave * 4 + gq) * 16 + r) * 64 + lane] = acc[pass * 4 + gq][r];
+    __syncthreads();
+    {
+      const int f = pass * 4 + wave;                         // this wave finishes group f of the pass
+      const int sh = (f & 3) == 3 ? 4 : 2 * (f & 3);         // the in-place field scale of the group: 4^g, 16 for the top field
+      const long indiv = (long)strip * (kTnSlabs * kSlabK) + 16 * cg + f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        int v = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) v += red[((w * 4 + wave) * 16 + r) * 64 + lane];
+        const int e = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        Pb[(size_t)e * m_pad + indiv] = v >> sh;             // exact: every product carried the factor
+      }
+    }
+    __syncthreads();
+  }
 }
 
 // ---- finish: sum the splits exactly (int64), combine the slices smallest scale first, centring, ldc store.
@@ -709,12 +836,39 @@ static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const 
 
 // Whole product on the device; B, C device pointers; asynchronous on s.  The workspace (exponents, slices, partials) lives with the
 // handle and only grows.
+// K splits of the transposed-operand kernel: workgroups = strips x splits on one resident workgroup per CU; the split count whose last round of
+// workgroups is fullest, counting a start-up worth a few stages per workgroup; at most 2047 stages per split (int32 accumulators)
+static void plan_i8_tn(long indiv_slabs, long snp_rows, int *strips, int *stages_total, int *stages_per_split, int *splits) {
+  *strips = (int)((indiv_slabs + kTnSlabs - 1) / kTnSlabs);
+  *stages_total = (int)((snp_rows + kTileRows - 1) / kTileRows);
+  long best_cost = -1; int best = 1;
+  for (int cand = 1; cand <= 64 && cand <= *stages_total; cand++) {
+    const long per = (*stages_total + cand - 1) / cand, actual = (*stages_total + per - 1) / per;
+    if (actual != cand || per > 2047) continue;
+    const long rounds = ((long)*strips * actual + 255) / 256;
+    const long cost = rounds * (per + 6);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cand; }
+  }
+  if (const char *e = getenv("MXA_I8_TN_SPLITS")) best = std::max(1, std::min(*stages_total, atoi(e)));
+  *stages_per_split = (*stages_total + best - 1) / best;
+  *splits = (*stages_total + *stages_per_split - 1) / *stages_per_split;
+}
+
 int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool centered, double *d_sumB,
                    double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out, int guard,
-                   const int **flag_out, double *colsum_scratch, int S_override) {
+                   const int **flag_out, double *colsum_scratch, int S_override, const PackedMatrix *G_tn) {
   const long m = G.rows, k = G.k;
-  const I8Plan p = plan_i8(m, G.k_pad, n, S_override);
+  I8Plan p = plan_i8(m, G.k_pad, n, S_override);
   if (p.m_pad > G.rows_pad) { set_error(4, "internal: packed matrix smaller than the i8 plan"); return 1; }
+  // transposed-operand form (G_tn = the copy whose ROWS are the K index; n <= 2 only): same digits, same exactness guard, other main kernel and P layout
+  const bool tn = G_tn != nullptr && p.nchunks == 1 && p.NT == 1 && p.nc <= 2;
+  int tn_strips = 0, tn_stages = 0, tn_sps = 0, tn_splits = 0;
+  if (tn) {
+    if (G_tn->k != m || G_tn->rows != k) { set_error(4, "internal: transposed operand has the wrong shape"); return 1; }
+    plan_i8_tn(G_tn->nslabs, G_tn->rows, &tn_strips, &tn_stages, &tn_sps, &tn_splits);
+    if ((long)tn_stages * kTileRows > G_tn->rows_pad) { set_error(4, "internal: packed matrix smaller than the transposed i8 plan"); return 1; }
+    p.T_total = (long)tn_stages * 8; p.splits = tn_splits; p.m_pad = (long)tn_strips * kTnSlabs * kSlabK; p.e_pad = 32;
+  }
   if (splits_out) *splits_out = p.splits;
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
   const size_t part_bytes = up(sizeof(double) * 128 * n), e_bytes = up(sizeof(int) * (n + 1));   // column maxima + minima; exponents + the guard flag
@@ -765,7 +919,7 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
     const int ncols = p.nchunks * p.nc;
     const long total = (long)p.T_total * 2 * ncols * 4;
     hipLaunchKernelGGL(k_slice_B, dim3((unsigned)std::min<long>((total + 255) / 256, 256L * 64)), dim3(256), 0, s, dB, ldb, k, n, d_E, p.S, p.nc, p.NT,
-                       p.T_total, ncols, reinterpret_cast<uint32_t *>(d_Bs), total, skip, fu);
+                       p.T_total, ncols, reinterpret_cast<uint32_t *>(d_Bs), total, skip, fu, tn ? 1 : 0);
   }
   MXA_HIP(hipGetLastError());
   if (ev0) MXA_HIP(hipEventRecord(ev0, s));
@@ -773,6 +927,18 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   const bool small_tile = p.nchunks == 1 && p.NT == 1 && p.nc * p.S <= 32 && (p.nc == 1 || p.nc == 2);   // n <= 2: one tile
   static const bool direct_on = [] { const char *e = getenv("MXA_I8_DIRECT"); return !e || atoi(e) != 0; }();
   I8Direct dir{};
+  if (tn) {
+    static unsigned long long attr_tn = 0;
+    if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8_tn), kTnLds, &attr_tn)) return 1;
+    hipLaunchKernelGGL(k_gemm_i8_tn, dim3((unsigned)(tn_strips * tn_splits)), dim3(256), kTnLds, s, G_tn->d, G_tn->nslabs, d_Bs, d_P, p.m_pad, tn_strips, tn_stages, tn_sps, skip);
+    MXA_HIP(hipGetLastError());
+    if (ev1) MXA_HIP(hipEventRecord(ev1, s));
+    dim3 grid((unsigned)((fill_rows + 255) / 256), (unsigned)n);
+    hipLaunchKernelGGL(k_finish_i8_t, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, d_part, dC, ldc, fill_rows, trans ? 1 : 0,
+                       centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip);
+    MXA_HIP(hipGetLastError());
+    return guard == 2 ? 3 : 0;
+  }
   if (direct_on && small_tile && p.splits == 1)
     dir = I8Direct{1, d_E, d_part, dC, ldc, m, fill_rows, n, p.S, p.nc, trans ? 1 : 0, centered ? 1 : 0, d_sumB, d_sumfB, d_f};
   switch (p.NT) {
