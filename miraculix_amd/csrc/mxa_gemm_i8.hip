@@ -431,8 +431,8 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
 // field is shifted down by 2, scale 16): R[f][q] is the operand of individual 16 cg + f, and MFMA number f of the K-step multiplies the 32 individuals
 // {16 cg + f}.  112 VALU per 16 MFMAs and 256 genotypes per lane -- 0.44 per genotype, what the plain unpack costs.  The accumulator of MFMA f carries
 // the scale 4^min(f & 3, 2) * (f & 3 == 3 ? 4 : 1); it is divided out (exact shift) when the partial sums are stored.
-// Workgroup = a strip of 512 individuals (4 slabs) x a range of row blocks (256 SNPs each); the 4 waves split the 8 K-steps of a row block and add their
-// accumulators at the end through LDS.  LDS image of a stage: [slab j][K-step][32 rows x 32 B], slab regions 64 B apart modulo the bank period and rows
+// Workgroup (8 waves) = a strip of 512 individuals (4 slabs) x a range of row blocks (256 SNPs each); four wave pairs split the 8 K-steps of a row block,
+// the two waves of a pair split the 16 MFMA groups; the accumulators are added at the end through LDS.  LDS image of a stage: [slab j][K-step][32 rows x 32 B], slab regions 64 B apart modulo the bank period and rows
 // 16..31 of every unit rotated by one row (done on the GLOBAL side of the lane-linear DMA), so that the 64 lanes of a W load hit 64 different banks
 // (bank = dword of the column group (8) + 8 * khalf + 16 * slab).
 // Partial sums go to P[split][e][individual] like the operand-swapped plain instantiations: k_finish_i8_t finishes them (exact int64 over the splits).
@@ -442,15 +442,19 @@ constexpr int kTnDigitOff = kTnSlabs * kTnSlabStride;         // digit fragments
 constexpr int kTnBufBytes = kTnDigitOff + 8 * 1024;
 constexpr int kTnBufs = 3;
 constexpr int kTnLds = kTnBufs * kTnBufBytes;                 // 123 648 B
-constexpr int kTnUnitsPerWave = (kTnSlabs * 8 + 8) / kI8Waves;   // 10 DMA units per wave and stage
+constexpr int kTnWaves = 8;                                   // 512 threads: two waves per SIMD (the first version, 4 waves with all 16 groups each, was latency-bound: 1.15-1.24 ms)
+constexpr int kTnUnitsPerWave = (kTnSlabs * 8 + 8) / kTnWaves;   // 5 DMA units per wave and stage
 
-__global__ void __launch_bounds__(256, 1)
+// Wave (w4 = wave & 3, fh = wave >> 2): K-steps {2 w4, 2 w4 + 1} of every row block, MFMA groups f = 8 fh .. 8 fh + 7 (the bytes b = 2 fh, 2 fh + 1 of the
+// gathered words: half of the byte gather each, no VALU is duplicated; the two waves of a pair read the same 16 dwords from LDS).
+__global__ void __launch_bounds__(512, 1)
 k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__restrict__ Ad, int *__restrict__ P, long m_pad, int strips, int stages_total,
              int stages_per_split, const int *__restrict__ skip_if_set) {
   if (skip_if_set && *skip_if_set) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int w4 = wave & 3, fh = wave >> 2;
   const int strip = blockIdx.x % strips, sp = blockIdx.x / strips;
   const int st0 = sp * stages_per_split, st1 = min(st0 + stages_per_split, stages_total);
   const int stages = st1 - st0;
@@ -464,7 +468,7 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
     const size_t rb = (size_t)(st0 + stage);
 #pragma unroll
     for (int i = 0; i < kTnUnitsPerWave; i++) {
-      const int u = wave + i * kI8Waves;                     // 0..31: packed units (slab j = u >> 3, K-step u & 7); 32..39: digit units
+      const int u = wave + i * kTnWaves;                     // 0..31: packed units (slab j = u >> 3, K-step u & 7); 32..39: digit units
       if (u < kTnSlabs * 8) {
         long sl = (long)strip * kTnSlabs + (u >> 3);
         if (sl >= nslabs_all) sl = nslabs_all - 1;           // individuals beyond the matrix: rows of P nobody reads
@@ -474,9 +478,9 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
       }
     }
   };
-  v16i acc[16];
+  v16i acc[8];
 #pragma unroll
-  for (int f = 0; f < 16; f++)
+  for (int f = 0; f < 8; f++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[f][r] = 0;
   const int cg = lane & 31, khalf = lane >> 5;
@@ -484,6 +488,7 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
   int w_off[16];
 #pragma unroll
   for (int r = 0; r < 16; r++) w_off[r] = (cg >> 3) * kTnSlabStride + (khalf ? 16 + ((r + 1) & 15) : r) * kSlabBytes + (cg & 7) * 4;
+  const uint32_t sel1 = fh ? 0x07030602u : 0x05010400u;     // first gather stage: byte pairs (2 fh, 2 fh + 1) of the two rows
 
   if (stages > 0) issue(0, 0);
   if (stages > 1) issue(1, 1);
@@ -495,51 +500,50 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
     const char *bufp = smem + (s % kTnBufs) * kTnBufBytes;
 #pragma unroll
     for (int kk = 0; kk < 2; kk++) {
-      const int T = 2 * wave + kk;                           // K-step of this wave inside the row block
+      const int T = 2 * w4 + kk;                             // K-step of this wave inside the row block
       const v4i af = *reinterpret_cast<const v4i *>(bufp + kTnDigitOff + T * 1024 + lane * 16);
       uint32_t W[16];
 #pragma unroll
       for (int r = 0; r < 16; r++) W[r] = *reinterpret_cast<const uint32_t *>(bufp + T * 1024 + w_off[r]);
-      // byte gather: P[q][b] byte i = byte b of W[4 i + q]
-      uint32_t Pq[4][4];
+      // byte gather, this wave's half: Pq[q][bb] byte i = byte (2 fh + bb) of W[4 i + q]
+      uint32_t Pq[4][2];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const uint32_t a = W[q], b = W[4 + q], c = W[8 + q], d = W[12 + q];
-        const uint32_t t0 = __builtin_amdgcn_perm(b, a, 0x05010400u), t1 = __builtin_amdgcn_perm(b, a, 0x07030602u);
-        const uint32_t u0 = __builtin_amdgcn_perm(d, c, 0x05010400u), u1 = __builtin_amdgcn_perm(d, c, 0x07030602u);
-        Pq[q][0] = __builtin_amdgcn_perm(u0, t0, 0x05040100u); Pq[q][1] = __builtin_amdgcn_perm(u0, t0, 0x07060302u);
-        Pq[q][2] = __builtin_amdgcn_perm(u1, t1, 0x05040100u); Pq[q][3] = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
+        const uint32_t t = __builtin_amdgcn_perm(W[4 + q], W[q], sel1), u = __builtin_amdgcn_perm(W[12 + q], W[8 + q], sel1);
+        Pq[q][0] = __builtin_amdgcn_perm(u, t, 0x05040100u); Pq[q][1] = __builtin_amdgcn_perm(u, t, 0x07060302u);
       }
 #pragma unroll
-      for (int f = 0; f < 16; f++) {
-        const int b = f >> 2, g = f & 3;
+      for (int f = 0; f < 8; f++) {
+        const int bb = f >> 2, g = f & 3;
         v4i bf;
 #pragma unroll
-        for (int q = 0; q < 4; q++) bf[q] = (int)(g < 3 ? (Pq[q][b] & (0x03030303u << (2 * g))) : ((Pq[q][b] >> 2) & 0x30303030u));
+        for (int q = 0; q < 4; q++) bf[q] = (int)(g < 3 ? (Pq[q][bb] & (0x03030303u << (2 * g))) : ((Pq[q][bb] >> 2) & 0x30303030u));
         acc[f] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[f], 0, 0, 0);
       }
     }
   }
-  // ---- add the four waves' accumulators (disjoint K-steps) through LDS, four MFMA groups per pass, and store P[split][e][individual]
+  // ---- add the accumulators of the four waves of a field half (disjoint K-steps) through LDS, two MFMA groups per pass, and store P[split][e][individual]
   __syncthreads();
-  int *red = reinterpret_cast<int *>(smem);                  // [wave][group in pass (4)][reg (16)][lane (64)] ints = 64 KiB
+  int *red = reinterpret_cast<int *>(smem);                  // [wave (8)][group in pass (2)][reg (16)][lane (64)] ints = 64 KiB
   int *Pb = P + (size_t)sp * 32 * m_pad;
 #pragma unroll
   for (int pass = 0; pass < 4; pass++) {
 #pragma unroll
-    for (int gq = 0; gq < 4; gq++)
+    for (int gq = 0; gq < 2; gq++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) red[((wave * 4 + gq) * 16 + r) * 64 + lane] = acc[pass * 4 + gq][r];
+      for (int r = 0; r < 16; r++) red[((wave * 2 + gq) * 16 + r) * 64 + lane] = acc[pass * 2 + gq][r];
     __syncthreads();
     {
-      const int f = pass * 4 + wave;                         // this wave finishes group f of the pass
+      const int gq = w4 & 1, r0 = 8 * (w4 >> 1);             // this wave finishes group gq of its field half, registers r0 .. r0 + 7
+      const int f = 8 * fh + 2 * pass + gq;                  // field of the dword = individual 16 cg + f
       const int sh = (f & 3) == 3 ? 4 : 2 * (f & 3);         // the in-place field scale of the group: 4^g, 16 for the top field
       const long indiv = (long)strip * (kTnSlabs * kSlabK) + 16 * cg + f;
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
+      for (int rr = 0; rr < 8; rr++) {
+        const int r = r0 + rr;
         int v = 0;
 #pragma unroll
-        for (int w = 0; w < 4; w++) v += red[((w * 4 + wave) * 16 + r) * 64 + lane];
+        for (int w = 0; w < 4; w++) v += red[(((4 * fh + w) * 2 + gq) * 16 + r) * 64 + lane];
         const int e = (r & 3) + 8 * (r >> 2) + 4 * khalf;
         Pb[(size_t)e * m_pad + indiv] = v >> sh;             // exact: every product carried the factor
       }
@@ -930,7 +934,7 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   if (tn) {
     static unsigned long long attr_tn = 0;
     if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8_tn), kTnLds, &attr_tn)) return 1;
-    hipLaunchKernelGGL(k_gemm_i8_tn, dim3((unsigned)(tn_strips * tn_splits)), dim3(256), kTnLds, s, G_tn->d, G_tn->nslabs, d_Bs, d_P, p.m_pad, tn_strips, tn_stages, tn_sps, skip);
+    hipLaunchKernelGGL(k_gemm_i8_tn, dim3((unsigned)(tn_strips * tn_splits)), dim3(512), kTnLds, s, G_tn->d, G_tn->nslabs, d_Bs, d_P, p.m_pad, tn_strips, tn_stages, tn_sps, skip);
     MXA_HIP(hipGetLastError());
     if (ev1) MXA_HIP(hipEventRecord(ev1, s));
     dim3 grid((unsigned)((fill_rows + 255) / 256), (unsigned)n);
