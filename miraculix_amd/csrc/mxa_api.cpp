@@ -184,6 +184,15 @@ static int stage_matrix(PackedMatrix &M, const uint8_t *src, size_t src_pitch, l
   return rc;
 }
 
+// dimensions of a packed matrix that is NOT stored (single-orientation objects): what stage_matrix would have set, d == nullptr
+static void describe_matrix(PackedMatrix &M, long rows, long k) {
+  M.d = nullptr; M.rows = rows; M.k = k;
+  M.rows_pad = (rows + kRowAlign - 1) / kRowAlign * kRowAlign;
+  M.k_pad = (k + kSlabK - 1) / kSlabK * kSlabK;
+  M.pitch = (size_t)M.k_pad / 4;
+  M.nslabs = M.k_pad / kSlabK;
+}
+
 // Both orientations from the SNP-major PLINK matrix alone: the raw bytes are brought to the device once (a host source: one compact upload;
 // a device source is used in place), recoded into the SNP-major object, transposed on the device (raw PLINK codes, so a missing 01 stays a
 // missing 01) and the transposed bytes recoded into the individual-major object -- bit-identical to staging a caller-supplied transposed
@@ -293,7 +302,9 @@ int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink
   // memory pre-flight like checkDevMemory (cuda_utils.cu:162-185)
   size_t free_b = 0, total_b = 0;
   MXA_HIP(hipMemGetInfo(&free_b, &total_b));
-  const size_t need = (size_t)((snps + kRowAlign) * ((indiv + kSlabK) / 4)) + (size_t)((indiv + kRowAlign) * ((snps + kSlabK) / 4)) +
+  const char *e_single0 = getenv("MXA_SINGLE_ORIENTATION");
+  const bool single0 = e_single0 && atoi(e_single0) != 0;
+  const size_t need = (size_t)((snps + kRowAlign) * ((indiv + kSlabK) / 4)) + (single0 ? 0 : (size_t)((indiv + kRowAlign) * ((snps + kSlabK) / 4))) +
                       (size_t)3 * sizeof(double) * (size_t)std::max(snps, indiv) * (size_t)std::max(max_n, 1);
   if (need > free_b) {
     set_error(12, "Not enough device memory available. Required %zu GB, free %zu GB, total on device %zu GB", need >> 30, free_b >> 30, total_b >> 30);
@@ -305,6 +316,15 @@ int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink
   // enqueued on the default stream (e.g. PyTorch ops) is complete before k_pack_B reads it, and later default-stream work sees
   // C.  Callers on other streams pass theirs to mxa_dgemm_compressed_device.
   if (!check_hip(hipStreamCreateWithFlags(&h->stream, hipStreamDefault), __func__, __LINE__)) { destroy_handle(h); return 1; }
+  // MXA_SINGLE_ORIENTATION=1 (read here, a property of the object from then on): only the SNP-major copy is staged; plink_transposed is not read
+  {
+    const char *e_single = getenv("MXA_SINGLE_ORIENTATION");
+    h->single = e_single && atoi(e_single) != 0;
+  }
+  if (h->single) {
+    if (stage_matrix(h->snp_major, plink, plink_pitch, snps, indiv, h->stream)) { destroy_handle(h); return 1; }
+    describe_matrix(h->ind_major, indiv, snps);
+  } else
   if (one_pointer ? stage_from_snp_major(h, plink, plink_pitch) :
                     (stage_matrix(h->snp_major, plink, plink_pitch, snps, indiv, h->stream) ||
                      stage_matrix(h->ind_major, plink_t, plink_t_pitch, indiv, snps, h->stream))) { destroy_handle(h); return 1; }
@@ -407,7 +427,8 @@ int enable_peer(int cur, int peer) {
 // 42.5 ms per launch against 43.9-44.0 = 75.3 against 72.8 TFLOP/s = 0.957 against 0.925 of the fp64 MFMA peak; config-4 shard 423.6 against 438.0 ms
 // (0.961); n = 20: 13.55 against 13.98; n = 16: 10.87 against 11.03; n = 12: 8.30-8.35 against 8.44-8.47; n = 8: 5.70 against 5.77-5.84.
 // MXA_GEMM_TR: 0 never (the plain form), otherwise / unset: always.  Read per call.
-static bool gemm_use_tr(const GemmPlan &) {
+static bool gemm_use_tr(const GemmPlan &, const Handle *h, bool trans) {
+  if (h->single) return !trans;            // one stored copy (SNP-major): 'N' transposed, 'T' plain
   const char *e = getenv("MXA_GEMM_TR");
   return !e || atoi(e) != 0;
 }
@@ -472,7 +493,10 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     return gemm_i8_device(G, trans, nc, dBc, ldb, dC + (size_t)c0 * ldc, ldc, fill_rows, centered, d_sumB + c0, d_sumfB + c0, h->d_f, w, s, e0, e1, splits_out, 0,
                           nullptr, nullptr, S) ? 1 : 0;
   };
-  if ((engine == 4 || ((engine == 0 || (engine == 2 && n > 4)) && n <= auto_exact_max_n)) && n >= 3 && k >= 128) {   // engine 2 = engine 0 for n > 4
+  // single-orientation object, 'N': the int8 kernels with two or more column tiles (3 <= n <= 6, peeled columns, the opt-in engines) have no transposed form;
+  // those products take the fp64 MFMA tile in its transposed form (n <= 2 has k_gemm_i8_tn)
+  const bool no_plain = h->single && !trans;
+  if (!no_plain && (engine == 4 || ((engine == 0 || (engine == 2 && n > 4)) && n <= auto_exact_max_n)) && n >= 3 && k >= 128) {   // engine 2 = engine 0 for n > 4
     int splits8 = 1, S = 0;
     const int rcx = exact_adaptive(0, n, pe0, pe1, &splits8, &S);
     if (rcx == 1) return 1;
@@ -485,22 +509,28 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
       return 0;
     }
   }
-  if (engine == 1 || (engine == 2 && n <= 4) || auto_i8) {   // exact int8 slicing of B on the int8 matrix cores (mxa_gemm_i8.hip)
+  if ((!no_plain && (engine == 1 || (engine == 2 && n <= 4))) || auto_i8) {   // exact int8 slicing of B on the int8 matrix cores (mxa_gemm_i8.hip)
     int splits8 = 1;
     const int *d_flag = nullptr;
     // auto_i8: the verdict of the exactness check stays on the device (guard = 2) -- the int8 chain and the fp64 fallback are both enqueued and
     // test the flag themselves, so the product has no host round trip in its middle (44 us of a 1.2 ms product in the kernel timeline)
     // MXA_I8_TN=1 (round 4, A/B of single-orientation storage for the CG step): n <= 2 from the copy whose rows are the K index (k_gemm_i8_tn)
     const char *e_tn = getenv("MXA_I8_TN");
-    const PackedMatrix *G_tn = (auto_i8 && e_tn && atoi(e_tn) != 0) ? &gemm_operand(h, trans, true) : nullptr;
+    const PackedMatrix *G_tn = (auto_i8 && (no_plain || (!h->single && e_tn && atoi(e_tn) != 0))) ? &gemm_operand(h, trans, true) : nullptr;
     const int rc8 = gemm_i8_device(G, trans, n, dB, ldb, dC, ldc, fill_rows, centered, d_sumB, d_sumfB, h->d_f, w, s, pe0, pe1,
                                    &splits8, auto_i8 ? 2 : 0, &d_flag, auto_i8 ? w.d_colpart : nullptr, 0, G_tn);
     if (rc8 == 0 || rc8 == 3) {
-      if (rc8 == 3) {   // fp64 pair tables, run only if the flag is set
+      if (rc8 == 3 && !no_plain) {   // fp64 pair tables, run only if the flag is set
         const GemmPlan pl = plan_lut(m, G.k_pad, n);
         if (ensure_partials(w, pl, s)) return 1;
         if (launch_lut(G, dB, ldb, n, w.d_P, pl, s, d_flag)) return 1;
         if (launch_finish(w.d_P, pl, m, n, dC, ldc, fill_rows, trans ? 1 : 0, centered, d_sumB, d_sumfB, h->d_f, s, nullptr, 0, 0, d_flag)) return 1;
+      } else if (rc8 == 3) {   // single-orientation 'N': the fp64 fallback is the narrow MFMA tile in its transposed form with plain operands, gated by the same flag
+        const GemmPlan pf = plan_gemm(m, G.k_pad, n);
+        if (ensure_partials(w, pf, s)) return 1;
+        if (launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, pf.n_pad, pf.c, s, nullptr, 0, -1, d_flag)) return 1;
+        if (launch_gemm(h->snp_major, w.d_Bp, w.d_P, pf, 0, s, next_ctr(w), 0, -1, d_flag, true)) return 1;
+        if (launch_finish(w.d_P, pf, m, n, dC, ldc, fill_rows, 0, centered, d_sumB, d_sumfB, h->d_f, s, nullptr, 0, 0, d_flag)) return 1;
       }
       std::lock_guard<std::mutex> lk(g_prof_mutex);
       Geometry &geo = last_geometry();
@@ -516,7 +546,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   // MFMA without padding.  If the guard declines, all n columns take the MFMA path as before.
   static const bool peel_on = [] { const char *e = getenv("MXA_PEEL"); return !e || atoi(e) != 0; }();
   const int n_odd = n & 3;
-  if (peel_on && (engine == 0 || engine == 2) && n > 4 && (n_odd == 1 || n_odd == 2) && k >= 128) {   // engine 2 = engine 0 for n > 4
+  if (!no_plain && peel_on && (engine == 0 || engine == 2) && n > 4 && (n_odd == 1 || n_odd == 2) && k >= 128) {   // engine 2 = engine 0 for n > 4
     const int n4 = n - n_odd;
     const int rc8 = gemm_i8_device(G, trans, n_odd, dB + (size_t)n4 * ldb, ldb, dC + (size_t)n4 * ldc, ldc, fill_rows, centered, d_sumB + n4, d_sumfB + n4, h->d_f, w, s,
                                    nullptr, nullptr, nullptr, true);
@@ -525,13 +555,13 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   }
   // n = 4q + 3, q >= 1 (round 3): the three odd columns through the exact route with per-call digits (1.2 ms on 500k x 50k) instead of a
   // quarter-full MFMA group (2.7-2.9 ms)
-  if (peel_on && (engine == 0 || engine == 2) && n > 6 && n_odd == 3 && k >= 128 && auto_exact_max_n >= 3) {
+  if (!no_plain && peel_on && (engine == 0 || engine == 2) && n > 6 && n_odd == 3 && k >= 128 && auto_exact_max_n >= 3) {
     const int rcx = exact_adaptive(n - 3, 3, nullptr, nullptr, nullptr, nullptr);
     if (rcx == 1) return 1;
     if (rcx == 0) n -= 3;
   }
   static const int lut_max_n = [] { const char *e = getenv("MXA_LUT_MAX_N"); return e ? atoi(e) : 2; }();
-  const bool use_lut = n <= lut_max_n && n <= 4;
+  const bool use_lut = n <= lut_max_n && n <= 4 && !no_plain;
   GemmPlan p = use_lut ? plan_lut(m, G.k_pad, n) : plan_gemm(m, G.k_pad, n);
   if (ensure_partials(w, p, s)) return 1;   // the plan of the columns left after a peel may need more than the plan ensure_workspace sized for
   {
@@ -540,7 +570,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c; geo.path = use_lut ? 1 : 0;
   }
   // MODE 2 / 3 (default): genotype operand as the denormal z * 2^-1074 (one VALU per fragment instead of two); B scaled per column
-  const bool tr = !use_lut && gemm_use_tr(p);   // transposed-operand form: from the OTHER stored orientation (gemm_use_tr)
+  const bool tr = !use_lut && gemm_use_tr(p, h, trans);   // transposed-operand form: from the OTHER stored orientation (gemm_use_tr)
   const PackedMatrix &GL = gemm_operand(h, trans, tr);
   int mode = gemm_default_mode(p.c);
   if (tr) mode = gemm_tr_mode(mode);
@@ -634,7 +664,7 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
   static const bool peel_on = [] { const char *e = getenv("MXA_PEEL"); return !e || atoi(e) != 0; }();
   const int n_all = n, n_odd = n & 3;
   bool b_uploaded = false;
-  if (peel_on && engine == 0 && n > 4 && (n_odd == 1 || n_odd == 2) && k >= 128) {
+  if (peel_on && engine == 0 && n > 4 && (n_odd == 1 || n_odd == 2) && k >= 128 && !(h->single && !trans)) {
     const int n4 = n - n_odd;
     if (!b_local) {
       if (kmode) MXA_HIP(copy_columns(w.d_Bstage + (size_t)n4 * k, sizeof(double) * k, B + (size_t)n4 * ldb, sizeof(double) * ldb, sizeof(double) * k, n_odd, s));
@@ -651,7 +681,11 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
     else if (rc8 != 2) return 1;
   }
   const GemmPlan p = plan_gemm(m, G.k_pad, n);
-  const bool tr = gemm_use_tr(p) && (kmode || p.a == 8);   // row ranges of a transposed launch are column ranges of the packed matrix: whole slabs only for the 128-row blocks of A = 8
+  bool tr = gemm_use_tr(p, h, trans);
+  if (tr && !kmode && p.a != 8) {   // row ranges of a transposed launch are column ranges of the packed matrix: whole slabs only for the 128-row blocks of A = 8
+    if (h->single) return 2;        // (a single-orientation object has no plain form for 'N': the caller's unpipelined path does this product)
+    tr = false;
+  }
   const PackedMatrix &GL = gemm_operand(h, trans, tr);
   int mode = gemm_default_mode(p.c);
   if (tr) mode = gemm_tr_mode(mode);
@@ -1092,6 +1126,12 @@ long mxa_plan_partial_doubles(long m, long k, int n) {
   const GemmPlan p = plan_gemm(m, (k + kSlabK - 1) / kSlabK * kSlabK, n);
   return (long)p.splits * p.n_pad * p.m_pad;
 }
+int mxa_single_orientation(void *compressed) {
+  if (!compressed) return -1;
+  if (is_multi(compressed)) return -1;
+  Handle *h = as_handle(compressed, "mxa_single_orientation");
+  return h ? (h->single ? 1 : 0) : -1;
+}
 long mxa_partial_capacity(void *compressed) {
   if (!compressed || is_multi(compressed)) return -1;
   Handle *h = as_handle(compressed, "mxa_partial_capacity");
@@ -1164,7 +1204,9 @@ int bed_range_to_handle(const char *base_c, long snps_total, long indiv, long sn
   auto bad = [&](hipError_t e, int line) { if (e != hipSuccess) { check_hip(e, "mxa_bed2compressed", line); rc = 1; } return rc; };
   const size_t rows_per_chunk = std::max<size_t>(1, ((size_t)64 << 20) / bps);
   const size_t chunk_bytes = std::min(rows_per_chunk, (size_t)rows) * bps;
-  if (bad(hipMalloc((void **)&d_plink, (size_t)rows * bps), __LINE__) || bad(hipMalloc((void **)&d_plink_t, (size_t)indiv * bpi), __LINE__) ||
+  const char *e_single = getenv("MXA_SINGLE_ORIENTATION");
+  const bool single = e_single && atoi(e_single) != 0;   // only the SNP-major copy will be kept: no transposed block is built
+  if (bad(hipMalloc((void **)&d_plink, (size_t)rows * bps), __LINE__) || (!single && bad(hipMalloc((void **)&d_plink_t, (size_t)indiv * bpi), __LINE__)) ||
       bad(hipMalloc((void **)&d_f, sizeof(double) * rows), __LINE__) || bad(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking), __LINE__)) goto out;
   for (int i = 0; i < 2; i++)
     if (bad(hipHostMalloc(&pin[i], chunk_bytes, hipHostMallocDefault), __LINE__) || bad(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming), __LINE__)) goto out;
@@ -1180,7 +1222,7 @@ int bed_range_to_handle(const char *base_c, long snps_total, long indiv, long sn
     }
     if (!rc) bad(hipStreamSynchronize(cs), __LINE__);
   }
-  if (!rc) rc = launch_transpose_2bit(d_plink, rows, indiv, d_plink_t, nullptr);
+  if (!rc && !single) rc = launch_transpose_2bit(d_plink, rows, indiv, d_plink_t, nullptr);
   if (!rc) rc = launch_allele_freq(d_plink, rows, indiv, d_f, nullptr);
   if (!rc) bad(hipDeviceSynchronize(), __LINE__);
   if (!rc) rc = create_handle(d_plink, bps, d_plink_t, bpi, rows, indiv, d_f, max_n, out, dev);

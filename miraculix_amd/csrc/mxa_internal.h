@@ -69,8 +69,12 @@ struct Handle {
   uint32_t magic = kMagic;
   int device = 0;
   long snps = 0, indiv = 0;
-  PackedMatrix snp_major;    // rows = snps,  k = indiv   (used by 'T')
-  PackedMatrix ind_major;    // rows = indiv, k = snps    (used by 'N')
+  PackedMatrix snp_major;    // rows = snps,  k = indiv
+  PackedMatrix ind_major;    // rows = indiv, k = snps.  Every product can be computed from either copy (mxa_api.cpp: gemm_use_tr).
+  // Single-orientation object (MXA_SINGLE_ORIENTATION=1 at plink2compressed; round 4): only the SNP-major copy exists -- half the HBM, half the staging.
+  // ind_major then holds the DIMENSIONS of the missing copy (for the launch plans) with d == nullptr; 'T' products run in the plain form, 'N' products in the
+  // transposed-operand forms (k_gemm<..., TR>, k_gemm_i8_tn), both on snp_major.
+  bool single = false;
   double *d_f = nullptr;     // snps
   double *h_f = nullptr;
   bool has_f = false;
