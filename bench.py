@@ -471,7 +471,7 @@ def _stage_full(torch, mx, dev, snps, indiv, n, seed, shards):
     return dict(torch=torch, mx=mx, dev=dev, plink=plink, plink_t=plink_t, f=f, dg=mx.dgemm_compressed, snps=snps, indiv=indiv, n=n)
 
 
-def _make_object(S, shards, centered):
+def _make_object(S, shards, centered, single=False):
     dg = S["dg"]
     dg.set_options(use_gpu=True, not_center=not centered, verbose=0)
     old = os.environ.get("MIRACULIX_NUM_GPUS")
@@ -480,8 +480,11 @@ def _make_object(S, shards, centered):
             os.environ["MIRACULIX_NUM_GPUS"] = str(shards)
         else:
             os.environ.pop("MIRACULIX_NUM_GPUS", None)
-        obj = dg.init_compressed(S["plink"], S["plink_t"], S["snps"], S["indiv"], S["f"], S["n"])
+        if single:      # one packed copy (SNP-major) serves both products; plink_transposed is not read
+            os.environ["MXA_SINGLE_ORIENTATION"] = "1"
+        obj = dg.init_compressed(S["plink"], None if single else S["plink_t"], S["snps"], S["indiv"], S["f"], S["n"])
     finally:
+        os.environ.pop("MXA_SINGLE_ORIENTATION", None)
         if old is None:
             os.environ.pop("MIRACULIX_NUM_GPUS", None)
         else:
@@ -494,7 +497,8 @@ def config5_full_leg(torch, mx, L, dev, snps=2_000_000, indiv=100_000, shards=8,
     """BASELINE config 5 at its FULL extent on one GPU: 2M SNPs x 100k individuals (2 x 50 GB packed), the GBLUP / CG loop of the reference's
     examples/iterative_solver/grm_solve_cg.jl:74-84,108-134 -- `iters` iterations of (Zc Zc^T + lambda I) x = b, one mxa_gram_matvec each --
     (i) on the object cut into 8 SNP shards behind the plain symbols (MIRACULIX_NUM_GPUS=8: the partition, staging, per-shard products and the
-    fixed-order reduction of the 8-GPU run, here with all shards on one device) and (ii) on one plain object.  Checks: sampled rows of both
+    fixed-order reduction of the 8-GPU run, here with all shards on one device), (ii) on one plain object and (iii) on one SINGLE-ORIENTATION object
+    (MXA_SINGLE_ORIENTATION=1: only the SNP-major copy, 50 GB instead of 100; 'N' by the transposed-operand kernel k_gemm_i8_tn).  Checks: sampled rows of both
     products against the long-double dense oracle, the residual the loop reports against a separately computed one, bitwise repeatability,
     and sharded == single object bit for bit on an integer-valued vector (uncentred: every partial sum is an exact integer)."""
     sys.path.insert(0, os.path.join(ROOT, "examples"))
@@ -510,10 +514,16 @@ def config5_full_leg(torch, mx, L, dev, snps=2_000_000, indiv=100_000, shards=8,
     lam = float(snps)
     sync = torch.cuda.synchronize
     keep = {}
-    for name, nsh in ((f"{shards}_virtual_shards", shards), ("one_object", 1)):
-        obj = _make_object(S, nsh, centered=True)
-        if name == "one_object":        # the raw matrices are no longer needed: the samples are on the host
-            S["plink"] = S["plink_t"] = None
+    for name, nsh in ((f"{shards}_virtual_shards", shards), ("one_object", 1), ("one_object_single_orientation", 1)):
+        single = name.endswith("single_orientation")
+        if single:                       # the individual-major raw matrix is not needed for this object: release it before staging
+            S["plink_t"] = None
+            torch.cuda.empty_cache()
+        free0 = torch.cuda.mem_get_info()[0]
+        obj = _make_object(S, nsh, centered=True, single=single)
+        held_gb = (free0 - torch.cuda.mem_get_info()[0]) / 1e9
+        if single:                       # the raw matrices are no longer needed: the samples are on the host
+            S["plink"] = None
             torch.cuda.empty_cache()
         try:
             class Op:
@@ -548,7 +558,8 @@ def config5_full_leg(torch, mx, L, dev, snps=2_000_000, indiv=100_000, shards=8,
             dg.set_options(use_gpu=True, not_center=False, verbose=0)
             keep[name] = (Ti, Ni, Gi)
             bytes_step = 2.0 * snps * ((indiv + 3) // 4)
-            res[name] = {"ms_per_cg_iteration_incl_vector_ops": round(dt / (it + 1) * 1e3, 3), "ms_per_gram_matvec": round(t_step * 1e3, 3),
+            res[name] = {"device_memory_held_by_the_object_GB": round(held_gb, 1),
+                         "ms_per_cg_iteration_incl_vector_ops": round(dt / (it + 1) * 1e3, 3), "ms_per_gram_matvec": round(t_step * 1e3, 3),
                          "algorithmic_TB_per_s": round(bytes_step / t_step * 1e-12, 3), "frac_of_8_TBs_spec": round(bytes_step / t_step * 1e-12 / 8.0, 4),
                          "cg_iterations": it, "cg_residual": resid, "rhs_norm": bnorm,
                          "check": {"T_32_sampled_rows_vs_dense_oracle_max_rel_err": err_t, "N_32_sampled_rows_vs_dense_oracle_max_rel_err": err_n,
@@ -558,8 +569,9 @@ def config5_full_leg(torch, mx, L, dev, snps=2_000_000, indiv=100_000, shards=8,
         finally:
             dg.free_compressed(obj)
             torch.cuda.empty_cache()
-    a, c = keep[f"{shards}_virtual_shards"], keep["one_object"]
+    a, c, d = keep[f"{shards}_virtual_shards"], keep["one_object"], keep["one_object_single_orientation"]
     res["check"] = {"sharded_equals_one_object_bitwise_on_integer_vector": bool(torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]) and torch.equal(a[2], c[2])),
+                    "single_orientation_equals_two_copies_bitwise_on_integer_vector": bool(torch.equal(d[0], c[0]) and torch.equal(d[1], c[1]) and torch.equal(d[2], c[2])),
                     "integer_gram_equals_T_then_N_bitwise": bool(torch.equal(c[1], c[2]))}
     S.clear(); keep.clear()
     torch.cuda.empty_cache()

@@ -36,12 +36,15 @@ def test_c5_full_extent_8_virtual_shards_and_one_object():
     L = mx.load_shared_library()
     leg = bench.config5_full_leg(torch, mx, L, dev, 2_000_000, 100_000, shards=8, iters=20)
     _assert_leg(leg)
-    for name in ("8_virtual_shards", "one_object"):
+    for name in ("8_virtual_shards", "one_object", "one_object_single_orientation"):
         ck = leg[name]["check"]
         assert leg[name]["cg_iterations"] == 20
         assert ck["T_32_sampled_rows_vs_dense_oracle_max_rel_err"] <= RTOL and ck["N_32_sampled_rows_vs_dense_oracle_max_rel_err"] <= RTOL
         assert ck["gram_matvec_vs_T_then_N_max_rel_err"] <= RTOL and ck["cg_bitwise_repeatable"] and ck["cg_residual_consistent_ok"] and ck["cg_converging_ok"]
     assert leg["check"]["sharded_equals_one_object_bitwise_on_integer_vector"] and leg["check"]["integer_gram_equals_T_then_N_bitwise"]
+    assert leg["check"]["single_orientation_equals_two_copies_bitwise_on_integer_vector"]
+    held = [leg[k]["device_memory_held_by_the_object_GB"] for k in ("one_object", "one_object_single_orientation")]
+    assert held[1] <= 0.56 * held[0]                                   # one packed copy instead of two (plus the same workspace)
 
 
 def test_c4_full_snp_extent_8_virtual_shards_and_one_object():
