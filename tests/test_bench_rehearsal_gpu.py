@@ -59,6 +59,8 @@ def test_bench_single_gpu_line_is_complete():
     ck = out["check"]
     assert ck["gpu_T_rows_vs_cpu_library_max_rel_err"] <= 1e-11 and ck["gpu_N_64_sampled_rows_vs_dense_oracle_max_rel_err"] <= 1e-11
     # the legs for BASELINE configs 3, 4 (shard) and 5 (shard), here at 2 % of their sizes: each carries its rates, its roofline fraction and its checks
+    for k in ("config5_cg_step", "config4_shard", "config3_crossprod", "config5_full_8_virtual_shards", "config4_full_extent_8_virtual_shards"):
+        assert "failed" not in out[k], out[k]
     c5, c4, c3 = out["config5_cg_step"], out["config4_shard"], out["config3_crossprod"]
     assert c5["ms_per_cg_step"] > 0 and c5["check"]["gram_matvec_bitwise_equals_T_then_N"] is True and 0 < c5["frac_of_8_TBs_spec"] < 1
     assert c5["check"]["T_32_sampled_rows_vs_dense_oracle_max_rel_err"] <= 1e-11 and c5["check"]["N_32_sampled_rows_vs_dense_oracle_max_rel_err"] <= 1e-11
@@ -70,6 +72,8 @@ def test_bench_single_gpu_line_is_complete():
     # configs 5 and 4 at their "full extent" legs (8 virtual shards + one object), here at 2 % of the sizes
     c5f, c4f = out["config5_full_8_virtual_shards"], out["config4_full_extent_8_virtual_shards"]
     assert c5f["check"]["sharded_equals_one_object_bitwise_on_integer_vector"] is True and c4f["check"]["sharded_equals_one_object_bitwise_on_integer_B"] is True
+    assert c5f["check"]["single_orientation_equals_two_copies_bitwise_on_integer_vector"] is True
+    assert c5f["one_object_single_orientation"]["ms_per_gram_matvec"] > 0
     for name in ("8_virtual_shards", "one_object"):
         assert c5f[name]["ms_per_gram_matvec"] > 0 and c5f[name]["check"]["cg_bitwise_repeatable"] is True
         assert c5f[name]["check"]["T_32_sampled_rows_vs_dense_oracle_max_rel_err"] <= 1e-11 and c5f[name]["check"]["N_32_sampled_rows_vs_dense_oracle_max_rel_err"] <= 1e-11

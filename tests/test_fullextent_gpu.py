@@ -21,7 +21,7 @@ def _mods():
 
 def _assert_leg(leg):
     from bench import leg_checks_ok
-    assert leg_checks_ok(leg), leg
+    assert "failed" not in leg and leg_checks_ok(leg), leg
 
 
 def test_c5_full_extent_8_virtual_shards_and_one_object():
