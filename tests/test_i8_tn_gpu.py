@@ -31,7 +31,7 @@ def _product(dg, obj, prob, trans, B, tn):
         os.environ.pop("MXA_I8_TN", None)
 
 
-@pytest.mark.parametrize("snps,indiv", [(3001, 1037), (2050, 1301), (700, 3001), (5000, 600), (1300, 130), (40000, 5000)])
+@pytest.mark.parametrize("snps,indiv", [(3001, 1037), (2050, 1301), (700, 3001), (5000, 600), (1300, 130)])
 @pytest.mark.parametrize("n", [1, 2])
 def test_transposed_int8_route_matches_plain_and_oracle(mx, snps, indiv, n):
     o = Oracle()

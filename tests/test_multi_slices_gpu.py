@@ -240,13 +240,16 @@ def test_async_chain_T_reads_the_result_of_the_preceding_N(mx, shards):
     it (advisor finding of round 3: the 'T' branch did not).  A big enough problem that the reduction is still running when 'T' is enqueued;
     the asynchronous chain must equal the synchronous one bit for bit, five times in a row."""
     import torch
+    from bench import synth_genotypes_device
     snps, indiv, n = 60_000, 20_000, 8
-    prob = make_problem(snps, indiv, n, seed=18)
+    dev = torch.device("cuda", 0)
+    plink = synth_genotypes_device(torch, snps, indiv, 18, dev)                 # generated, transposed and counted on the device: seconds instead of a minute of numpy
+    plink_t = mx.compressed_operations.transpose_genotype_matrix(plink, snps, indiv)
+    prob = dict(snps=snps, indiv=indiv, plink=plink, plink_t=plink_t, f=mx.read_plink.calc_freq(plink, snps, indiv))
     dg = mx.dgemm_compressed
     dg.set_options(use_gpu=True, not_center=False, verbose=0)
     obj = _make(mx, prob, n, shards)
     try:
-        dev = torch.device("cuda", 0)
         bounds = dg.shard_bounds(obj, snps)
         ld = max(e - b for b, e in bounds)
         g = torch.Generator(device=dev); g.manual_seed(2)

@@ -124,7 +124,7 @@ def test_half_the_device_memory_shards_and_bed(mx, tmp_path):
     honour the mode too"""
     import torch
     o = Oracle()
-    snps, indiv, n = 40_000, 30_000, 4
+    snps, indiv, n = 16_000, 12_000, 4
     prob = make_problem(snps, indiv, n, seed=2)
     dg = mx.dgemm_compressed
     dg.set_options(use_gpu=True, not_center=False, verbose=0)
