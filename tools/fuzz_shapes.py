@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""random shapes / widths / engines / centring / spans through the C ABI against the long-double dense oracle (tests/_util.Oracle):
-fuzz_shapes.py [cases] [seed]"""
+"""random shapes / widths / engines / centring / spans / one- or two-pointer staging through the C ABI against the long-double dense oracle (tests/_util.Oracle):
+fuzz_shapes.py [cases] [seed]      (MXA_SINGLE_ORIENTATION=1 in the environment runs the same through one-copy objects)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -24,7 +24,8 @@ for c in range(cases):
     prob = make_problem(snps, indiv, n, seed=int(rng.integers(1 << 30)), missing_frac=float(rng.choice([0.0, 0.02])))
     dg.set_engine(eng)
     dg.set_options(use_gpu=True, not_center=not centered, verbose=0)
-    obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], n)
+    one_pointer = bool(rng.integers(0, 3) == 0)                         # a third of the objects staged from the SNP-major matrix alone (the library transposes)
+    obj = dg.init_compressed(prob["plink"], None if one_pointer else prob["plink_t"], snps, indiv, prob["f"], n)
     try:
         for trans in (0, 1):
             k, m = (indiv, snps) if trans else (snps, indiv)
