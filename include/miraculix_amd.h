@@ -321,14 +321,16 @@ void mxa_last_geometry(long *m, long *k, int *n, int *splits, int *a_tile, int *
 /* doubles of split-K partial sums the fp64 MFMA launch of an m x k x n product writes (no device needed: tests check that the plan of the
  * columns left after a peel, which can be LARGER than the plan of all n columns, never outgrows the workspace) */
 long mxa_plan_partial_doubles(long m, long k, int n);
-/* Single-orientation objects (round 4, opt-in: MXA_SINGLE_ORIENTATION=1 in the environment when plink2compressed / mxa_bed2compressed /
- * mxa_plink2compressed_shard runs; a property of the object from then on).  Only the SNP-major copy is stored -- half the HBM (config 5 at its
+/* Single-orientation objects (round 4; a property of the object from plink2compressed / mxa_bed2compressed / mxa_plink2compressed_shard on).
+ * MXA_SINGLE_ORIENTATION in the environment of that call: 1 = always, 0 = never, unset or "auto" = only when the two packed copies do NOT fit the
+ * device's free memory while one does -- where the reference reports "Not enough device memory" (cuda_utils.cu:162-185) this build keeps one copy and
+ * carries on (a line under PRINT_LEVEL > 0 says so); a multi-device object decides once for all its shards.  Only the SNP-major copy is stored -- half the HBM (config 5 at its
  * full 2M x 100k: 50 GB instead of 100) and half the staging upload; plink_transposed is not read.  Both products then read that one copy: 'T' in
  * the plain form, 'N' in the transposed-operand forms (fp64 MFMA: k_gemm<..., TR>, as fast as with two copies; n <= 2: k_gemm_i8_tn, ~13 % slower
  * than the plain int8 kernel).  Results are those of a two-copy object to rounding (bit-identical on the fp64 MFMA path).  What is given up:
  * for 'N' with 3 <= n <= 6 and for the peeled odd columns of 'N' the exact int8 shortcut has no transposed form -- those products take the fp64
  * MFMA tile (n = 3..6: 2-3x slower than the int8 route); the opt-in engines i8 / i8-exact apply to 'T' only; 'T' with n >= 7 runs the plain
- * fp64 MFMA form (0.925 instead of 0.957 of the peak).  mxa_single_orientation: 1 / 0, -1 for an invalid or multi-device handle. */
+ * fp64 MFMA form (0.925 instead of 0.957 of the peak).  mxa_single_orientation: 1 / 0 (multi-device object: of its shards), -1 for an invalid handle. */
 int mxa_single_orientation(void *compressed);
 /* capacity (doubles) of the partial-sum workspace an object holds right now; -1 for an invalid / multi-device object */
 long mxa_partial_capacity(void *compressed);

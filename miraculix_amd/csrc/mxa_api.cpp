@@ -275,6 +275,19 @@ static int ensure_workspace(Handle *h, int n) {
   return 0;
 }
 
+thread_local int tl_single_override = -1;
+
+int single_orientation_policy() {
+  const char *e = getenv("MXA_SINGLE_ORIENTATION");
+  if (!e || !*e || !strcmp(e, "auto")) return 2;
+  return atoi(e) != 0 ? 1 : 0;
+}
+
+size_t object_footprint(long snps, long indiv, int max_n, bool single) {
+  return (size_t)((snps + kRowAlign) * ((indiv + kSlabK) / 4)) + (single ? 0 : (size_t)((indiv + kRowAlign) * ((snps + kSlabK) / 4))) +
+         (size_t)3 * sizeof(double) * (size_t)std::max(snps, indiv) * (size_t)std::max(max_n, 1);
+}
+
 int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink_t, size_t plink_t_pitch, long snps, long indiv, const double *f,
                   int max_n, void **out, int device) {
   if (out) *out = nullptr;
@@ -299,13 +312,16 @@ int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink
     print_compile_info("dgemm_compressed");
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) printf("miraculix_amd - dgemm_compressed: using device %s (device no %d).\n", prop.name, dev);
   }
-  // memory pre-flight like checkDevMemory (cuda_utils.cu:162-185)
+  // memory pre-flight like checkDevMemory (cuda_utils.cu:162-185).  Where the reference gives up -- two packed copies do not fit -- this build keeps
+  // the SNP-major copy alone if THAT fits (MXA_SINGLE_ORIENTATION unset / auto; Handle::single): both products then read the one copy.
   size_t free_b = 0, total_b = 0;
   MXA_HIP(hipMemGetInfo(&free_b, &total_b));
-  const char *e_single0 = getenv("MXA_SINGLE_ORIENTATION");
-  const bool single0 = e_single0 && atoi(e_single0) != 0;
-  const size_t need = (size_t)((snps + kRowAlign) * ((indiv + kSlabK) / 4)) + (single0 ? 0 : (size_t)((indiv + kRowAlign) * ((snps + kSlabK) / 4))) +
-                      (size_t)3 * sizeof(double) * (size_t)std::max(snps, indiv) * (size_t)std::max(max_n, 1);
+  const int policy = tl_single_override >= 0 ? tl_single_override : single_orientation_policy();
+  const size_t need_two = object_footprint(snps, indiv, max_n, false), need_one = object_footprint(snps, indiv, max_n, true);
+  const bool single0 = policy == 1 || (policy == 2 && need_two > free_b && need_one <= free_b);
+  if (single0 && policy == 2 && (env_print_level() > 0 || o.print_level > 0))
+    printf("miraculix_amd - dgemm_compressed: two packed copies need %.1f GB, %.1f GB are free: keeping the SNP-major copy only (%.1f GB).\n", need_two / 1e9, free_b / 1e9, need_one / 1e9);
+  const size_t need = single0 ? need_one : need_two;
   if (need > free_b) {
     set_error(12, "Not enough device memory available. Required %zu GB, free %zu GB, total on device %zu GB", need >> 30, free_b >> 30, total_b >> 30);
     return 1;
@@ -316,11 +332,8 @@ int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink
   // enqueued on the default stream (e.g. PyTorch ops) is complete before k_pack_B reads it, and later default-stream work sees
   // C.  Callers on other streams pass theirs to mxa_dgemm_compressed_device.
   if (!check_hip(hipStreamCreateWithFlags(&h->stream, hipStreamDefault), __func__, __LINE__)) { destroy_handle(h); return 1; }
-  // MXA_SINGLE_ORIENTATION=1 (read here, a property of the object from then on): only the SNP-major copy is staged; plink_transposed is not read
-  {
-    const char *e_single = getenv("MXA_SINGLE_ORIENTATION");
-    h->single = e_single && atoi(e_single) != 0;
-  }
+  // decided above, a property of the object from then on: only the SNP-major copy is staged; plink_transposed is not read
+  h->single = single0;
   if (h->single) {
     if (stage_matrix(h->snp_major, plink, plink_pitch, snps, indiv, h->stream)) { destroy_handle(h); return 1; }
     describe_matrix(h->ind_major, indiv, snps);
@@ -1128,7 +1141,7 @@ long mxa_plan_partial_doubles(long m, long k, int n) {
 }
 int mxa_single_orientation(void *compressed) {
   if (!compressed) return -1;
-  if (is_multi(compressed)) return -1;
+  if (is_multi(compressed)) return multi_single(compressed);
   Handle *h = as_handle(compressed, "mxa_single_orientation");
   return h ? (h->single ? 1 : 0) : -1;
 }
@@ -1204,8 +1217,15 @@ int bed_range_to_handle(const char *base_c, long snps_total, long indiv, long sn
   auto bad = [&](hipError_t e, int line) { if (e != hipSuccess) { check_hip(e, "mxa_bed2compressed", line); rc = 1; } return rc; };
   const size_t rows_per_chunk = std::max<size_t>(1, ((size_t)64 << 20) / bps);
   const size_t chunk_bytes = std::min(rows_per_chunk, (size_t)rows) * bps;
-  const char *e_single = getenv("MXA_SINGLE_ORIENTATION");
-  const bool single = e_single && atoi(e_single) != 0;   // only the SNP-major copy will be kept: no transposed block is built
+  // only the SNP-major copy will be kept (no transposed block is built): asked for, or the raw block + its transpose + the two packed copies do not fit
+  bool single;
+  {
+    const int policy = tl_single_override >= 0 ? tl_single_override : single_orientation_policy();
+    size_t free_b = 0, total_b = 0;
+    if (bad(hipMemGetInfo(&free_b, &total_b), __LINE__)) goto out;
+    const size_t raw = (size_t)rows * bps, raw_t = (size_t)indiv * bpi;
+    single = policy == 1 || (policy == 2 && raw + raw_t + object_footprint(rows, indiv, max_n, false) > free_b && raw + object_footprint(rows, indiv, max_n, true) <= free_b);
+  }
   if (bad(hipMalloc((void **)&d_plink, (size_t)rows * bps), __LINE__) || (!single && bad(hipMalloc((void **)&d_plink_t, (size_t)indiv * bpi), __LINE__)) ||
       bad(hipMalloc((void **)&d_f, sizeof(double) * rows), __LINE__) || bad(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking), __LINE__)) goto out;
   for (int i = 0; i < 2; i++)
@@ -1225,7 +1245,12 @@ int bed_range_to_handle(const char *base_c, long snps_total, long indiv, long sn
   if (!rc && !single) rc = launch_transpose_2bit(d_plink, rows, indiv, d_plink_t, nullptr);
   if (!rc) rc = launch_allele_freq(d_plink, rows, indiv, d_f, nullptr);
   if (!rc) bad(hipDeviceSynchronize(), __LINE__);
-  if (!rc) rc = create_handle(d_plink, bps, d_plink_t, bpi, rows, indiv, d_f, max_n, out, dev);
+  if (!rc) {
+    const int keep = tl_single_override;
+    tl_single_override = single ? 1 : 0;     // the object follows the decision taken for the staging buffers
+    rc = create_handle(d_plink, bps, d_plink_t, bpi, rows, indiv, d_f, max_n, out, dev);
+    tl_single_override = keep;
+  }
   if (!rc && f_out_local) bad(hipMemcpy(f_out_local, d_f, sizeof(double) * rows, hipMemcpyDeviceToHost), __LINE__);
 out:
   fclose(fh);

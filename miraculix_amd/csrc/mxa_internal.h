@@ -71,7 +71,7 @@ struct Handle {
   long snps = 0, indiv = 0;
   PackedMatrix snp_major;    // rows = snps,  k = indiv
   PackedMatrix ind_major;    // rows = indiv, k = snps.  Every product can be computed from either copy (mxa_api.cpp: gemm_use_tr).
-  // Single-orientation object (MXA_SINGLE_ORIENTATION=1 at plink2compressed; round 4): only the SNP-major copy exists -- half the HBM, half the staging.
+  // Single-orientation object (MXA_SINGLE_ORIENTATION=1 at plink2compressed, or by itself when two copies do not fit the device; round 4): only the SNP-major copy exists -- half the HBM, half the staging.
   // ind_major then holds the DIMENSIONS of the missing copy (for the launch plans) with d == nullptr; 'T' products run in the plain form, 'N' products in the
   // transposed-operand forms (k_gemm<..., TR>, k_gemm_i8_tn), both on snp_major.
   bool single = false;
@@ -110,6 +110,12 @@ Geometry &last_geometry();
 // device < 0: taken from HIP_DEVICE / CUDA_DEVICE / the current device
 int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink_t, size_t plink_t_pitch, long snps, long indiv,
                   const double *f, int max_n, void **out, int device = -1);
+// MXA_SINGLE_ORIENTATION: 0 = always both copies, 1 = always the SNP-major copy alone, unset / "auto" (2) = both copies unless they do not fit the
+// device's free memory while one copy does.  mxa_multi.cpp decides once per object (all shards alike) and tells its workers' create_handle calls
+// through tl_single_override (-1: decide here).
+int single_orientation_policy();
+size_t object_footprint(long snps, long indiv, int max_n, bool single);   // device bytes of a staged object: packed copies (tile padding included) + workspace
+extern thread_local int tl_single_override;
 void destroy_handle(Handle *h);
 // pointer classification: 0 = host, 1 = device / managed memory (its device in *dev)
 int ptr_location(const void *p, int *dev);
@@ -136,6 +142,7 @@ int multi_create(const uint8_t *plink, const uint8_t *plink_t, long snps, long i
 int multi_create_from_bed(const char *base, long snps, long indiv, int max_n, int shards, void **out, double *f_out);
 int multi_gemm(void *obj, bool trans, int n, const double *B, long ldb, double *C, long ldc);
 int multi_gram(void *obj, int n, const double *V, long ldv, double *out, long ldo);
+int multi_single(const void *obj);         // 1: the shards keep the SNP-major copy only, 0: both copies (all shards of an object are alike)
 void multi_freq(void *obj, double *f);
 void multi_destroy(void *obj);
 bool is_multi(const void *obj);

@@ -166,3 +166,68 @@ def test_half_the_device_memory_shards_and_bed(mx, tmp_path):
         assert np.abs(C.T - reff).max() <= RTOL * np.abs(reff).max()
     finally:
         dg.free_compressed(ob)
+
+
+def test_two_copies_that_do_not_fit_keep_one(mx):
+    """MXA_SINGLE_ORIENTATION unset (auto): where the reference's pre-flight stops with "Not enough device memory" (cuda_utils.cu:162-185) because the two
+    packed copies do not fit, the object keeps the SNP-major copy alone if that fits -- same results (bit-identical on the fp64 MFMA path); with
+    MXA_SINGLE_ORIENTATION=0 the call fails like the reference's; a sharded object decides once for all its shards.  The device is filled with a
+    ballast tensor so that the case costs megabytes, not hundreds of gigabytes."""
+    import torch
+    from bench import synth_genotypes_device
+    dg = mx.dgemm_compressed
+    L = mx.check_library_handle()
+    L.mxa_single_orientation.argtypes = [ctypes.c_void_p]
+    dev = torch.device("cuda", 0)
+    snps, indiv, n = 48_000, 32_000, 8
+    plink = synth_genotypes_device(torch, snps, indiv, 5, dev)
+    f = mx.read_plink.calc_freq(plink, snps, indiv)
+    g = torch.Generator(device=dev); g.manual_seed(6)
+    Bn = torch.randn((n, snps), dtype=torch.float64, device=dev, generator=g).t()
+    Bt = torch.randn((n, indiv), dtype=torch.float64, device=dev, generator=g).t()
+    dg.set_options(use_gpu=True, not_center=False, verbose=0)
+    os.environ.pop("MXA_SINGLE_ORIENTATION", None)
+
+    def products(obj):
+        out = [dg.dgemm_compressed_main(False, obj, Bn, snps, indiv).clone(), dg.dgemm_compressed_main(True, obj, Bt, snps, indiv).clone()]
+        torch.cuda.synchronize()
+        return out
+
+    obj = dg.init_compressed(plink, None, snps, indiv, f, n)          # plenty of room: two copies (this also loads every code object before the squeeze)
+    assert L.mxa_single_orientation(obj) == 0
+    ref = products(obj)
+    dg.free_compressed(obj)
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    one_copy = (snps + 256) * ((indiv + 128) // 4)                     # bytes of one packed copy with its tile padding: 388 MB
+    free_b, _ = torch.cuda.mem_get_info()
+    ballast = torch.empty(free_b - int(1.5 * one_copy), dtype=torch.uint8, device=dev)   # room for one copy and the workspace, not for two
+    try:
+        obj = dg.init_compressed(plink, None, snps, indiv, f, n)
+        try:
+            assert L.mxa_single_orientation(obj) == 1
+            got = products(obj)
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+        finally:
+            dg.free_compressed(obj)
+        os.environ["MXA_SINGLE_ORIENTATION"] = "0"
+        try:
+            with pytest.raises(RuntimeError, match="Not enough device memory"):
+                dg.init_compressed(plink, None, snps, indiv, f, n)
+        finally:
+            os.environ.pop("MXA_SINGLE_ORIENTATION", None)
+        os.environ["MIRACULIX_NUM_GPUS"] = "3"
+        try:
+            obj = dg.init_compressed(plink, None, snps, indiv, f, n)
+        finally:
+            os.environ.pop("MIRACULIX_NUM_GPUS", None)
+        try:
+            assert dg.num_shards(obj) == 3 and L.mxa_single_orientation(obj) == 1
+            got = products(obj)
+            assert torch.equal(got[1], ref[1])                                            # 'T': disjoint row blocks, the same arithmetic per row
+            scale = float(ref[0].abs().max())
+            assert float((got[0] - ref[0]).abs().max()) <= RTOL * scale                    # 'N': the sum over the SNP blocks is associated differently
+        finally:
+            dg.free_compressed(obj)
+    finally:
+        del ballast
+        torch.cuda.empty_cache()
