@@ -270,7 +270,11 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
   auto issue = [&](int stage, int buf) {   // stage index relative to st0
     const uint32_t base = lds0 + buf * Cfg::kBufBytes;
     const char *asrc = A_u + (size_t)(st0 + stage) * kTileBytes;
+#if defined(MXA_I8_EXP_CHEAPB)   // experiment (wrong results): every stage loads the digits of stage 0 -- what the digit slabs' trips to L2 cost
+    const char *bsrc = B_u + (size_t)(st0 + (stage & 1)) * ((size_t)4 * NT * 1024);
+#else
     const char *bsrc = B_u + (size_t)(st0 + stage) * ((size_t)4 * NT * 1024);
+#endif
 #pragma unroll
     for (int i = 0; i < (Cfg::kUnits + kI8Waves - 1) / kI8Waves; i++) {
       const int u = wave + i * kI8Waves;
@@ -344,8 +348,12 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
           if (b >= lo && b < hi) bf_nxt[b] = *reinterpret_cast<const v4i *>(bsrc + b * 1024);
 #pragma unroll
         for (int b = 0; b < NTW; b++)
+#if defined(MXA_I8_EXP_NOMFMA)   // experiment (wrong results): the operands are formed, the matrix cores stay idle -- is the stream slowed by the arithmetic?
+          { acc[a][b][0] += af_cur[0] ^ bf_cur[b][0]; acc[a][b][1] += af_cur[1] ^ bf_cur[b][1]; acc[a][b][2] += af_cur[2] ^ bf_cur[b][2]; acc[a][b][3] += af_cur[3] ^ bf_cur[b][3]; }
+#else
           acc[a][b] = kSwap ? __builtin_amdgcn_mfma_i32_32x32x32_i8(bf_cur[b], af_cur, acc[a][b], 0, 0, 0)
                             : __builtin_amdgcn_mfma_i32_32x32x32_i8(af_cur, bf_cur[b], acc[a][b], 0, 0, 0);
+#endif
         SchedIter<0, NTW, (NTW + MT - 1) / MT>::run();
         __builtin_amdgcn_sched_barrier(0);
         af_cur = af_nxt;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel timeline of the CG step (mxa_gram_matvec, n = 1) on the config-5 shard: where the time between the two big kernels goes
-R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/r03"; mkdir -p "$O"
+R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/r04g"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 rm -rf "$O/tmp_g"
 timeout -k 10 600 rocprofv3 --kernel-trace --output-format csv -d "$O/tmp_g" -- python3 "$R/tools/perf_gram.py" 250000 100000 1 > "$O/gram_trace_run.log" 2>&1
