@@ -193,15 +193,18 @@ constexpr int kI8Waves = 4;
 constexpr int kI8StageK = 128;                    // genotypes per stage = one slab of the tiled layout
 constexpr int kI8ABytes = kTileRows * kSlabBytes; // 8 KiB
 
-template <int NT>
+template <int NT, int ROWS = kTileRows>
 struct I8Cfg {
+  static constexpr int kABytes = ROWS * kSlabBytes;   // the workgroup's rows of one packed tile: 8 KiB, or 4 KiB for a half-tile workgroup (ROWS = 128)
   static constexpr int kBBytes = 4 * NT * 1024;   // 4 K-steps x NT tiles x 1 KiB
-  static constexpr int kBufBytes = kI8ABytes + kBBytes;
+  static constexpr int kBufBytes = kABytes + kBBytes;
   // ring depth: as many stages as fit the 160 KiB LDS when one workgroup owns the CU (NT >= 5)
   // NT <= 4 needs at most 128 accumulator registers: two workgroups share a CU (3 buffers each) and hide each other's waits.
-  static constexpr int kBufs = NT <= 4 ? 3 : 163840 / kBufBytes;
+  // Half-tile workgroups move half the packed bytes per stage: five buffers (40 KiB, four workgroups per CU) keep as many bytes in flight.
+  static constexpr int kBufs = ROWS < kTileRows ? 5 : NT <= 4 ? 3 : 163840 / kBufBytes;
   static constexpr int kLds = kBufs * kBufBytes;
-  static constexpr int kUnits = 8 + 4 * NT;       // 1 KiB DMA units per stage
+  static constexpr int kAUnits = kABytes / 1024;
+  static constexpr int kUnits = kAUnits + 4 * NT;       // 1 KiB DMA units per stage
 };
 
 // scheduling pattern of one group of NM MFMAs: after MFMA i one LDS read (while i < NLOAD) and its share of the 7 unpack VALU
@@ -220,6 +223,10 @@ struct SchedIter {
 // columns with MT * (4/WC) = 8 so that a workgroup covers one 256-row tile of the packed layout.
 //   <NT, 2, 1>: every wave reads all NT B fragments per K-step (LDS read traffic 4 x NT KiB per K-step of 512 MFMA cycles)
 //   <NT, 4, 2>: wave tile 128 x (NT/2 x 32): half the B-fragment LDS traffic, twice the unpack VALU (28 per 16 MFMAs)
+//   <1, 1, 1>:  HALF-TILE workgroup (round 4): 128 rows (rows 128 h .. of a packed tile are 4 KiB in a row), wave tile 32 rows.  For an n <= 2 product with
+//               few row tiles (the 'N' product of a CG step: 391 tiles on 1024 slots) twice the workgroups fill the chip WITHOUT K splits, so the product
+//               finishes inside the kernel (no partial sums through HBM, no finish launch) at the price of the digit slabs crossing L2 -> LDS twice as often.
+//               That price is too high (1.36 ms against 0.965): experiment only, MXA_I8_HALF_TILE=1.
 // Direct finish (n <= 2, ONE K split, round 3): the workgroup holds the complete integer sums of its 256 rows, so it scales them, adds the digits
 // of a column across the lanes in a fixed butterfly, applies the centring term and stores C itself -- no partial sums through HBM, no finish launch
 // (the 'T' product of a CG step: 128 MB of int32 partials and ~25 us).  Same arithmetic as k_finish_i8_small up to the (fixed) order of the additions.
@@ -235,10 +242,11 @@ __global__ void __launch_bounds__(256, 1)
 k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict__ Bs, long T_total, int *__restrict__ P, long m_pad, int e_pad,
           int rowblocks, int nchunks, int stages_total, int stages_per_split, unsigned long long *__restrict__ diag, const int *__restrict__ skip_if_set,
           I8Direct dir) {
-  using Cfg = I8Cfg<NT>;
+  constexpr int ROWS = MT * (4 / WC) * 32;             // rows of the packed tile this workgroup multiplies: the whole tile, or one half
+  using Cfg = I8Cfg<NT, ROWS>;
   if (skip_if_set && *skip_if_set) return;
   constexpr int NTW = NT / WC;
-  static_assert(NT % WC == 0 && MT * (4 / WC) == 8 && MT * NTW <= 16, "wave tiling");
+  static_assert(NT % WC == 0 && (ROWS == kTileRows || (ROWS == kTileRows / 2 && NT == 1)) && MT * NTW <= 16, "wave tiling");
   // Operand roles (round 3).  The matrix cores draw less power when the FULL-entropy operand (the radix-256 digits) is the instruction's A and the
   // low-entropy one (genotype bytes 0..2) its B: a bare MFMA loop runs 4.17 Pop/s at 2.11 GHz that way round against 3.60 at 1.84 GHz the other
   // (tools/mfma_i8_probe3.hip), and from two tiles on this kernel is power-bound.  The fragments are symmetric (a lane holds 16 consecutive k of one
@@ -262,7 +270,7 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
   const int stages = st1 - st0;
   const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
   const uint32_t v_lane = lane * 16;
-  const char *A_u = reinterpret_cast<const char *>(G) + (size_t)rb * (pitch / kSlabBytes) * kTileBytes;
+  const char *A_u = reinterpret_cast<const char *>(G) + (size_t)(ROWS == kTileRows ? rb : rb >> 1) * (pitch / kSlabBytes) * kTileBytes + (ROWS == kTileRows ? 0 : (rb & 1) * Cfg::kABytes);
   const char *B_u = reinterpret_cast<const char *>(Bs) + (size_t)nc * ((size_t)T_total * NT * 1024);
 
   // (with several column chunks -- the opt-in engines at wide n -- a packed tile is an operand of every chunk; choosing the policy per launch with a
@@ -279,8 +287,8 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
     for (int i = 0; i < (Cfg::kUnits + kI8Waves - 1) / kI8Waves; i++) {
       const int u = wave + i * kI8Waves;
       if (Cfg::kUnits % kI8Waves == 0 || u < Cfg::kUnits) {
-        if (u < 8) idma16_stream(asrc + u * 1024, v_lane, base + u * 1024);
-        else idma16_s(bsrc + (u - 8) * 1024, v_lane, base + kI8ABytes + (u - 8) * 1024);
+        if (u < Cfg::kAUnits) idma16_stream(asrc + u * 1024, v_lane, base + u * 1024);
+        else idma16_s(bsrc + (u - Cfg::kAUnits) * 1024, v_lane, base + Cfg::kABytes + (u - Cfg::kAUnits) * 1024);
       }
     }
   };
@@ -294,7 +302,7 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
       for (int r = 0; r < 16; r++) acc[a][b][r] = 0;
 
   const int a_off = (wr * (MT * 32) + (lane & 31)) * kSlabBytes + (lane >> 5) * 16;
-  const int b_off = kI8ABytes + (wc * NTW) * 1024 + lane * 16;
+  const int b_off = Cfg::kABytes + (wc * NTW) * 1024 + lane * 16;
 
   constexpr int NB = Cfg::kBufs;
   constexpr int kPerWave = Cfg::kUnits / kI8Waves;     // 2 + NT DMAs per wave and stage
@@ -390,7 +398,7 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
     for (int a = 0; a < MT; a++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const long row = (long)rb * kTileRows + wr * (MT * 32) + a * 32 + (r & 3) + 8 * (r >> 2) + rq;
+        const long row = (long)rb * ROWS + wr * (MT * 32) + a * 32 + (r & 3) + 8 * (r >> 2) + rq;
         double v = live ? ldexp((double)acc[a][0][r], sh) : 0.0;
         // the 32 lanes of a half-wave hold the digits of one row; lanes of one column: e = jj, jj + nc, ...  (nc = 1: all 32; nc = 2: equal parity)
         for (int off = 16; off >= dir.nc; off >>= 1) v += __shfl_xor(v, off, 32);
@@ -413,7 +421,7 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
       for (int b = 0; b < NTW; b++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          const long row = (long)rb * kTileRows + wr * (MT * 32) + a * 32 + col;
+          const long row = (long)rb * ROWS + wr * (MT * 32) + a * 32 + col;
           const int e = nc * (NT * 32) + (wc * NTW + b) * 32 + (r & 3) + 8 * (r >> 2) + rq;
           Pb[(size_t)e * m_pad + row] = acc[a][b][r];
         }
@@ -425,7 +433,7 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
     for (int b = 0; b < NTW; b++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const long row = (long)rb * kTileRows + wr * (MT * 32) + a * 32 + (r & 3) + 8 * (r >> 2) + rq;
+        const long row = (long)rb * ROWS + wr * (MT * 32) + a * 32 + (r & 3) + 8 * (r >> 2) + rq;
         Pb[(size_t)row * e_pad + (size_t)nc * (NT * 32) + (wc * NTW + b) * 32 + col] = acc[a][b][r];
       }
 }
@@ -760,7 +768,7 @@ __global__ void __launch_bounds__(256) k_finish_i8_small(const int *__restrict__
   }
 }
 
-struct I8Plan { int S, nc, nchunks, NT, e_pad, rowblocks, stages_total, stages_per_split, splits; long m_pad, T_total; };
+struct I8Plan { int S, nc, nchunks, NT, e_pad, rowblocks, stages_total, stages_per_split, splits, rows_wg; long m_pad, T_total; };
 
 static I8Plan plan_i8(long m, long k_pad, int n, int S_override) {
   I8Plan p{};
@@ -777,38 +785,53 @@ static I8Plan plan_i8(long m, long k_pad, int n, int S_override) {
   p.nc = (n + p.nchunks - 1) / p.nchunks;
   p.NT = (p.nc * S + 31) / 32;
   p.e_pad = p.nchunks * p.NT * 32;
-  p.rowblocks = (int)((m + kTileRows - 1) / kTileRows);
-  p.m_pad = (long)p.rowblocks * kTileRows;
   p.stages_total = (int)(k_pad / kI8StageK);
   p.T_total = k_pad / 32;
-  const long units = (long)p.rowblocks * p.nchunks;
   // K splits.  The kernel runs one workgroup per piece and the hardware keeps as many resident as the LDS allows (NT = 1: four per CU; the
   // launch is HBM-bound there and more workgroups mean more bytes in flight).  Measured on the config-5 shard (n = 1): what matters is that the
   // workgroup total fills whole rounds of the resident slots -- 391 row tiles x 5 splits = 1.91 rounds of 1024: 1.08 ms, x 6 = 2.29 rounds:
   // 1.19 ms -- and, at equal fill, FEWER splits (less partial-sum traffic, fewer prologues): 977 tiles x 3: 1.05 ms, x 7: 1.16 ms.
-  const long lds_wg = 3L * (kI8ABytes + 4L * p.NT * 1024);
-  const long resident = 256L * (p.NT <= 4 ? std::max<long>(1, std::min<long>(4, 163840 / lds_wg)) : 1);
   long max_splits = std::max<long>(1, p.stages_total / 32);
-  long splits = 1;
-  {
-    // Cost model (round 3; replaces "fill the rounds to 3 %"): main kernel = the larger of the packed-matrix stream at ~6 TB/s and the int8
-    // work at the ~2.4 Pop/s the power limit allows, stretched by the unfilled part of the last round of resident slots and by a per-piece
-    // prologue worth ~6 stages; plus the partial sums, written once and read once by the finish (none when the single split of an n <= 2
-    // product finishes inside the kernel).  Fewest splits within 1 % of the best.
-    static const long search = [] { const char *e = getenv("MXA_I8_SPLIT_SEARCH"); return e ? atol(e) : 1L; }();
-    const double t_main = std::max((double)p.m_pad * (double)k_pad / 4.0 * p.nchunks / 6.0e12, 2.0 * (double)p.m_pad * (double)k_pad * p.e_pad / 2.4e15);
-    const bool direct_possible = p.nchunks == 1 && p.NT == 1 && p.nc <= 2;
+  const bool direct_possible = p.nchunks == 1 && p.NT == 1 && p.nc <= 2;
+  // Cost model (round 3; replaces "fill the rounds to 3 %"): main kernel = the larger of the packed-matrix stream at ~6 TB/s and the int8
+  // work at the ~2.4 Pop/s the power limit allows, stretched by the unfilled part of the last round of resident slots and by a per-piece
+  // prologue worth ~6 stages; plus the partial sums, written once and read once by the finish (none when the single split of an n <= 2
+  // product finishes inside the kernel).  Fewest splits within 1 % of the best.  Evaluated for whole-tile workgroups (256 rows) and, under
+  // MXA_I8_HALF_TILE=1, for half-tile workgroups (128 rows, five-deep rings; the model for those is a guess that the measurement refuted).
+  static const long search = [] { const char *e = getenv("MXA_I8_SPLIT_SEARCH"); return e ? atol(e) : 1L; }();
+  auto evaluate = [&](int rows_wg, long *splits_out) {
+    const long rowblocks = (m + rows_wg - 1) / rows_wg, m_pad = rowblocks * rows_wg, units = rowblocks * p.nchunks;
+    const bool half = rows_wg < kTileRows;
+    const long lds_wg = half ? 5L * (rows_wg * kSlabBytes + 4L * p.NT * 1024) : 3L * (kI8ABytes + 4L * p.NT * 1024);
+    const long resident = 256L * (p.NT <= 4 ? std::max<long>(1, std::min<long>(4, 163840 / lds_wg)) : 1);
+    const double t_main = std::max((double)m_pad * (double)k_pad / 4.0 * p.nchunks / 6.0e12, 2.0 * (double)m_pad * (double)k_pad * p.e_pad / 2.4e15) * (half ? 1.015 : 1.0);
+    const double prologue = half ? 12.0 : 6.0;
     double best = 1e300;
+    long splits = 1;
     for (long cand = 1; search && cand <= std::min<long>(max_splits, 64); cand++) {
       const long per = (p.stages_total + cand - 1) / cand, actual = (p.stages_total + per - 1) / per;
       if (actual != cand) continue;
       const long wgs = units * actual, rounds = (wgs + resident - 1) / resident;
-      const double quant = (double)(rounds * resident) / (double)wgs;
-      const double t_p = (actual == 1 && direct_possible) ? 0.0 : 2.0 * (double)actual * (double)p.m_pad * p.e_pad * 4.0 / 5.0e12;
-      const double t = t_main * quant * (double)(per + 6) / (double)per + t_p;
+      double quant = (double)(rounds * resident) / (double)wgs;
+      if (half && rounds == 1) quant = std::max(1.0, 0.65 * (double)resident / (double)wgs);
+      const double t_p = (actual == 1 && direct_possible) ? 0.0 : 2.0 * (double)actual * (double)m_pad * p.e_pad * 4.0 / 5.0e12 + 5.0e-6;
+      const double t = t_main * quant * ((double)per + prologue) / (double)per + t_p;
       if (t < best * 0.99) { best = t; splits = cand; }
     }
+    *splits_out = splits;
+    return best;
+  };
+  long splits = 1, splits_half = 1;
+  (void)evaluate(kTileRows, &splits);
+  p.rows_wg = kTileRows;
+  if (direct_possible && p.S * p.nc <= 32) {
+    // MEASURED SLOWER, off unless MXA_I8_HALF_TILE=1 (profiles/r04_i8_half_tile_ab.txt): config-5 shard 'N' 1.36 ms without splits against 0.965 with
+    // five, 'T' 1.11 against 0.94 -- the digit slabs then cross L2 -> LDS as 2x the packed bytes and the DMA path, not HBM, sets the pace.
+    const char *e_half = getenv("MXA_I8_HALF_TILE");   // read per call: the tests switch it
+    if (e_half && atoi(e_half) == 1) { (void)evaluate(kTileRows / 2, &splits_half); p.rows_wg = kTileRows / 2; splits = splits_half; }
   }
+  p.rowblocks = (int)((m + p.rows_wg - 1) / p.rows_wg);
+  p.m_pad = (long)p.rowblocks * p.rows_wg;
   if (const char *e = getenv("MXA_I8_SPLITS")) splits = std::max<long>(1, std::min<long>(max_splits, atol(e)));   // A/B measurement
   splits = std::max<long>(splits, (p.stages_total + 32767) / 32768);   // int32 accumulators: 2 * 128 * (K per split) < 2^31
   p.stages_per_split = (int)((p.stages_total + splits - 1) / splits);
@@ -818,7 +841,7 @@ static I8Plan plan_i8(long m, long k_pad, int n, int S_override) {
 
 template <int NT, int MT, int WC>
 static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const I8Plan &p, hipStream_t s, const int *skip_if_set, const I8Direct &dir) {
-  using Cfg = I8Cfg<NT>;
+  using Cfg = I8Cfg<NT, MT * (4 / WC) * 32>;
   static unsigned long long attr_a = 0, attr_b = 0;   // function attributes are per device
   if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8<NT, MT, WC, false>), Cfg::kLds, &attr_a) ||
       ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8<NT, MT, WC, true>), Cfg::kLds, &attr_b)) return 1;
@@ -954,7 +977,7 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   if (direct_on && small_tile && p.splits == 1)
     dir = I8Direct{1, d_E, d_part, dC, ldc, m, fill_rows, n, p.S, p.nc, trans ? 1 : 0, centered ? 1 : 0, d_sumB, d_sumfB, d_f};
   switch (p.NT) {
-    case 1: rc = launch_i8_t<1, 2, 1>(G, d_Bs, d_P, p, s, skip, dir); break;
+    case 1: rc = p.rows_wg == kTileRows ? launch_i8_t<1, 2, 1>(G, d_Bs, d_P, p, s, skip, dir) : launch_i8_t<1, 1, 1>(G, d_Bs, d_P, p, s, skip, dir); break;
     case 2: rc = launch_i8_t<2, 2, 1>(G, d_Bs, d_P, p, s, skip, dir); break;
     case 3: rc = launch_i8_t<3, 2, 1>(G, d_Bs, d_P, p, s, skip, dir); break;
     case 4: rc = launch_i8_t<4, 2, 1>(G, d_Bs, d_P, p, s, skip, dir); break;

@@ -241,3 +241,29 @@ def test_result_does_not_depend_on_ldc_or_operand_residence(mx, n, trans, center
             assert np.all(buf[:, m:].cpu().numpy() == 0.0)
     finally:
         dg.free_compressed(obj)
+
+
+@pytest.mark.parametrize("snps,indiv", [(2051, 777), (700, 3001), (130, 129)])
+def test_half_tile_workgroups_experiment(mx, snps, indiv):
+    """MXA_I8_HALF_TILE=1: k_gemm_i8<1,1,1>, 128-row workgroups that finish an n <= 2 product inside the kernel without K splits (a measured dead end for
+    speed, profiles/r04_i8_half_tile_ab.txt; kept as an experiment, so it has to stay correct): odd numbers of half tiles, last half beyond m, both
+    products, centred, against the long-double oracle at the exact route's bound"""
+    import os
+    o = Oracle()
+    dg = mx.dgemm_compressed
+    prob = make_problem(snps, indiv, 2, seed=31, missing_frac=0.02)
+    dg.set_options(use_gpu=True, not_center=False, verbose=0)
+    obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], 2)
+    os.environ["MXA_I8_HALF_TILE"] = "1"
+    try:
+        for n in (1, 2):
+            for trans in (0, 1):
+                k = indiv if trans else snps
+                B = np.random.default_rng(7 + n).standard_normal((n, k))
+                C = _run(mx, obj, prob, trans, B)
+                assert dg.last_path() == "k_gemm_i8"
+                ref = o.dgemm_dense(trans, prob, B, 1)[:, : C.shape[1]]
+                assert np.abs(C - ref).max() <= 1e-11 * np.abs(ref).max()
+    finally:
+        os.environ.pop("MXA_I8_HALF_TILE", None)
+        dg.free_compressed(obj)
