@@ -196,13 +196,16 @@ void oracle5_free(void *hh) {
 /* genoVector kernel for up to VATONCE = 4 right-hand side columns per pass over the code matrix (the reference interleaves VatOnce = 4 columns in
  * one AVX2 register, 5codesIntern.h:130-266; each column's arithmetic is independent and identical to the one-column scalar form, so the
  * results do not depend on how the columns are grouped -- checked bit for bit against the reference library in tests/test_oracle.py). */
-/* Columns per pass: 1.  Four per pass (the reference's VatOnce) is 1.5x faster on the build container's Xeon but 1.5x SLOWER for 'N' on the GPU
- * hosts' EPYC 9575F (16 cores: N 1.22 s against 0.79 s on the 100k x 50k x 32 sample; T 1.80 s either way), where the baseline is timed. */
+/* Columns per pass: 1.  Four per pass (the reference's VatOnce) is 1.5x faster on the build container's Xeon but no faster on the GPU hosts' EPYC
+ * 9575F, where the baseline is timed (16 cores, 100k x 50k x 32 sample: N 0.437 s / T 0.476 s against 0.423 / 0.437 with one column per pass). */
 #ifndef GV5_VATONCE
 #define GV5_VATONCE 1
 #endif
+/* scratch of a product: the 243-entry tables and the partial vectors, allocated once per oracle5_dgemm call and reused by its passes (the
+ * reference allocates them once per call for all columns, 5codesIntern.h:96-128; a fresh calloc per pass costs the page faults of 64 MB each time) */
+typedef struct { double *F; size_t f_len; double *Tmp; size_t tmp_len; } gv5_scratch;
 static void gv5_kernel(const uint8_t *code, long rows, long cols, long groups_padded, const double *const *v, int nv, int cores,
-                       double *const *ans) {
+                       double *const *ans, gv5_scratch *sc) {
   const long colsCpB = div_geq(cols, 5);
   const long colBlocks = div_geq(colsCpB, 4);
   long blockSliceLen = div_geq(colBlocks, (long)cores * 5); /* coreFactor 5: 5codesIntern.h:54 */
@@ -214,7 +217,11 @@ static void gv5_kernel(const uint8_t *code, long rows, long cols, long groups_pa
   (void)groups_padded;
   /* hash tables: [group][column q][243] so that the nv tables of a group are neighbours */
   const size_t fstride = (size_t)nv * 243;
-  double *F = (double *)calloc((size_t)colBlocks * 4 * fstride, sizeof(double));
+  const size_t f_len = (size_t)colBlocks * 4 * fstride;
+  if (sc->f_len < f_len) { free(sc->F); sc->F = (double *)malloc(f_len * sizeof(double)); sc->f_len = f_len; }
+  double *F = sc->F;
+#pragma omp parallel for schedule(static) num_threads(cores)
+  for (long i = colsCpB; i < colBlocks * 4; i++) memset(F + (size_t)i * fstride, 0, fstride * sizeof(double));   /* tables of the padding groups */
 #pragma omp parallel for schedule(static) num_threads(cores)
   for (long i = 0; i < colsCpB; i++) {
     for (int q = 0; q < nv; q++) {
@@ -244,7 +251,11 @@ static void gv5_kernel(const uint8_t *code, long rows, long cols, long groups_pa
   }
   /* main loop: one partial vector per slice and column (+1 zero slab per column used by the tree) */
   const size_t tstride = (size_t)(blocks + 1) * rows;
-  double *Tmp = (double *)calloc((size_t)nv * tstride, sizeof(double));
+  if (sc->tmp_len < (size_t)nv * tstride) { free(sc->Tmp); sc->Tmp = (double *)malloc((size_t)nv * tstride * sizeof(double)); sc->tmp_len = (size_t)nv * tstride; }
+  double *Tmp = sc->Tmp;
+#pragma omp parallel for schedule(static) num_threads(cores)
+  for (long Cb = 0; Cb <= blocks; Cb++)     /* every thread clears the slabs it is about to accumulate into (and the zero slab the tree reads) */
+    for (int q = 0; q < nv; q++) memset(Tmp + (size_t)q * tstride + rows * Cb, 0, (size_t)rows * sizeof(double));
   const long RoughRowChunk = 35000;
   long rowBlocks = rows / RoughRowChunk; if (rowBlocks < 1) rowBlocks = 1;
   const long RowChunk = div_geq(rows, rowBlocks);
@@ -277,26 +288,32 @@ static void gv5_kernel(const uint8_t *code, long rows, long cols, long groups_pa
       }
     }
   }
-  /* 4-way tree sum of the slices, per column */
-  for (int q = 0; q < nv; q++) {
-    double *T = Tmp + (size_t)q * tstride;
-    const long blocksXrows = blocks * rows;
-    long level = rows, tmpCols = blocks;
-    while (tmpCols > 1) {
-      long tmpC4 = div_geq(tmpCols - 1, 4);
-      for (long k = 0; k < tmpC4; k++) {
-        long kS = k * 4;
-        long o0 = (kS + 0) * level, o1 = (kS + 1) * level, o2 = (kS + 2) * level, o3 = (kS + 3) * level;
-        double *t0 = T + (o0 < blocksXrows ? o0 : blocksXrows), *t1 = T + (o1 < blocksXrows ? o1 : blocksXrows);
-        double *t2 = T + (o2 < blocksXrows ? o2 : blocksXrows), *t3 = T + (o3 < blocksXrows ? o3 : blocksXrows);
-        for (long j = 0; j < rows; j++) t0[j] = (t0[j] + t1[j]) + (t2[j] + t3[j]);
+  /* 4-way tree sum of the slices, per column (5codesIntern.h:321-341).  The reference runs this loop in parallel over its groups of columns
+   * (:408-411); here every pass handles one group, so the rows are dealt to the threads instead -- each thread walks the whole tree for its
+   * own rows: the same additions in the same order for every element. */
+  const long blocksXrows = blocks * rows;
+  const long chunk = 4096;
+#pragma omp parallel for schedule(static) num_threads(cores)
+  for (long r0 = 0; r0 < rows; r0 += chunk) {
+    const long r1 = r0 + chunk < rows ? r0 + chunk : rows;
+    for (int q = 0; q < nv; q++) {
+      double *T = Tmp + (size_t)q * tstride;
+      long level = rows, tmpCols = blocks;
+      while (tmpCols > 1) {
+        long tmpC4 = div_geq(tmpCols - 1, 4);
+        for (long k = 0; k < tmpC4; k++) {
+          long kS = k * 4;
+          long o0 = (kS + 0) * level, o1 = (kS + 1) * level, o2 = (kS + 2) * level, o3 = (kS + 3) * level;
+          double *t0 = T + (o0 < blocksXrows ? o0 : blocksXrows), *t1 = T + (o1 < blocksXrows ? o1 : blocksXrows);
+          double *t2 = T + (o2 < blocksXrows ? o2 : blocksXrows), *t3 = T + (o3 < blocksXrows ? o3 : blocksXrows);
+          for (long j = r0; j < r1; j++) t0[j] = (t0[j] + t1[j]) + (t2[j] + t3[j]);
+        }
+        level *= 4;
+        tmpCols = div_geq(tmpCols, 4);
       }
-      level *= 4;
-      tmpCols = div_geq(tmpCols, 4);
+      for (long bb = r0; bb < r1; bb++) ans[q][bb] = T[bb];
     }
-    for (long bb = 0; bb < rows; bb++) ans[q][bb] = T[bb];
   }
-  free(F); free(Tmp);
 }
 
 void oracle5_dgemm(void *hh, int trans, int centered, long n, const double *B, long ldb, double *C, long ldc) {
@@ -305,13 +322,15 @@ void oracle5_dgemm(void *hh, int trans, int centered, long n, const double *B, l
   const uint8_t *code = trans ? h->code_T : h->code_N;
   const long groups = trans ? h->groups_T : h->groups_N;
   memset(C, 0, (size_t)ldc * n * sizeof(double)); /* 5codesIntern.h:67 */
+  gv5_scratch sc = {0, 0, 0, 0};
   for (long j0 = 0; j0 < n; j0 += GV5_VATONCE) {
     const int nv = (int)(n - j0 < GV5_VATONCE ? n - j0 : GV5_VATONCE);
     const double *vv[GV5_VATONCE];
     double *aa[GV5_VATONCE];
     for (int q = 0; q < nv; q++) { vv[q] = B + (j0 + q) * ldb; aa[q] = C + (j0 + q) * ldc; }
-    gv5_kernel(code, rows, cols, groups, vv, nv, h->cores, aa);
+    gv5_kernel(code, rows, cols, groups, vv, nv, h->cores, aa, &sc);
   }
+  free(sc.F); free(sc.Tmp);
   for (long j = 0; j < n; j++) {
     const double *v = B + j * ldb;
     double *a = C + j * ldc;
