@@ -326,11 +326,11 @@ long mxa_plan_partial_doubles(long m, long k, int n);
  * device's free memory while one does -- where the reference reports "Not enough device memory" (cuda_utils.cu:162-185) this build keeps one copy and
  * carries on (a line under PRINT_LEVEL > 0 says so); a multi-device object decides once for all its shards.  Only the SNP-major copy is stored -- half the HBM (config 5 at its
  * full 2M x 100k: 50 GB instead of 100) and half the staging upload; plink_transposed is not read.  Both products then read that one copy: 'T' in
- * the plain form, 'N' in the transposed-operand forms (fp64 MFMA: k_gemm<..., TR>, as fast as with two copies; n <= 2: k_gemm_i8_tn, ~13 % slower
- * than the plain int8 kernel).  Results are those of a two-copy object to rounding (bit-identical on the fp64 MFMA path).  What is given up:
- * for 'N' with 3 <= n <= 6 and for the peeled odd columns of 'N' the exact int8 shortcut has no transposed form -- those products take the fp64
- * MFMA tile (n = 3..6: 2-3x slower than the int8 route); the opt-in engines i8 / i8-exact apply to 'T' only; 'T' with n >= 7 runs the plain
- * fp64 MFMA form (0.925 instead of 0.957 of the peak).  mxa_single_orientation: 1 / 0 (multi-device object: of its shards), -1 for an invalid handle. */
+ * the plain form, 'N' in the transposed-operand forms (fp64 MFMA: k_gemm<..., TR>, as fast as with two copies; the exact int8 route of n <= 6 and
+ * of the peeled odd columns: k_gemm_i8_tn, one pass over the matrix per tile of 32 expanded columns -- n <= 3: one pass, ~13 % slower than the plain
+ * int8 kernel; n = 4..6: two passes, 2.4 ms against 1.4 on 500k x 50k, still ahead of the fp64 tile).  Results are those of a two-copy object to
+ * rounding (bit-identical on the fp64 MFMA path).  What is given up: the opt-in engines i8 / i8-exact at wide n apply to 'T' only; 'T' with
+ * n >= 7 runs the plain fp64 MFMA form (0.925 instead of 0.957 of the peak).  mxa_single_orientation: 1 / 0 (multi-device object: of its shards), -1 for an invalid handle. */
 int mxa_single_orientation(void *compressed);
 /* capacity (doubles) of the partial-sum workspace an object holds right now; -1 for an invalid / multi-device object */
 long mxa_partial_capacity(void *compressed);

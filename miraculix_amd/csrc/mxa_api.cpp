@@ -493,6 +493,11 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   // tile the extraction VALU hurts most, MFMA pipe busy 0.82 at best; n = 5, 6 need a peel pass on top).  There the int8 route is bound by the
   // packed-matrix stream like n <= 2 (1.3-1.9 ms against 3.2-4.4 ms on 500k x 50k), and it is taken only when it is exact.
   static const int auto_exact_max_n = [] { const char *e = getenv("MXA_AUTO_EXACT_MAX_N"); return e ? atoi(e) : 6; }();
+  // single-orientation object, 'N': the plain int8 kernel needs the individual-major copy; k_gemm_i8_tn multiplies from the SNP-major one, one pass per
+  // tile of 32 expanded columns (n <= 2: one tile; 3 <= n <= 6 and peeled columns: 1-5).  gemm_i8_device declines (2) what would take more passes than
+  // the fp64 MFMA tile in its transposed form costs, and products with several column chunks (the opt-in engines at wide n): those run on the fp64 path.
+  const bool no_plain = h->single && !trans;
+  const PackedMatrix *G_tn_single = no_plain ? &gemm_operand(h, trans, true) : nullptr;
   // columns [c0, c0 + nc) of this product through the exact int8 route with per-call digits: 0 done, 2 declined (not exact within 24 digits), 1 error
   auto exact_adaptive = [&](int c0, int nc, hipEvent_t e0, hipEvent_t e1, int *splits_out, int *digits_out) -> int {
     int hs[3] = {0, 0, 1};
@@ -503,13 +508,11 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     const int S = std::max(7, (hs[0] + 55 + 7) / 8);
     if (hs[2] || S > kI8ExactMaxDigits || hs[1] < 8 * S - 1023) return 2;
     if (digits_out) *digits_out = S;
-    return gemm_i8_device(G, trans, nc, dBc, ldb, dC + (size_t)c0 * ldc, ldc, fill_rows, centered, d_sumB + c0, d_sumfB + c0, h->d_f, w, s, e0, e1, splits_out, 0,
-                          nullptr, nullptr, S) ? 1 : 0;
+    const int rc = gemm_i8_device(G, trans, nc, dBc, ldb, dC + (size_t)c0 * ldc, ldc, fill_rows, centered, d_sumB + c0, d_sumfB + c0, h->d_f, w, s, e0, e1, splits_out, 0,
+                                  nullptr, nullptr, S, G_tn_single);
+    return rc == 2 ? 2 : rc ? 1 : 0;
   };
-  // single-orientation object, 'N': the int8 kernels with two or more column tiles (3 <= n <= 6, peeled columns, the opt-in engines) have no transposed form;
-  // those products take the fp64 MFMA tile in its transposed form (n <= 2 has k_gemm_i8_tn)
-  const bool no_plain = h->single && !trans;
-  if (!no_plain && (engine == 4 || ((engine == 0 || (engine == 2 && n > 4)) && n <= auto_exact_max_n)) && n >= 3 && k >= 128) {   // engine 2 = engine 0 for n > 4
+  if ((engine == 4 || ((engine == 0 || (engine == 2 && n > 4)) && n <= auto_exact_max_n)) && n >= 3 && k >= 128) {   // engine 2 = engine 0 for n > 4
     int splits8 = 1, S = 0;
     const int rcx = exact_adaptive(0, n, pe0, pe1, &splits8, &S);
     if (rcx == 1) return 1;
@@ -522,14 +525,14 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
       return 0;
     }
   }
-  if ((!no_plain && (engine == 1 || (engine == 2 && n <= 4))) || auto_i8) {   // exact int8 slicing of B on the int8 matrix cores (mxa_gemm_i8.hip)
+  if (engine == 1 || (engine == 2 && n <= 4) || auto_i8) {   // exact int8 slicing of B on the int8 matrix cores (mxa_gemm_i8.hip)
     int splits8 = 1;
     const int *d_flag = nullptr;
     // auto_i8: the verdict of the exactness check stays on the device (guard = 2) -- the int8 chain and the fp64 fallback are both enqueued and
     // test the flag themselves, so the product has no host round trip in its middle (44 us of a 1.2 ms product in the kernel timeline)
     // MXA_I8_TN=1 (round 4, A/B of single-orientation storage for the CG step): n <= 2 from the copy whose rows are the K index (k_gemm_i8_tn)
     const char *e_tn = getenv("MXA_I8_TN");
-    const PackedMatrix *G_tn = (auto_i8 && (no_plain || (!h->single && e_tn && atoi(e_tn) != 0))) ? &gemm_operand(h, trans, true) : nullptr;
+    const PackedMatrix *G_tn = no_plain ? G_tn_single : (auto_i8 && e_tn && atoi(e_tn) != 0) ? &gemm_operand(h, trans, true) : nullptr;
     const int rc8 = gemm_i8_device(G, trans, n, dB, ldb, dC, ldc, fill_rows, centered, d_sumB, d_sumfB, h->d_f, w, s, pe0, pe1,
                                    &splits8, auto_i8 ? 2 : 0, &d_flag, auto_i8 ? w.d_colpart : nullptr, 0, G_tn);
     if (rc8 == 0 || rc8 == 3) {
@@ -559,16 +562,16 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   // MFMA without padding.  If the guard declines, all n columns take the MFMA path as before.
   static const bool peel_on = [] { const char *e = getenv("MXA_PEEL"); return !e || atoi(e) != 0; }();
   const int n_odd = n & 3;
-  if (!no_plain && peel_on && (engine == 0 || engine == 2) && n > 4 && (n_odd == 1 || n_odd == 2) && k >= 128) {   // engine 2 = engine 0 for n > 4
+  if (peel_on && (engine == 0 || engine == 2) && n > 4 && (n_odd == 1 || n_odd == 2) && k >= 128) {   // engine 2 = engine 0 for n > 4
     const int n4 = n - n_odd;
     const int rc8 = gemm_i8_device(G, trans, n_odd, dB + (size_t)n4 * ldb, ldb, dC + (size_t)n4 * ldc, ldc, fill_rows, centered, d_sumB + n4, d_sumfB + n4, h->d_f, w, s,
-                                   nullptr, nullptr, nullptr, true);
+                                   nullptr, nullptr, nullptr, true, nullptr, nullptr, 0, G_tn_single);
     if (rc8 == 0) n = n4;            // the rest of this function multiplies the first n4 columns
     else if (rc8 != 2) return 1;
   }
   // n = 4q + 3, q >= 1 (round 3): the three odd columns through the exact route with per-call digits (1.2 ms on 500k x 50k) instead of a
   // quarter-full MFMA group (2.7-2.9 ms)
-  if (!no_plain && peel_on && (engine == 0 || engine == 2) && n > 6 && n_odd == 3 && k >= 128 && auto_exact_max_n >= 3) {
+  if (peel_on && (engine == 0 || engine == 2) && n > 6 && n_odd == 3 && k >= 128 && auto_exact_max_n >= 3) {
     const int rcx = exact_adaptive(n - 3, 3, nullptr, nullptr, nullptr, nullptr);
     if (rcx == 1) return 1;
     if (rcx == 0) n -= 3;

@@ -464,8 +464,10 @@ constexpr int kTnUnitsPerWave = (kTnSlabs * 8 + 8) / kTnWaves;   // 5 DMA units 
 // Wave (w4 = wave & 3, fh = wave >> 2): K-steps {2 w4, 2 w4 + 1} of every row block, MFMA groups f = 8 fh .. 8 fh + 7 (the bytes b = 2 fh, 2 fh + 1 of the
 // gathered words: half of the byte gather each, no VALU is duplicated; the two waves of a pair read the same 16 dwords from LDS).
 __global__ void __launch_bounds__(512, 1)
-k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__restrict__ Ad, int *__restrict__ P, long m_pad, int strips, int stages_total,
-             int stages_per_split, const int *__restrict__ skip_if_set) {
+k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__restrict__ Ad, int digit_tiles, int *__restrict__ P, long m_pad, int e_pad, int e_off,
+             int strips, int stages_total, int stages_per_split, const int *__restrict__ skip_if_set) {
+  // Ad: the digit fragments of THIS launch's tile of 32 expanded columns, K-steps digit_tiles KiB apart (k_slice_B interleaves the tiles of a K-step);
+  // the sums go to rows e_off .. e_off + 31 of P[split][e_pad][m_pad].  A product with several tiles (3 <= n <= 6, the opt-in engines) is one launch per tile.
   if (skip_if_set && *skip_if_set) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -490,7 +492,7 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
         if (sl >= nslabs_all) sl = nslabs_all - 1;           // individuals beyond the matrix: rows of P nobody reads
         idma16_stream(reinterpret_cast<const char *>(G) + (rb * (size_t)nslabs_all + (size_t)sl) * kTileBytes + (u & 7) * 1024, v_pack, base + (u >> 3) * kTnSlabStride + (u & 7) * 1024);
       } else {
-        idma16_s(reinterpret_cast<const char *>(Ad) + (rb * 8 + (size_t)(u - kTnSlabs * 8)) * 1024, v_lin, base + kTnDigitOff + (u - kTnSlabs * 8) * 1024);
+        idma16_s(reinterpret_cast<const char *>(Ad) + (rb * 8 + (size_t)(u - kTnSlabs * 8)) * ((size_t)digit_tiles * 1024), v_lin, base + kTnDigitOff + (u - kTnSlabs * 8) * 1024);
       }
     }
   };
@@ -541,7 +543,7 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
   // ---- add the accumulators of the four waves of a field half (disjoint K-steps) through LDS, two MFMA groups per pass, and store P[split][e][individual]
   __syncthreads();
   int *red = reinterpret_cast<int *>(smem);                  // [wave (8)][group in pass (2)][reg (16)][lane (64)] ints = 64 KiB
-  int *Pb = P + (size_t)sp * 32 * m_pad;
+  int *Pb = P + ((size_t)sp * e_pad + e_off) * m_pad;
 #pragma unroll
   for (int pass = 0; pass < 4; pass++) {
 #pragma unroll
@@ -896,13 +898,16 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   I8Plan p = plan_i8(m, G.k_pad, n, S_override);
   if (p.m_pad > G.rows_pad) { set_error(4, "internal: packed matrix smaller than the i8 plan"); return 1; }
   // transposed-operand form (G_tn = the copy whose ROWS are the K index; n <= 2 only): same digits, same exactness guard, other main kernel and P layout
-  const bool tn = G_tn != nullptr && p.nchunks == 1 && p.NT == 1 && p.nc <= 2;
+  // (several tiles of 32 expanded columns: one pass over the matrix per tile -- 3 <= n <= 6 and peeled columns of single-orientation objects; beyond what the
+  // fp64 MFMA tile would take, or with several column chunks, the caller's fp64 path is the better choice: declined with 2 before anything is enqueued)
+  if (G_tn != nullptr && (p.nchunks != 1 || p.NT > (n <= 4 ? 2 : 5))) return 2;
+  const bool tn = G_tn != nullptr;
   int tn_strips = 0, tn_stages = 0, tn_sps = 0, tn_splits = 0;
   if (tn) {
     if (G_tn->k != m || G_tn->rows != k) { set_error(4, "internal: transposed operand has the wrong shape"); return 1; }
     plan_i8_tn(G_tn->nslabs, G_tn->rows, &tn_strips, &tn_stages, &tn_sps, &tn_splits);
     if ((long)tn_stages * kTileRows > G_tn->rows_pad) { set_error(4, "internal: packed matrix smaller than the transposed i8 plan"); return 1; }
-    p.T_total = (long)tn_stages * 8; p.splits = tn_splits; p.m_pad = (long)tn_strips * kTnSlabs * kSlabK; p.e_pad = 32;
+    p.T_total = (long)tn_stages * 8; p.splits = tn_splits; p.m_pad = (long)tn_strips * kTnSlabs * kSlabK; p.e_pad = p.NT * 32;
   }
   if (splits_out) *splits_out = p.splits;
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
@@ -965,7 +970,9 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   if (tn) {
     static unsigned long long attr_tn = 0;
     if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8_tn), kTnLds, &attr_tn)) return 1;
-    hipLaunchKernelGGL(k_gemm_i8_tn, dim3((unsigned)(tn_strips * tn_splits)), dim3(512), kTnLds, s, G_tn->d, G_tn->nslabs, d_Bs, d_P, p.m_pad, tn_strips, tn_stages, tn_sps, skip);
+    for (int nt = 0; nt < p.NT; nt++)
+      hipLaunchKernelGGL(k_gemm_i8_tn, dim3((unsigned)(tn_strips * tn_splits)), dim3(512), kTnLds, s, G_tn->d, G_tn->nslabs, d_Bs + (size_t)nt * 1024, p.NT, d_P, p.m_pad, p.e_pad, nt * 32,
+                         tn_strips, tn_stages, tn_sps, skip);
     MXA_HIP(hipGetLastError());
     if (ev1) MXA_HIP(hipEventRecord(ev1, s));
     dim3 grid((unsigned)((fill_rows + 255) / 256), (unsigned)n);

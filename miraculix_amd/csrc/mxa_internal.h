@@ -240,7 +240,8 @@ int launch_sparse_times_plink(const uint8_t *dP, size_t pitch, long entries, int
 int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool centered, double *d_sumB,
                    double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out, int guard = 0,
                    const int **flag_out = nullptr, double *colsum_scratch = nullptr, int S_override = 0, const PackedMatrix *G_tn = nullptr);
-// G_tn (n <= 2 only): the OTHER stored orientation (rows = the K index); the main kernel then runs in the transposed-operand form k_gemm_i8_tn
+// G_tn: the OTHER stored orientation (rows = the K index); the main kernel then runs in the transposed-operand form k_gemm_i8_tn, one launch per tile of 32
+// expanded columns.  Returns 2 (nothing enqueued) when that would take more passes than the fp64 MFMA tile costs or the plan has several column chunks.
 
 // mxa_dense.hip: dense fp64 MFMA building blocks of the solver twin
 int launch_dgemm(bool ta, bool tb, long M, long N, long K, double alpha, const double *A, long lda, const double *B, long ldb, double beta, double *C, long ldc,

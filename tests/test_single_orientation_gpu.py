@@ -62,10 +62,7 @@ def test_every_n_both_products(mx, snps, indiv, n):
                 path2 = dg.last_path()
                 ref = o.dgemm_dense(trans, prob, B, centered)[:, :m]
                 assert np.abs(C1.T - ref).max() <= RTOL * np.abs(ref).max()
-                if trans or n <= 2:
-                    assert path1 == path2                                    # 'T' takes the same route as a two-copy object; so does n <= 2 (int8, transposed kernel)
-                else:
-                    assert path1 == "k_gemm"                                 # 'N', n >= 3: the fp64 MFMA tile in its transposed form
+                assert path1 == path2                                        # the same route as a two-copy object: 'N' with n <= 6 and the peeled columns on the transposed int8 kernel
                 if path1 == "k_gemm" and path2 == "k_gemm" and n % 4 == 0:
                     assert np.array_equal(C1, C2)                            # same plan, same sums
                 Bi = np.round(B * 64.0)
