@@ -228,3 +228,63 @@ def test_two_copies_that_do_not_fit_keep_one(mx):
     finally:
         del ballast
         torch.cuda.empty_cache()
+
+
+def test_bed_staging_under_a_memory_squeeze_keeps_one_copy(mx, tmp_path):
+    """the automatic policy on the .bed route (mxa_bed2compressed: raw block + its transpose + two packed copies do not fit, raw block + one packed copy
+    do), single-device and sharded: the object keeps one copy and multiplies like the two-copy object created before the squeeze"""
+    import torch
+    from bench import synth_genotypes_device
+    dg = mx.dgemm_compressed
+    L = mx.check_library_handle()
+    L.mxa_single_orientation.argtypes = [ctypes.c_void_p]
+    dev = torch.device("cuda", 0)
+    snps, indiv, n = 32_000, 24_000, 8
+    plink = synth_genotypes_device(torch, snps, indiv, 9, dev)
+    bed = tmp_path / "y.bed"
+    with open(bed, "wb") as fh:
+        fh.write(bytes([0x6C, 0x1B, 0x01]))
+        fh.write(plink.cpu().numpy().tobytes())
+    (tmp_path / "y.bim").write_text("\n".join("1 s 0 0 A B" for _ in range(snps)) + "\n")
+    (tmp_path / "y.fam").write_text("\n".join("f i 0 0 0 0" for _ in range(indiv)) + "\n")
+    del plink
+    g = torch.Generator(device=dev); g.manual_seed(10)
+    Bn = torch.randn((n, snps), dtype=torch.float64, device=dev, generator=g).t()
+    Bt = torch.randn((n, indiv), dtype=torch.float64, device=dev, generator=g).t()
+    dg.set_options(use_gpu=True, not_center=False, verbose=0)
+    os.environ.pop("MXA_SINGLE_ORIENTATION", None)
+
+    def products(obj):
+        out = [dg.dgemm_compressed_main(False, obj, Bn, snps, indiv).clone(), dg.dgemm_compressed_main(True, obj, Bt, snps, indiv).clone()]
+        torch.cuda.synchronize()
+        return out
+
+    obj, _, _, _ = dg.init_compressed_from_bed(str(bed), n)
+    assert L.mxa_single_orientation(obj) == 0
+    ref = products(obj)
+    dg.free_compressed(obj)
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    one_copy = (snps + 256) * ((indiv + 128) // 4)                     # 194 MB; the raw block is about as big
+    free_b, _ = torch.cuda.mem_get_info()
+    ballast = torch.empty(free_b - int(2.7 * one_copy), dtype=torch.uint8, device=dev)   # raw + one copy fit (2x), raw + transpose + two copies (4x) do not
+    try:
+        for shards in (1, 2):
+            if shards > 1:
+                os.environ["MIRACULIX_NUM_GPUS"] = str(shards)
+            try:
+                obj, _, _, _ = dg.init_compressed_from_bed(str(bed), n)
+            finally:
+                os.environ.pop("MIRACULIX_NUM_GPUS", None)
+            try:
+                assert dg.num_shards(obj) == shards and L.mxa_single_orientation(obj) == 1
+                got = products(obj)
+                assert torch.equal(got[1], ref[1])
+                if shards == 1:
+                    assert torch.equal(got[0], ref[0])
+                else:
+                    assert float((got[0] - ref[0]).abs().max()) <= RTOL * float(ref[0].abs().max())
+            finally:
+                dg.free_compressed(obj)
+    finally:
+        del ballast
+        torch.cuda.empty_cache()
