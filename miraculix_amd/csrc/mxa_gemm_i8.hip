@@ -897,7 +897,7 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   const long m = G.rows, k = G.k;
   I8Plan p = plan_i8(m, G.k_pad, n, S_override);
   if (p.m_pad > G.rows_pad) { set_error(4, "internal: packed matrix smaller than the i8 plan"); return 1; }
-  // transposed-operand form (G_tn = the copy whose ROWS are the K index; n <= 2 only): same digits, same exactness guard, other main kernel and P layout
+  // transposed-operand form (G_tn = the copy whose ROWS are the K index): same digits, same exactness guard, other main kernel and P layout
   // (several tiles of 32 expanded columns: one pass over the matrix per tile -- 3 <= n <= 6 and peeled columns of single-orientation objects; beyond what the
   // fp64 MFMA tile would take, or with several column chunks, the caller's fp64 path is the better choice: declined with 2 before anything is enqueued)
   if (G_tn != nullptr && (p.nchunks != 1 || p.NT > (n <= 4 ? 2 : 5))) return 2;

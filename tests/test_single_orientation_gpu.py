@@ -1,8 +1,9 @@
-"""Single-orientation objects (round 4; MXA_SINGLE_ORIENTATION=1 when plink2compressed runs): only the SNP-major copy is stored; 'T' products run in the
+"""Single-orientation objects (round 4; MXA_SINGLE_ORIENTATION=1 when plink2compressed runs, or by itself when two packed copies do not fit the device): only the SNP-major copy is stored; 'T' products run in the
 plain form, 'N' products in the transposed-operand forms (k_gemm<..., TR>, k_gemm_i8_tn) on the same copy (halves the HBM
 footprint and the staging upload).  Every n, both products, centred and not, missing codes, ragged sizes, padded leading dimensions, the range and
 exactness fallbacks, mxa_gram_matvec, SNP shards behind MIRACULIX_NUM_GPUS, staging from a .bed file -- against the long-double oracle, against the
-two-copy object (bit-identical on the fp64 MFMA path and for integer-valued B), and the device memory the object holds."""
+two-copy object (bit-identical on the fp64 MFMA path and for integer-valued B), the device memory the object holds, and the automatic case under a
+memory squeeze (a ballast tensor fills the device)."""
 import ctypes
 import os
 
