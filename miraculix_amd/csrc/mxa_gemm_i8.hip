@@ -21,6 +21,7 @@
 // int8 slices of B are pre-arranged in MFMA fragment order by k_slice_B so every LDS read is a lane-linear ds_read_b128.
 #include "mxa_internal.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -452,27 +453,38 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
 // 16..31 of every unit rotated by one row (done on the GLOBAL side of the lane-linear DMA), so that the 64 lanes of a W load hit 64 different banks
 // (bank = dword of the column group (8) + 8 * khalf + 16 * slab).
 // Partial sums go to P[split][e][individual] like the operand-swapped plain instantiations: k_finish_i8_t finishes them (exact int64 over the splits).
-constexpr int kTnSlabs = 4;                                   // slabs (128 individuals) per workgroup strip
 constexpr int kTnSlabStride = kTileBytes + 64;                // LDS bytes between the slab regions of a stage
-constexpr int kTnDigitOff = kTnSlabs * kTnSlabStride;         // digit fragments of the stage's 8 K-steps (8 KiB) behind them
-constexpr int kTnBufBytes = kTnDigitOff + 8 * 1024;
 constexpr int kTnBufs = 3;
-constexpr int kTnLds = kTnBufs * kTnBufBytes;                 // 123 648 B
-constexpr int kTnWaves = 8;                                   // 512 threads: two waves per SIMD (the first version, 4 waves with all 16 groups each, was latency-bound: 1.15-1.24 ms)
-constexpr int kTnUnitsPerWave = (kTnSlabs * 8 + 8) / kTnWaves;   // 5 DMA units per wave and stage
+// SLABS = slabs (128 individuals) per workgroup strip; workgroup = 2 SLABS waves.
+//   SLABS = 4 (first version): 512 individuals, 8 waves, one workgroup per CU (LDS 121 KiB).  Wave (w4 = wave & 3, fh = wave >> 2): K-steps {2 w4, 2 w4 + 1} of
+//              every row block, MFMA groups f = 8 fh .. 8 fh + 7 (the bytes 2 fh, 2 fh + 1 of the gathered words; the two waves of a pair read the same dwords).
+//   SLABS = 2: 256 individuals, 4 waves, TWO workgroups per CU (72 KiB each) that fill each other's barrier and DMA waits, and twice as many, half as long
+//              workgroups for the rounds.  Only 16 column groups exist, so the byte-pair split moves from the waves INTO the lanes: lane (cg = lane & 15,
+//              fh = (lane >> 4) & 1, khalf = lane >> 5) -- the two lanes of a column group read the same dword (an LDS broadcast) and gather different byte
+//              pairs (the v_perm selector is per lane); MFMA group j multiplies the individuals 16 cg + 8 fh + j.  Wave w: K-steps {2 w, 2 w + 1}.
+template <int SLABS>
+struct TnCfg {
+  static constexpr int kWaves = 2 * SLABS;
+  static constexpr int kDigitOff = SLABS * kTnSlabStride;     // digit fragments of the stage's 8 K-steps (8 KiB) behind the slab regions
+  static constexpr int kBufBytes = kDigitOff + 8 * 1024;
+  static constexpr int kLds = kTnBufs * kBufBytes;            // 123 648 B (SLABS = 4), 74 112 B (SLABS = 2)
+  static constexpr int kUnitsPerWave = (SLABS * 8 + 8) / kWaves;   // DMA units per wave and stage: 5 / 6
+  static_assert((SLABS == 4 || SLABS == 2) && (SLABS * 8 + 8) % kWaves == 0, "strip shape");
+};
 
-// Wave (w4 = wave & 3, fh = wave >> 2): K-steps {2 w4, 2 w4 + 1} of every row block, MFMA groups f = 8 fh .. 8 fh + 7 (the bytes b = 2 fh, 2 fh + 1 of the
-// gathered words: half of the byte gather each, no VALU is duplicated; the two waves of a pair read the same 16 dwords from LDS).
-__global__ void __launch_bounds__(512, 1)
+template <int SLABS>
+__global__ void __launch_bounds__(128 * SLABS, SLABS == 2 ? 2 : 1)
 k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__restrict__ Ad, int digit_tiles, int *__restrict__ P, long m_pad, int e_pad, int e_off,
              int strips, int stages_total, int stages_per_split, const int *__restrict__ skip_if_set) {
   // Ad: the digit fragments of THIS launch's tile of 32 expanded columns, K-steps digit_tiles KiB apart (k_slice_B interleaves the tiles of a K-step);
   // the sums go to rows e_off .. e_off + 31 of P[split][e_pad][m_pad].  A product with several tiles (3 <= n <= 6, the opt-in engines) is one launch per tile.
+  using Cfg = TnCfg<SLABS>;
   if (skip_if_set && *skip_if_set) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int w4 = wave & 3, fh = wave >> 2;
+  const int w4 = wave & 3;
+  const int fh = SLABS == 4 ? wave >> 2 : (lane >> 4) & 1;    // field half: wave-uniform (8 waves) or per lane (4 waves)
   const int strip = blockIdx.x % strips, sp = blockIdx.x / strips;
   const int st0 = sp * stages_per_split, st1 = min(st0 + stages_per_split, stages_total);
   const int stages = st1 - st0;
@@ -482,17 +494,17 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
   const uint32_t v_pack = lane < 32 ? (uint32_t)lane * 16 : (uint32_t)(2 * (16 + ((rho + 15) & 15)) + (lane & 1)) * 16;
   const uint32_t v_lin = (uint32_t)lane * 16;
   auto issue = [&](int stage, int buf) {   // stage relative to st0
-    const uint32_t base = lds0 + buf * kTnBufBytes;
+    const uint32_t base = lds0 + buf * Cfg::kBufBytes;
     const size_t rb = (size_t)(st0 + stage);
 #pragma unroll
-    for (int i = 0; i < kTnUnitsPerWave; i++) {
-      const int u = wave + i * kTnWaves;                     // 0..31: packed units (slab j = u >> 3, K-step u & 7); 32..39: digit units
-      if (u < kTnSlabs * 8) {
-        long sl = (long)strip * kTnSlabs + (u >> 3);
+    for (int i = 0; i < Cfg::kUnitsPerWave; i++) {
+      const int u = wave + i * Cfg::kWaves;                  // packed units first (slab j = u >> 3, K-step u & 7), then the 8 digit units
+      if (u < SLABS * 8) {
+        long sl = (long)strip * SLABS + (u >> 3);
         if (sl >= nslabs_all) sl = nslabs_all - 1;           // individuals beyond the matrix: rows of P nobody reads
         idma16_stream(reinterpret_cast<const char *>(G) + (rb * (size_t)nslabs_all + (size_t)sl) * kTileBytes + (u & 7) * 1024, v_pack, base + (u >> 3) * kTnSlabStride + (u & 7) * 1024);
       } else {
-        idma16_s(reinterpret_cast<const char *>(Ad) + (rb * 8 + (size_t)(u - kTnSlabs * 8)) * ((size_t)digit_tiles * 1024), v_lin, base + kTnDigitOff + (u - kTnSlabs * 8) * 1024);
+        idma16_s(reinterpret_cast<const char *>(Ad) + (rb * 8 + (size_t)(u - SLABS * 8)) * ((size_t)digit_tiles * 1024), v_lin, base + Cfg::kDigitOff + (u - SLABS * 8) * 1024);
       }
     }
   };
@@ -501,7 +513,7 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
   for (int f = 0; f < 8; f++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[f][r] = 0;
-  const int cg = lane & 31, khalf = lane >> 5;
+  const int cg = SLABS == 4 ? lane & 31 : lane & 15, khalf = lane >> 5;
   // byte offset of W[r] inside a packed unit: slab region + row position (rotated for the upper half) * 32 + dword of the column group
   int w_off[16];
 #pragma unroll
@@ -511,19 +523,23 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
   if (stages > 0) issue(0, 0);
   if (stages > 1) issue(1, 1);
   for (int s = 0; s < stages; s++) {
-    if (s + 1 < stages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kTnUnitsPerWave) : "memory");   // stage s has landed (stage s + 1 may be in flight)
+    if (s + 1 < stages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::kUnitsPerWave) : "memory");   // stage s has landed (stage s + 1 may be in flight)
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                         // ... for every wave; and everybody is done with stage s - 1, whose buffer is refilled now
     if (s + 2 < stages) issue(s + 2, (s + 2) % kTnBufs);
-    const char *bufp = smem + (s % kTnBufs) * kTnBufBytes;
+    const char *bufp = smem + (s % kTnBufs) * Cfg::kBufBytes;
+#if defined(MXA_I8_TN_EXP_NOCOMPUTE)   // experiment (wrong results): DMA ring and barriers only -- what the workgroup structure alone delivers
+    if (lane == 0 && bufp[0] == 77) acc[0][0] += 1;
+    continue;
+#endif
 #pragma unroll
     for (int kk = 0; kk < 2; kk++) {
       const int T = 2 * w4 + kk;                             // K-step of this wave inside the row block
-      const v4i af = *reinterpret_cast<const v4i *>(bufp + kTnDigitOff + T * 1024 + lane * 16);
+      const v4i af = *reinterpret_cast<const v4i *>(bufp + Cfg::kDigitOff + T * 1024 + lane * 16);
       uint32_t W[16];
 #pragma unroll
       for (int r = 0; r < 16; r++) W[r] = *reinterpret_cast<const uint32_t *>(bufp + T * 1024 + w_off[r]);
-      // byte gather, this wave's half: Pq[q][bb] byte i = byte (2 fh + bb) of W[4 i + q]
+      // byte gather, this wave's / lane's half: Pq[q][bb] byte i = byte (2 fh + bb) of W[4 i + q]
       uint32_t Pq[4][2];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
@@ -540,10 +556,11 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
       }
     }
   }
-  // ---- add the accumulators of the four waves of a field half (disjoint K-steps) through LDS, two MFMA groups per pass, and store P[split][e][individual]
+  // ---- add the accumulators of the four waves that split the K-steps (per field half) through LDS, two MFMA groups per pass, and store P[split][e][individual]
   __syncthreads();
-  int *red = reinterpret_cast<int *>(smem);                  // [wave (8)][group in pass (2)][reg (16)][lane (64)] ints = 64 KiB
+  int *red = reinterpret_cast<int *>(smem);                  // [wave][group in pass (2)][reg (16)][lane (64)] ints = 8 KiB per wave
   int *Pb = P + ((size_t)sp * e_pad + e_off) * m_pad;
+  const int wbase = SLABS == 4 ? 4 * (wave >> 2) : 0;        // the four waves whose sums belong together
 #pragma unroll
   for (int pass = 0; pass < 4; pass++) {
 #pragma unroll
@@ -555,13 +572,13 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
       const int gq = w4 & 1, r0 = 8 * (w4 >> 1);             // this wave finishes group gq of its field half, registers r0 .. r0 + 7
       const int f = 8 * fh + 2 * pass + gq;                  // field of the dword = individual 16 cg + f
       const int sh = (f & 3) == 3 ? 4 : 2 * (f & 3);         // the in-place field scale of the group: 4^g, 16 for the top field
-      const long indiv = (long)strip * (kTnSlabs * kSlabK) + 16 * cg + f;
+      const long indiv = (long)strip * (SLABS * kSlabK) + 16 * cg + f;
 #pragma unroll
       for (int rr = 0; rr < 8; rr++) {
         const int r = r0 + rr;
         int v = 0;
 #pragma unroll
-        for (int w = 0; w < 4; w++) v += red[(((4 * fh + w) * 2 + gq) * 16 + r) * 64 + lane];
+        for (int w = 0; w < 4; w++) v += red[(((wbase + w) * 2 + gq) * 16 + r) * 64 + lane];
         const int e = (r & 3) + 8 * (r >> 2) + 4 * khalf;
         Pb[(size_t)e * m_pad + indiv] = v >> sh;             // exact: every product carried the factor
       }
@@ -665,33 +682,50 @@ __global__ void __launch_bounds__(256) k_finish_i8(const int *__restrict__ P, lo
 // finish for the TRANSPOSED partial sums of the operand-swapped instantiations (NT >= 2): P[split][e][row], e = chunk * NT * 32 + s * nc + jj.
 // One thread per (row, column): every load is a 1 KiB run along the rows, C is written along the rows.  Same arithmetic, in the same order, as
 // k_finish_i8: exact int64 sums over the splits, digits added smallest scale first.
+// Block = 64 rows x 4 digit groups (round 4; was one thread per row walking all S digits and K splits in a chain of dependent loads: 100-170 us behind a
+// 1 ms product).  Thread (row, g) owns the digits s in [g Sg, (g + 1) Sg), Sg = ceil(S / 4) <= 8: all their partial sums over the K splits are loaded
+// before the first use (rows along the lanes: 256-byte runs), added exactly (int64), scaled (exact) and added smallest scale first; the four groups of a
+// row are then added smallest first through LDS -- a fixed order, at most Sg + 3 roundings per result.
+constexpr int kFinTGroups = 4;
 __global__ void __launch_bounds__(256) k_finish_i8_t(const int *__restrict__ P, long m_pad, int e_pad, int splits, long m, int n, int S, int nc, int NT,
                                                      const int *__restrict__ E, const double *__restrict__ colmax_part, double *__restrict__ Cout, long ldc,
                                                      long fill_rows, int mode_trans, int centered, const double *__restrict__ sumB, const double *__restrict__ sumfB,
                                                      const double *__restrict__ f, const int *__restrict__ skip_if_set) {
   if (skip_if_set && *skip_if_set) return;
   const int j = blockIdx.y, chunk = j / nc, jj = j - chunk * nc;
-  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long r = (long)blockIdx.x * 64 + lane;
   __shared__ int bad;
+  __shared__ double part[kFinTGroups][64];
   if (threadIdx.x == 0) {
     double cm = 0.0;
     for (int c = 0; c < 64; c++) cm = fmax(cm, colmax_part[(size_t)j * 64 + c]);
     bad = !(cm <= 1.7976931348623157e308);      // column holds an inf or a NaN: the result column is NaN, like 0 * inf in fp64
   }
-  __syncthreads();
-  if (r >= fill_rows) return;
   double v = 0.0;
   if (r < m) {
-    if (bad) v = __longlong_as_double(0x7ff8000000000000ll);
-    else {
-      const int Ej = E[j];
-      const int *p0 = P + (size_t)(chunk * (NT * 32) + jj) * m_pad + r;
-      for (int s = S - 1; s >= 0; s--) {
-        long long t = 0;
-        for (int sp = 0; sp < splits; sp++) t += p0[((size_t)sp * e_pad + (size_t)s * nc) * m_pad];
-        v += ldexp((double)t, Ej - 8 * (s + 1));
-      }
+    const int Sg = (S + kFinTGroups - 1) / kFinTGroups, s0 = g * Sg;
+    const int Ej = E[j];
+    const int *p0 = P + (size_t)(chunk * (NT * 32) + jj) * m_pad + r;
+    long long t[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = 0;
+    for (int sp = 0; sp < splits; sp++) {
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        if (i < Sg && s0 + i < S) t[i] += p0[((size_t)sp * e_pad + (size_t)(s0 + i) * nc) * m_pad];
     }
+#pragma unroll
+    for (int i = 7; i >= 0; i--)
+      if (i < Sg && s0 + i < S) v += ldexp((double)t[i], Ej - 8 * (s0 + i + 1));
+  }
+  part[g][lane] = v;
+  __syncthreads();
+  if (g != 0 || r >= fill_rows) return;
+  v = 0.0;
+  if (r < m) {
+    if (bad) v = __longlong_as_double(0x7ff8000000000000ll);
+    else v = ((part[3][lane] + part[2][lane]) + part[1][lane]) + part[0][lane];
     if (centered) {
       if (mode_trans) v = fma(-2.0 * sumB[j], f[r], v);
       else v += -2.0 * sumfB[j];
@@ -875,20 +909,36 @@ static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const 
 // handle and only grows.
 // K splits of the transposed-operand kernel: workgroups = strips x splits on one resident workgroup per CU; the split count whose last round of
 // workgroups is fullest, counting a start-up worth a few stages per workgroup; at most 2047 stages per split (int32 accumulators)
-static void plan_i8_tn(long indiv_slabs, long snp_rows, int *strips, int *stages_total, int *stages_per_split, int *splits) {
-  *strips = (int)((indiv_slabs + kTnSlabs - 1) / kTnSlabs);
+static void plan_i8_tn(long indiv_slabs, long snp_rows, int slabs_wg, int *strips, int *stages_total, int *stages_per_split, int *splits) {
+  *strips = (int)((indiv_slabs + slabs_wg - 1) / slabs_wg);
   *stages_total = (int)((snp_rows + kTileRows - 1) / kTileRows);
-  long best_cost = -1; int best = 1;
+  const double slots = 256.0 * (slabs_wg == 2 ? 2 : 1);      // resident workgroups
+  // Cost in stage times: whole rounds of the resident slots (a workgroup keeps two stages in flight and does not run faster when its neighbours have
+  // finished, so a thinly filled last round costs a whole one) x (stages per workgroup + 35 stages' worth of start-up, LDS reduction and stores -- the value
+  // that ranks the measured sweeps right: config-5 shard 'N' 2 .. 13 splits = 1.17, 1.05, 1.09, 1.03 (5: chosen), 1.11, 1.07, 1.07, 1.05 ms; 'T' 1 split
+  // 1.00 against 1.08 with 2; tools/gpu_r4_tn_splits.sh) + the finish kernel's pass over the partial sums.
+  double best_cost = -1.0; int best = 1;
   for (int cand = 1; cand <= 64 && cand <= *stages_total; cand++) {
     const long per = (*stages_total + cand - 1) / cand, actual = (*stages_total + per - 1) / per;
     if (actual != cand || per > 2047) continue;
-    const long rounds = ((long)*strips * actual + 255) / 256;
-    const long cost = rounds * (per + 6);
+    const double rounds = std::ceil((double)*strips * actual / slots);
+    const double cost = rounds * ((double)per + 35.0) + (double)actual * (double)*strips * slabs_wg * kSlabK * 128.0 / 3.0e6;
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cand; }
   }
   if (const char *e = getenv("MXA_I8_TN_SPLITS")) best = std::max(1, std::min(*stages_total, atoi(e)));
   *stages_per_split = (*stages_total + best - 1) / best;
   *splits = (*stages_total + *stages_per_split - 1) / *stages_per_split;
+}
+
+template <int SLABS>
+static int launch_i8_tn(const PackedMatrix &G_tn, const int8_t *d_Bs, int *d_P, const I8Plan &p, int strips, int stages, int sps, int splits, hipStream_t s, const int *skip) {
+  static unsigned long long attr_tn = 0;
+  if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8_tn<SLABS>), TnCfg<SLABS>::kLds, &attr_tn)) return 1;
+  for (int nt = 0; nt < p.NT; nt++)
+    hipLaunchKernelGGL(k_gemm_i8_tn<SLABS>, dim3((unsigned)(strips * splits)), dim3(128 * SLABS), TnCfg<SLABS>::kLds, s, G_tn.d, G_tn.nslabs, d_Bs + (size_t)nt * 1024, p.NT, d_P, p.m_pad, p.e_pad,
+                       nt * 32, strips, stages, sps, skip);
+  MXA_HIP(hipGetLastError());
+  return 0;
 }
 
 int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool centered, double *d_sumB,
@@ -903,11 +953,13 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   if (G_tn != nullptr && (p.nchunks != 1 || p.NT > (n <= 4 ? 2 : 5))) return 2;
   const bool tn = G_tn != nullptr;
   int tn_strips = 0, tn_stages = 0, tn_sps = 0, tn_splits = 0;
+  const char *e_slabs = getenv("MXA_I8_TN_SLABS");             // strip width of the transposed kernel: 2 (256 individuals, two workgroups per CU) or 4 (512, one)
+  const int tn_slabs = e_slabs && atoi(e_slabs) == 4 ? 4 : 2;
   if (tn) {
     if (G_tn->k != m || G_tn->rows != k) { set_error(4, "internal: transposed operand has the wrong shape"); return 1; }
-    plan_i8_tn(G_tn->nslabs, G_tn->rows, &tn_strips, &tn_stages, &tn_sps, &tn_splits);
+    plan_i8_tn(G_tn->nslabs, G_tn->rows, tn_slabs, &tn_strips, &tn_stages, &tn_sps, &tn_splits);
     if ((long)tn_stages * kTileRows > G_tn->rows_pad) { set_error(4, "internal: packed matrix smaller than the transposed i8 plan"); return 1; }
-    p.T_total = (long)tn_stages * 8; p.splits = tn_splits; p.m_pad = (long)tn_strips * kTnSlabs * kSlabK; p.e_pad = p.NT * 32;
+    p.T_total = (long)tn_stages * 8; p.splits = tn_splits; p.m_pad = (long)tn_strips * tn_slabs * kSlabK; p.e_pad = p.NT * 32;
   }
   if (splits_out) *splits_out = p.splits;
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
@@ -968,14 +1020,9 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   static const bool direct_on = [] { const char *e = getenv("MXA_I8_DIRECT"); return !e || atoi(e) != 0; }();
   I8Direct dir{};
   if (tn) {
-    static unsigned long long attr_tn = 0;
-    if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8_tn), kTnLds, &attr_tn)) return 1;
-    for (int nt = 0; nt < p.NT; nt++)
-      hipLaunchKernelGGL(k_gemm_i8_tn, dim3((unsigned)(tn_strips * tn_splits)), dim3(512), kTnLds, s, G_tn->d, G_tn->nslabs, d_Bs + (size_t)nt * 1024, p.NT, d_P, p.m_pad, p.e_pad, nt * 32,
-                         tn_strips, tn_stages, tn_sps, skip);
-    MXA_HIP(hipGetLastError());
+    if (tn_slabs == 4 ? launch_i8_tn<4>(*G_tn, d_Bs, d_P, p, tn_strips, tn_stages, tn_sps, tn_splits, s, skip) : launch_i8_tn<2>(*G_tn, d_Bs, d_P, p, tn_strips, tn_stages, tn_sps, tn_splits, s, skip)) return 1;
     if (ev1) MXA_HIP(hipEventRecord(ev1, s));
-    dim3 grid((unsigned)((fill_rows + 255) / 256), (unsigned)n);
+    dim3 grid((unsigned)((fill_rows + 63) / 64), (unsigned)n);
     hipLaunchKernelGGL(k_finish_i8_t, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, d_part, dC, ldc, fill_rows, trans ? 1 : 0,
                        centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip);
     MXA_HIP(hipGetLastError());
@@ -1001,7 +1048,7 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
     hipLaunchKernelGGL(k_finish_i8_small, dim3((unsigned)((fill_rows + kFinSmallBlockRows - 1) / kFinSmallBlockRows)), dim3(256), 0, s, d_P, p.m_pad, p.splits, m, n, p.S, p.nc, d_E, d_part, dC, ldc, fill_rows,
                        trans ? 1 : 0, centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip);
   } else if (p.NT >= 2) {   // operand-swapped instantiations: transposed partial sums
-    dim3 grid((unsigned)((fill_rows + 255) / 256), (unsigned)n);
+    dim3 grid((unsigned)((fill_rows + 63) / 64), (unsigned)n);
     hipLaunchKernelGGL(k_finish_i8_t, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, d_part, dC, ldc, fill_rows, trans ? 1 : 0,
                        centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip);
   } else {

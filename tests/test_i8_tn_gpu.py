@@ -31,9 +31,17 @@ def _product(dg, obj, prob, trans, B, tn):
         os.environ.pop("MXA_I8_TN", None)
 
 
+@pytest.fixture(params=[2, 4])
+def slabs(request):
+    """strip width of k_gemm_i8_tn: 2 slabs (256 individuals, 4 waves, two workgroups per CU: the default) or 4 (512 individuals, 8 waves)"""
+    os.environ["MXA_I8_TN_SLABS"] = str(request.param)
+    yield request.param
+    os.environ.pop("MXA_I8_TN_SLABS", None)
+
+
 @pytest.mark.parametrize("snps,indiv", [(3001, 1037), (2050, 1301), (700, 3001), (5000, 600), (1300, 130)])
 @pytest.mark.parametrize("n", [1, 2])
-def test_transposed_int8_route_matches_plain_and_oracle(mx, snps, indiv, n):
+def test_transposed_int8_route_matches_plain_and_oracle(mx, snps, indiv, n, slabs):
     o = Oracle()
     prob = make_problem(snps, indiv, n, seed=snps + 3 * n, missing_frac=0.03)
     dg = mx.dgemm_compressed
