@@ -868,6 +868,11 @@ def main():
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child(args)
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner when its communicator comes up, i.e. on every
+    # N > 1 run): keep the real stdout aside for the line and send everything else that reaches fd 1 to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     inprocess = world == 1 and args.gpus > 1
@@ -1106,7 +1111,8 @@ def main():
         if bad:
             raise SystemExit(f"bench.py: parity check failed in {bad}: {json.dumps({k: out[k] for k in bad})}")
     if W.rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 
