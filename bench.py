@@ -873,6 +873,7 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver only supports dmabuf IPC (RCCL and peer access between processes need it); set before HIP comes up
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     inprocess = world == 1 and args.gpus > 1
