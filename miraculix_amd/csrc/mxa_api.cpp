@@ -318,7 +318,12 @@ int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink
   MXA_HIP(hipMemGetInfo(&free_b, &total_b));
   const int policy = tl_single_override >= 0 ? tl_single_override : single_orientation_policy();
   const size_t need_two = object_footprint(snps, indiv, max_n, false), need_one = object_footprint(snps, indiv, max_n, true);
-  const bool single0 = policy == 1 || (policy == 2 && need_two > free_b && need_one <= free_b);
+  // what the staging itself holds on top at its peak: a host source goes through a 256 MB bounce buffer; the one-pointer shape keeps the raw transposed
+  // block (about one packed copy) until the second copy is built
+  int src_dev0 = -1;
+  const size_t bounce = ptr_location(plink, &src_dev0) == 1 ? 0 : (size_t)256 << 20;
+  const size_t tmp_two = one_pointer ? (size_t)indiv * (((size_t)snps + 3) / 4) + bounce : bounce, tmp_one = bounce;
+  const bool single0 = policy == 1 || (policy == 2 && need_two + tmp_two > free_b && need_one + tmp_one <= free_b);
   if (single0 && policy == 2 && (env_print_level() > 0 || o.print_level > 0))
     printf("miraculix_amd - dgemm_compressed: two packed copies need %.1f GB, %.1f GB are free: keeping the SNP-major copy only (%.1f GB).\n", need_two / 1e9, free_b / 1e9, need_one / 1e9);
   const size_t need = single0 ? need_one : need_two;
