@@ -411,7 +411,7 @@ int multi_create(const uint8_t *plink, const uint8_t *plink_t, long snps, long i
   if (!plink) { if (out) *out = nullptr; set_error(1, "plink2compressed: plink is NULL"); return 1; }
   const bool one_pointer = !plink_t || plink_t == plink;   // the reference's CPU call shape (benchmark.f90:185): every shard transposes its own SNP block on its device
   const size_t ps = ((size_t)indiv + 3) / 4, pi = ((size_t)snps + 3) / 4;
-  return multi_build(snps, indiv, max_n, false, shards, out, [=](int, long b, long e, int dev, void **h) {
+  return multi_build(snps, indiv, max_n, one_pointer, shards, out, [=](int, long b, long e, int dev, void **h) {   // (one pointer: every shard holds a raw transposed block while it stages)
     // rows [b, e) of the SNP-major matrix; byte columns [b/4, ..) of the individual-major matrix (row pitch of the FULL matrix)
     return create_handle(plink + (size_t)b * ps, ps, one_pointer ? nullptr : plink_t + (size_t)b / 4, pi, e - b, indiv, f ? f + b : nullptr, max_n, h, dev);
   });
