@@ -345,7 +345,7 @@ void multi_destroy(void *obj) {
   delete m;
 }
 
-static int multi_build(long snps, long indiv, int max_n, bool raw_blocks, int shards, void **out, const std::function<int(int g, long b, long e, int dev, void **h)> &make) {
+static int multi_build(long snps, long indiv, int max_n, int staging, int shards, void **out, const std::function<int(int g, long b, long e, int dev, void **h)> &make) {
   if (out) *out = nullptr;
   if (!out) { set_error(1, "plink2compressed: compressed is NULL"); return 1; }
   if (snps <= 0 || indiv <= 0) { set_error(1, "plink2compressed: snps and indiv must be positive"); return 1; }
@@ -360,8 +360,8 @@ static int multi_build(long snps, long indiv, int max_n, bool raw_blocks, int sh
   m->sh.resize(G);
   for (int g = 0; g < G; g++) { m->sh[g].begin = b[g]; m->sh[g].end = e[g]; m->sh[g].worker = worker_pool().borrow(); }
   // One or two packed copies (MXA_SINGLE_ORIENTATION, mxa_internal.h): decided here for the whole object, so that all shards are alike -- under the
-  // automatic policy the SNP-major copy alone when, on any device, the shards it will hold do not fit with two copies (raw_blocks: the staging from a
-  // .bed file also holds each shard's raw block and its transpose while it runs) but do with one.
+  // automatic policy the SNP-major copy alone when, on any device, the shards it will hold do not fit with two copies (counting what their staging holds
+  // while it runs) but do with one.
   int single = single_orientation_policy();
   if (single == 2) {
     single = 0;
@@ -373,7 +373,8 @@ static int multi_build(long snps, long indiv, int max_n, bool raw_blocks, int sh
       size_t two = 0, one = 0, free_b = 0, total_b = 0;
       for (int q = g; q < G; q++) if (dev[q] == dev[g]) {
         const long rows = e[q] - b[q];
-        const size_t raw = raw_blocks ? (size_t)rows * (((size_t)indiv + 3) / 4) : 0, raw_t = raw_blocks ? (size_t)indiv * (((size_t)rows + 3) / 4) : 0;
+        // temporaries of the staging: from a .bed file (staging 1) each shard's raw block, and its transpose for two copies; one-pointer shape (2): the raw transpose
+        const size_t raw = staging == 1 ? (size_t)rows * (((size_t)indiv + 3) / 4) : 0, raw_t = staging ? (size_t)indiv * (((size_t)rows + 3) / 4) : 0;
         two += object_footprint(rows, indiv, max_n, false) + raw + raw_t;
         one += object_footprint(rows, indiv, max_n, true) + raw;
       }
@@ -411,7 +412,7 @@ int multi_create(const uint8_t *plink, const uint8_t *plink_t, long snps, long i
   if (!plink) { if (out) *out = nullptr; set_error(1, "plink2compressed: plink is NULL"); return 1; }
   const bool one_pointer = !plink_t || plink_t == plink;   // the reference's CPU call shape (benchmark.f90:185): every shard transposes its own SNP block on its device
   const size_t ps = ((size_t)indiv + 3) / 4, pi = ((size_t)snps + 3) / 4;
-  return multi_build(snps, indiv, max_n, one_pointer, shards, out, [=](int, long b, long e, int dev, void **h) {   // (one pointer: every shard holds a raw transposed block while it stages)
+  return multi_build(snps, indiv, max_n, one_pointer ? 2 : 0, shards, out, [=](int, long b, long e, int dev, void **h) {
     // rows [b, e) of the SNP-major matrix; byte columns [b/4, ..) of the individual-major matrix (row pitch of the FULL matrix)
     return create_handle(plink + (size_t)b * ps, ps, one_pointer ? nullptr : plink_t + (size_t)b / 4, pi, e - b, indiv, f ? f + b : nullptr, max_n, h, dev);
   });
@@ -419,7 +420,7 @@ int multi_create(const uint8_t *plink, const uint8_t *plink_t, long snps, long i
 
 int multi_create_from_bed(const char *base, long snps, long indiv, int max_n, int shards, void **out, double *f_out) {
   const std::string b0(base);
-  return multi_build(snps, indiv, max_n, true, shards, out, [=](int, long b, long e, int dev, void **h) {
+  return multi_build(snps, indiv, max_n, 1, shards, out, [=](int, long b, long e, int dev, void **h) {
     return bed_range_to_handle(b0.c_str(), snps, indiv, b, e, max_n, dev, h, f_out ? f_out + b : nullptr);
   });
 }
