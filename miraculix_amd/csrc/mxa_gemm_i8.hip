@@ -847,8 +847,13 @@ static I8Plan plan_i8(long m, long k_pad, int n, int S_override) {
     for (long cand = 1; search && cand <= std::min<long>(max_splits, 64); cand++) {
       const long per = (p.stages_total + cand - 1) / cand, actual = (p.stages_total + per - 1) / per;
       if (actual != cand) continue;
-      const long wgs = units * actual, rounds = (wgs + resident - 1) / resident;
+      // Whole rounds of the resident slots.  Exception (round 4): ONE split of a product with at least two full rounds of row tiles -- its thinly
+      // filled last round costs max(its workgroups, 0.6 slots), not a whole round: 500k x 50k, n = 4 .. 6, 'T' (1954 tiles on 768 slots) runs 2-10 % faster
+      // uncut than in the three splits the whole-round rule chose (tools/gpu_r4_i8_splits_n46.sh).  Products with few row tiles ('N') keep the
+      // whole-round rule: there the sweeps want MORE workgroups than the soft rule would ask for (config-5 shard 'N' 2 / 5 splits 1.04 / 0.96 ms).
+      const long wgs = units * actual, rounds = (wgs + resident - 1) / resident, full = wgs / resident, last = wgs - full * resident;
       double quant = (double)(rounds * resident) / (double)wgs;
+      if (actual == 1 && full >= 2) quant = ((double)full * (double)resident + (last ? std::max((double)last, 0.6 * (double)resident) : 0.0)) / (double)wgs;
       if (half && rounds == 1) quant = std::max(1.0, 0.65 * (double)resident / (double)wgs);
       const double t_p = (actual == 1 && direct_possible) ? 0.0 : 2.0 * (double)actual * (double)m_pad * p.e_pad * 4.0 / 5.0e12 + 5.0e-6;
       const double t = t_main * quant * ((double)per + prologue) / (double)per + t_p;
