@@ -682,11 +682,14 @@ __global__ void __launch_bounds__(256) k_finish_i8(const int *__restrict__ P, lo
 // finish for the TRANSPOSED partial sums of the operand-swapped instantiations (NT >= 2): P[split][e][row], e = chunk * NT * 32 + s * nc + jj.
 // One thread per (row, column): every load is a 1 KiB run along the rows, C is written along the rows.  Same arithmetic, in the same order, as
 // k_finish_i8: exact int64 sums over the splits, digits added smallest scale first.
-// Block = 64 rows x 4 digit groups (round 4; was one thread per row walking all S digits and K splits in a chain of dependent loads: 100-170 us behind a
-// 1 ms product).  Thread (row, g) owns the digits s in [g Sg, (g + 1) Sg), Sg = ceil(S / 4) <= 8: all their partial sums over the K splits are loaded
-// before the first use (rows along the lanes: 256-byte runs), added exactly (int64), scaled (exact) and added smallest scale first; the four groups of a
-// row are then added smallest first through LDS -- a fixed order, at most Sg + 3 roundings per result.
+// Block = 256 rows x 4 digit groups (round 4; was one thread per row walking all S digits and K splits in a chain of dependent loads: 100-170 us behind a
+// 1 ms product).  Thread (lane, g) owns the digits s in [g Sg, (g + 1) Sg), Sg = ceil(S / 4) <= 8, of FOUR rows (lane, lane + 64, ...): all their partial
+// sums over the K splits are loaded before the first use (rows along the lanes: 256-byte runs; one row per thread left the launch bound by the life
+// time of its 47 000 short blocks: 81 us for 128 MB), added exactly (int64), scaled (exact) and added smallest scale first; the four groups of a row
+// are then added smallest first through LDS -- a fixed order, at most Sg + 3 roundings per result.
 constexpr int kFinTGroups = 4;
+constexpr int kFinTRows = 4;                  // rows per thread
+constexpr int kFinTBlockRows = 64 * kFinTRows;
 __global__ void __launch_bounds__(256) k_finish_i8_t(const int *__restrict__ P, long m_pad, int e_pad, int splits, long m, int n, int S, int nc, int NT,
                                                      const int *__restrict__ E, const double *__restrict__ colmax_part, double *__restrict__ Cout, long ldc,
                                                      long fill_rows, int mode_trans, int centered, const double *__restrict__ sumB, const double *__restrict__ sumfB,
@@ -694,44 +697,60 @@ __global__ void __launch_bounds__(256) k_finish_i8_t(const int *__restrict__ P, 
   if (skip_if_set && *skip_if_set) return;
   const int j = blockIdx.y, chunk = j / nc, jj = j - chunk * nc;
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const long r = (long)blockIdx.x * 64 + lane;
+  const long rbase = (long)blockIdx.x * kFinTBlockRows + lane;
   __shared__ int bad;
-  __shared__ double part[kFinTGroups][64];
-  if (threadIdx.x == 0) {
-    double cm = 0.0;
-    for (int c = 0; c < 64; c++) cm = fmax(cm, colmax_part[(size_t)j * 64 + c]);
-    bad = !(cm <= 1.7976931348623157e308);      // column holds an inf or a NaN: the result column is NaN, like 0 * inf in fp64
+  __shared__ double part[kFinTGroups][kFinTBlockRows];
+  if (threadIdx.x < 64) {   // wave 0: the column's largest |entry| from the 64 chunk maxima
+    double cm = colmax_part[(size_t)j * 64 + lane];
+    const bool nonfinite = !(cm <= 1.7976931348623157e308);
+    const unsigned long long any = __ballot(nonfinite);
+    if (lane == 0) bad = any != 0ull;            // column holds an inf or a NaN: the result column is NaN, like 0 * inf in fp64
   }
-  double v = 0.0;
-  if (r < m) {
-    const int Sg = (S + kFinTGroups - 1) / kFinTGroups, s0 = g * Sg;
-    const int Ej = E[j];
-    const int *p0 = P + (size_t)(chunk * (NT * 32) + jj) * m_pad + r;
-    long long t[8];
+  const int Sg = (S + kFinTGroups - 1) / kFinTGroups, s0 = g * Sg;
+  const int Ej = E[j];
+  const int *p0 = P + (size_t)(chunk * (NT * 32) + jj) * m_pad;
+  // rows clamped to valid addresses; every load of a digit pair is issued before the first use (few registers: eight waves per SIMD keep ~64 KiB per CU in flight)
+  long rl[kFinTRows];
+  double v[kFinTRows];
 #pragma unroll
-    for (int i = 0; i < 8; i++) t[i] = 0;
+  for (int i = 0; i < kFinTRows; i++) { const long r = rbase + 64 * i; rl[i] = r < m_pad ? r : m_pad - 1; v[i] = 0.0; }
+  const int nd = s0 < S ? (S - s0 < Sg ? S - s0 : Sg) : 0;     // digits of this group
+  for (int d = nd - 1; d >= 0; d -= 2) {                        // smallest scale first, two digits per step (the lower one masked when d == 0)
+    const int d1 = d > 0 ? d - 1 : 0;
+    const int *pa = p0 + (size_t)(s0 + d) * nc * m_pad, *pb = p0 + (size_t)(s0 + d1) * nc * m_pad;
+    long long ta[kFinTRows], tb[kFinTRows];
+#pragma unroll
+    for (int i = 0; i < kFinTRows; i++) { ta[i] = 0; tb[i] = 0; }
     for (int sp = 0; sp < splits; sp++) {
+      const size_t off = (size_t)sp * e_pad * m_pad;
+      int xa[kFinTRows], xb[kFinTRows];
 #pragma unroll
-      for (int i = 0; i < 8; i++)
-        if (i < Sg && s0 + i < S) t[i] += p0[((size_t)sp * e_pad + (size_t)(s0 + i) * nc) * m_pad];
+      for (int i = 0; i < kFinTRows; i++) { xa[i] = pa[off + rl[i]]; xb[i] = pb[off + rl[i]]; }
+#pragma unroll
+      for (int i = 0; i < kFinTRows; i++) { ta[i] += xa[i]; tb[i] += xb[i]; }
     }
 #pragma unroll
-    for (int i = 7; i >= 0; i--)
-      if (i < Sg && s0 + i < S) v += ldexp((double)t[i], Ej - 8 * (s0 + i + 1));
+    for (int i = 0; i < kFinTRows; i++) {
+      v[i] += ldexp((double)ta[i], Ej - 8 * (s0 + d + 1));
+      if (d > 0) v[i] += ldexp((double)tb[i], Ej - 8 * (s0 + d1 + 1));
+    }
   }
-  part[g][lane] = v;
+#pragma unroll
+  for (int i = 0; i < kFinTRows; i++) part[g][64 * i + lane] = v[i];
   __syncthreads();
-  if (g != 0 || r >= fill_rows) return;
-  v = 0.0;
+  // thread (lane, g) finishes row 64 g + lane of the block
+  const long r = (long)blockIdx.x * kFinTBlockRows + threadIdx.x;
+  if (r >= fill_rows) return;
+  double out = 0.0;
   if (r < m) {
-    if (bad) v = __longlong_as_double(0x7ff8000000000000ll);
-    else v = ((part[3][lane] + part[2][lane]) + part[1][lane]) + part[0][lane];
+    if (bad) out = __longlong_as_double(0x7ff8000000000000ll);
+    else out = ((part[3][threadIdx.x] + part[2][threadIdx.x]) + part[1][threadIdx.x]) + part[0][threadIdx.x];
     if (centered) {
-      if (mode_trans) v = fma(-2.0 * sumB[j], f[r], v);
-      else v += -2.0 * sumfB[j];
+      if (mode_trans) out = fma(-2.0 * sumB[j], f[r], out);
+      else out += -2.0 * sumfB[j];
     }
   }
-  Cout[r + (long)j * ldc] = v;
+  Cout[r + (long)j * ldc] = out;
 }
 
 // n <= 2 (one tile of 32 expanded columns, e = s * nc + jj, nc * S <= 32, nc = 1 or 2).  Pure HBM streaming: splits x 128 bytes per row.  Eight
@@ -1027,7 +1046,7 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   if (tn) {
     if (tn_slabs == 4 ? launch_i8_tn<4>(*G_tn, d_Bs, d_P, p, tn_strips, tn_stages, tn_sps, tn_splits, s, skip) : launch_i8_tn<2>(*G_tn, d_Bs, d_P, p, tn_strips, tn_stages, tn_sps, tn_splits, s, skip)) return 1;
     if (ev1) MXA_HIP(hipEventRecord(ev1, s));
-    dim3 grid((unsigned)((fill_rows + 63) / 64), (unsigned)n);
+    dim3 grid((unsigned)((fill_rows + kFinTBlockRows - 1) / kFinTBlockRows), (unsigned)n);
     hipLaunchKernelGGL(k_finish_i8_t, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, d_part, dC, ldc, fill_rows, trans ? 1 : 0,
                        centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip);
     MXA_HIP(hipGetLastError());
@@ -1053,7 +1072,7 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
     hipLaunchKernelGGL(k_finish_i8_small, dim3((unsigned)((fill_rows + kFinSmallBlockRows - 1) / kFinSmallBlockRows)), dim3(256), 0, s, d_P, p.m_pad, p.splits, m, n, p.S, p.nc, d_E, d_part, dC, ldc, fill_rows,
                        trans ? 1 : 0, centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip);
   } else if (p.NT >= 2) {   // operand-swapped instantiations: transposed partial sums
-    dim3 grid((unsigned)((fill_rows + 63) / 64), (unsigned)n);
+    dim3 grid((unsigned)((fill_rows + kFinTBlockRows - 1) / kFinTBlockRows), (unsigned)n);
     hipLaunchKernelGGL(k_finish_i8_t, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, d_part, dC, ldc, fill_rows, trans ? 1 : 0,
                        centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip);
   } else {
