@@ -514,7 +514,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     if (hs[2] || S > kI8ExactMaxDigits || hs[1] < 8 * S - 1023) return 2;
     if (digits_out) *digits_out = S;
     const int rc = gemm_i8_device(G, trans, nc, dBc, ldb, dC + (size_t)c0 * ldc, ldc, fill_rows, centered, d_sumB + c0, d_sumfB + c0, h->d_f, w, s, e0, e1, splits_out, 0,
-                                  nullptr, nullptr, S, G_tn_single);
+                                  nullptr, nullptr, S, G_tn_single, w.d_colpart);
     return rc == 2 ? 2 : rc ? 1 : 0;
   };
   if ((engine == 4 || ((engine == 0 || (engine == 2 && n > 4)) && n <= auto_exact_max_n)) && n >= 3 && k >= 128) {   // engine 2 = engine 0 for n > 4

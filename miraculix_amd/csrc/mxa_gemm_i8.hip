@@ -967,7 +967,7 @@ static int launch_i8_tn(const PackedMatrix &G_tn, const int8_t *d_Bs, int *d_P, 
 
 int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool centered, double *d_sumB,
                    double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out, int guard,
-                   const int **flag_out, double *colsum_scratch, int S_override, const PackedMatrix *G_tn) {
+                   const int **flag_out, double *colsum_scratch, int S_override, const PackedMatrix *G_tn, double *stats_part) {
   const long m = G.rows, k = G.k;
   I8Plan p = plan_i8(m, G.k_pad, n, S_override);
   if (p.m_pad > G.rows_pad) { set_error(4, "internal: packed matrix smaller than the i8 plan"); return 1; }
@@ -998,7 +998,7 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
     w.cap_i8 = need;
   }
   char *base = static_cast<char *>(w.d_i8);
-  double *d_part = reinterpret_cast<double *>(base);
+  double *d_part = (stats_part && !guard) ? stats_part : reinterpret_cast<double *>(base);
   int *d_E = reinterpret_cast<int *>(base + part_bytes);
   int8_t *d_Bs = reinterpret_cast<int8_t *>(base + part_bytes + e_bytes);
   int *d_P = reinterpret_cast<int *>(base + part_bytes + e_bytes + bs_bytes);
@@ -1008,7 +1008,8 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   bool fused = false;
   SliceFused fu{};
   if (!guard) {
-    if (launch_colexp(dB, ldb, k, n, d_part, d_E, 2, s)) return 1;
+    if (stats_part) { if (launch_colexp_from_part(d_part, n, d_E, 2, s)) return 1; }
+    else if (launch_colexp(dB, ldb, k, n, d_part, d_E, 2, s)) return 1;
   } else {
     // Exactness guard of the default small-n route.  With |b| = f 2^e, f in [1/2, 1), an entry is the integer m 2^(e-53);
     // the last digit has weight 2^(E_j - 8S) = 2^(e_max + 2 - 8S).  Every entry is an exact multiple of it iff e_min - 53 >= e_max + 2 - 8S,

@@ -179,6 +179,7 @@ constexpr int kDenMaxSpan = 800;
 // d_flag (nullable, device int): range guard of the exact int8 slicing, see k_colexp_final; then d_part needs 128 * n doubles
 constexpr int kI8ExactMaxDigits = 24;   // engine 4: more digits than this cost more than the fp64 MFMA path
 int launch_colspan(const double *dB, long ldb, long k, int n, double *d_part, int *d_out3, hipStream_t s);   // engine 4: span / e_max / non-finite verdict for the host
+int launch_colexp_from_part(const double *d_part, int n, int *d_E, int bias, hipStream_t s);
 int launch_colexp(const double *dB, long ldb, long k, int n, double *d_part, int *d_E, int bias, hipStream_t s, int *d_flag = nullptr, int max_span = 0,
                   int min_emax = 0, bool reset_flag = true);
 // d_E (nullable): per-column exponents for the denormal-operand mode
@@ -239,7 +240,10 @@ int launch_sparse_times_plink(const uint8_t *dP, size_t pitch, long entries, int
 // the exponents and the guard (k_colstats_partial; finished inside k_slice_B) -- the caller must not have launched launch_colsums for them
 int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool centered, double *d_sumB,
                    double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out, int guard = 0,
-                   const int **flag_out = nullptr, double *colsum_scratch = nullptr, int S_override = 0, const PackedMatrix *G_tn = nullptr);
+                   const int **flag_out = nullptr, double *colsum_scratch = nullptr, int S_override = 0, const PackedMatrix *G_tn = nullptr,
+                   double *stats_part = nullptr);
+// stats_part (guard = 0): the column maxima / minima of B are already there (k_colmax_partial's layout, 128 n doubles; the caller's launch_colspan made them to
+// choose S): only the exponents are derived, no second pass over B
 // G_tn: the OTHER stored orientation (rows = the K index); the main kernel then runs in the transposed-operand form k_gemm_i8_tn, one launch per tile of 32
 // expanded columns.  Returns 2 (nothing enqueued) when that would take more passes than the fp64 MFMA tile costs or the plan has several column chunks.
 

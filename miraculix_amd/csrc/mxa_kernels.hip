@@ -167,6 +167,13 @@ int launch_colexp(const double *dB, long ldb, long k, int n, double *d_part, int
   return 0;
 }
 
+// exponents only, from column maxima that are already there (launch_colspan ran over the same columns)
+int launch_colexp_from_part(const double *d_part, int n, int *d_E, int bias, hipStream_t s) {
+  hipLaunchKernelGGL(k_colexp_final, dim3((n + 63) / 64), dim3(64), 0, s, d_part, n, bias, d_E, (int *)nullptr, 0, 0);
+  MXA_HIP(hipGetLastError());
+  return 0;
+}
+
 // engine 4 (i8-exact): what the host needs to choose the digit count: out[0] = largest exponent span e_max - e_min over the columns (non-zero
 // entries only), out[1] = smallest e_max over the non-zero columns (0 if there is none), out[2] = 1 if any entry is inf / NaN.  One workgroup.
 __global__ void __launch_bounds__(256) k_colspan_final(const double *__restrict__ part, int n, int *__restrict__ out) {
