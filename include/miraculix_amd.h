@@ -328,7 +328,7 @@ long mxa_plan_partial_doubles(long m, long k, int n);
  * full 2M x 100k: 50 GB instead of 100) and half the staging upload; plink_transposed is not read.  Both products then read that one copy: 'T' in
  * the plain form, 'N' in the transposed-operand forms (fp64 MFMA: k_gemm<..., TR>, as fast as with two copies; the exact int8 route of n <= 6 and
  * of the peeled odd columns: k_gemm_i8_tn, one pass over the matrix per tile of 32 expanded columns -- n <= 3: one pass, ~10 % slower than the plain
- * int8 kernel (a CG step 2.09 ms against 1.98 on 250k x 100k); n = 4..6: two passes, 2.2 ms against 1.4 on 500k x 50k, still ahead of the fp64 tile).  Results are those of a two-copy object to
+ * int8 kernel (a CG step 2.08 ms against 1.98 on 250k x 100k); n = 4..6: two passes, 2.2 ms against 1.4 on 500k x 50k, still ahead of the fp64 tile).  Results are those of a two-copy object to
  * rounding (bit-identical on the fp64 MFMA path).  What is given up: the opt-in engines i8 / i8-exact at wide n apply to 'T' only; 'T' with
  * n >= 7 runs the plain fp64 MFMA form (0.925 instead of 0.957 of the peak).  mxa_single_orientation: 1 / 0 (multi-device object: of its shards), -1 for an invalid handle. */
 int mxa_single_orientation(void *compressed);
