@@ -238,7 +238,7 @@ struct I8Direct {
   const double *sumB, *sumfB, *f;
 };
 
-template <int NT, int MT, int WC, bool DIAG>
+template <int NT, int MT, int WC, bool DIAG, bool SWAP1 = false>
 __global__ void __launch_bounds__(256, 1)
 k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict__ Bs, long T_total, int *__restrict__ P, long m_pad, int e_pad,
           int rowblocks, int nchunks, int stages_total, int stages_per_split, unsigned long long *__restrict__ diag, const int *__restrict__ skip_if_set,
@@ -253,7 +253,9 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
   // (tools/mfma_i8_probe3.hip), and from two tiles on this kernel is power-bound.  The fragments are symmetric (a lane holds 16 consecutive k of one
   // row / column), so swapping them just transposes the accumulator tile: lane & 31 = genotype row, registers = expanded column; the partial sums
   // then go to P TRANSPOSED, P[split][e][row] (rows along the lanes: 128-byte runs), and k_finish_i8_t reads them that way.
-  constexpr bool kSwap = NT >= 2;
+  // (SWAP1: the one-tile launch of a product with three or more columns -- no in-kernel finish, no k_finish_i8_small -- stores transposed like the wider ones,
+  // so that k_finish_i8_t finishes it: 36 us where k_finish_i8's row-major pass took 77 behind a 500k-row product)
+  constexpr bool kSwap = NT >= 2 || SWAP1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -899,18 +901,18 @@ static I8Plan plan_i8(long m, long k_pad, int n, int S_override) {
   return p;
 }
 
-template <int NT, int MT, int WC>
+template <int NT, int MT, int WC, bool SWAP1 = false>
 static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const I8Plan &p, hipStream_t s, const int *skip_if_set, const I8Direct &dir) {
   using Cfg = I8Cfg<NT, MT * (4 / WC) * 32>;
   static unsigned long long attr_a = 0, attr_b = 0;   // function attributes are per device
-  if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8<NT, MT, WC, false>), Cfg::kLds, &attr_a) ||
-      ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8<NT, MT, WC, true>), Cfg::kLds, &attr_b)) return 1;
+  if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8<NT, MT, WC, false, SWAP1>), Cfg::kLds, &attr_a) ||
+      ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8<NT, MT, WC, true, SWAP1>), Cfg::kLds, &attr_b)) return 1;
   const long grid = (long)p.rowblocks * p.nchunks * p.splits;
   static const bool diag_on = getenv("MXA_DIAG") != nullptr;
   if (diag_on) {   // in-kernel clocks: shader cycles and 100 MHz ticks per workgroup K loop
     unsigned long long *d_diag = nullptr;
     MXA_HIP(hipMalloc((void **)&d_diag, sizeof(unsigned long long) * 2 * grid));
-    hipLaunchKernelGGL((k_gemm_i8<NT, MT, WC, true>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBs, p.T_total, dP, p.m_pad, p.e_pad,
+    hipLaunchKernelGGL((k_gemm_i8<NT, MT, WC, true, SWAP1>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBs, p.T_total, dP, p.m_pad, p.e_pad,
                        p.rowblocks, p.nchunks, p.stages_total, p.stages_per_split, d_diag, skip_if_set, dir);
     std::vector<unsigned long long> h(2 * grid);
     MXA_HIP(hipStreamSynchronize(s));
@@ -923,7 +925,7 @@ static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const 
                              NT, MT, WC, grid, ghz[ghz.size() / 2], ghz.front(), ghz.back(), cyc[cyc.size() / 2], 4 * 2 * NT * 32);
     return 0;
   }
-  hipLaunchKernelGGL((k_gemm_i8<NT, MT, WC, false>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBs, p.T_total, dP, p.m_pad, p.e_pad,
+  hipLaunchKernelGGL((k_gemm_i8<NT, MT, WC, false, SWAP1>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBs, p.T_total, dP, p.m_pad, p.e_pad,
                      p.rowblocks, p.nchunks, p.stages_total, p.stages_per_split, (unsigned long long *)nullptr, skip_if_set, dir);
   MXA_HIP(hipGetLastError());
   return 0;
@@ -1055,8 +1057,11 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   }
   if (direct_on && small_tile && p.splits == 1)
     dir = I8Direct{1, d_E, d_part, dC, ldc, m, fill_rows, n, p.S, p.nc, trans ? 1 : 0, centered ? 1 : 0, d_sumB, d_sumfB, d_f};
+  // one tile, three or more columns (n = 3; n = 4 with few digits), one chunk: transposed partial sums like the wider launches (k_finish_i8_t)
+  const bool swap1 = p.NT == 1 && !small_tile && p.nchunks == 1 && p.rows_wg == kTileRows;
   switch (p.NT) {
-    case 1: rc = p.rows_wg == kTileRows ? launch_i8_t<1, 2, 1>(G, d_Bs, d_P, p, s, skip, dir) : launch_i8_t<1, 1, 1>(G, d_Bs, d_P, p, s, skip, dir); break;
+    case 1: rc = swap1 ? launch_i8_t<1, 2, 1, true>(G, d_Bs, d_P, p, s, skip, dir)
+                      : p.rows_wg == kTileRows ? launch_i8_t<1, 2, 1>(G, d_Bs, d_P, p, s, skip, dir) : launch_i8_t<1, 1, 1>(G, d_Bs, d_P, p, s, skip, dir); break;
     case 2: rc = launch_i8_t<2, 2, 1>(G, d_Bs, d_P, p, s, skip, dir); break;
     case 3: rc = launch_i8_t<3, 2, 1>(G, d_Bs, d_P, p, s, skip, dir); break;
     case 4: rc = launch_i8_t<4, 2, 1>(G, d_Bs, d_P, p, s, skip, dir); break;
@@ -1072,7 +1077,7 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   } else if (small_tile) {   // n <= 2: one tile, the fast finish
     hipLaunchKernelGGL(k_finish_i8_small, dim3((unsigned)((fill_rows + kFinSmallBlockRows - 1) / kFinSmallBlockRows)), dim3(256), 0, s, d_P, p.m_pad, p.splits, m, n, p.S, p.nc, d_E, d_part, dC, ldc, fill_rows,
                        trans ? 1 : 0, centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip);
-  } else if (p.NT >= 2) {   // operand-swapped instantiations: transposed partial sums
+  } else if (p.NT >= 2 || swap1) {   // operand-swapped instantiations: transposed partial sums
     dim3 grid((unsigned)((fill_rows + kFinTBlockRows - 1) / kFinTBlockRows), (unsigned)n);
     hipLaunchKernelGGL(k_finish_i8_t, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, d_part, dC, ldc, fill_rows, trans ? 1 : 0,
                        centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip);
