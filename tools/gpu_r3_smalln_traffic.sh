@@ -1,6 +1,6 @@
 #!/bin/bash
 # fabric-side read traffic of k_gemm_i8 on the config-5 shard (n = 1, 2, 4): algorithmic 6.25 GB of packed matrix + the digit slabs
-R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/r03"; mkdir -p "$O"
+R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/r04s"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 for n in 1 4; do
   rm -rf "$O/snt"
