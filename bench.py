@@ -635,6 +635,114 @@ def config4_full_extent_leg(torch, mx, L, dev, snps=5_000_000, indiv=25_000, n=1
     return res
 
 
+def config4_full_one_copy_leg(torch, mx, L, dev, snps=5_000_000, indiv=200_000, n=128, block_snps=50_000, seed=50, log=None):
+    """BASELINE config 4 as ONE product at its stated size on ONE MI355X: 5 000 000 SNPs x 200 000 individuals, ncol = 128, allele-frequency centred.
+    250 GB packed: the object holds ONE packed copy (SNP-major; 'T' in the plain form, 'N' in the transposed-operand form of k_gemm) and is staged
+    INCREMENTALLY (mxa_plink2compressed_begin / _rows / _end) from SNP blocks generated on the device, so nothing but the object and one block is ever
+    resident -- where the reference's pre-flight gives up (src/cuda/dgemm_compressed_cuda.cu:93-100; it needs both copies AND the host matrices).
+    The split-K partial sums of these products (18 x 5.1 GB for 'T', 407 x 0.2 GB for 'N') do not fit beside the matrix: the K splits run in groups
+    with the running sum kept in C (bit-identical to one pass: tests/test_grouped_and_incremental_gpu.py).
+    Checks: sampled rows of both products against the centred long-double oracle on the extracted packed rows (<= 1e-11), the centred adjoint identity,
+    bitwise repeatability of 'N'.  If the byte budget does not fit this device the budget is reported and the largest SNP count that fits is run."""
+    import numpy as np
+    dg = mx.dgemm_compressed
+    say = log or (lambda *a: None)
+    dg.set_options(use_gpu=True, not_center=False, verbose=0)
+    torch.cuda.empty_cache()
+    free0, total = torch.cuda.mem_get_info()
+    rb = (indiv + 3) // 4
+
+    def budget(s):
+        packed = (s + 512) * ((indiv + 128) // 4)
+        big = 8 * s * n                                   # one snps x n fp64 array
+        return {"packed_one_copy_GB": packed / 1e9, "B_of_N_and_C_of_T_GB": 2 * big / 1e9, "B_in_fragment_order_GB": big / 1e9,
+                "partial_sums_one_group_GB": max(big, min(16 * 2 ** 30, 18 * big)) / 1e9,   # the library's soft cap: 16 GiB, at least one K split
+                "small_operands_and_frequencies_GB": (4 * 8 * indiv * n + 8 * s) / 1e9,
+                "generator_block_and_margin_GB": (block_snps * rb * 2 + (4 << 30)) / 1e9}
+    want = snps
+    while sum(budget(snps).values()) * 1e9 > free0 and snps > 500_000:
+        snps -= 250_000
+    bud = budget(snps)
+    res = {"workload": f"{snps} SNPs x {indiv} indiv, ncol={n}, centred: BASELINE config 4 as ONE product on one device, one packed copy staged incrementally",
+           "device_memory_GB": {"total": round(total / 1e9, 1), "free_at_start": round(free0 / 1e9, 1)},
+           "byte_budget_GB": {k: round(v, 2) for k, v in bud.items()} | {"sum": round(sum(bud.values()), 1)},
+           "snps_requested": want, "snps_run": snps}
+    rng = np.random.default_rng(seed)
+    nsample = 16
+    ii = np.sort(rng.choice(indiv, nsample, replace=False))
+    ss = np.sort(rng.choice(snps, nsample, replace=False))
+    rows_s = np.zeros((nsample, rb), dtype=np.uint8)
+    rows_t = np.zeros((nsample, (snps + 3) // 4), dtype=np.uint8)
+    ii_dev = torch.from_numpy(ii).to(dev)
+    w4 = torch.tensor([1, 4, 16, 64], dtype=torch.uint8, device=dev)
+    t0 = time.perf_counter()
+    obj = dg.init_compressed_begin(snps, indiv, n)
+    try:
+        t_gen = t_app = 0.0
+        for bi, b0 in enumerate(range(0, snps, block_snps)):
+            nb = min(block_snps, snps - b0)
+            ta = time.perf_counter()
+            blk = synth_genotypes_device(torch, nb, indiv, seed + 1 + bi, dev)
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            dg.append_rows(obj, blk, b0)                                             # recoded into the tiled layout, frequencies counted on the device
+            t_app += time.perf_counter() - tb
+            t_gen += tb - ta
+            for q in np.nonzero((ss >= b0) & (ss < b0 + nb))[0]:
+                rows_s[q] = blk[int(ss[q] - b0)].cpu().numpy()
+            codes = (blk[:, ii_dev // 4] >> (2 * (ii_dev % 4)).to(torch.uint8)) & 3   # nb x nsample PLINK codes of the sampled individuals
+            if nb % 4:
+                codes = torch.nn.functional.pad(codes, (0, 0, 0, 4 - nb % 4))
+            packed = (codes.view(-1, 4, nsample) * w4[None, :, None]).sum(dim=1, dtype=torch.uint8)    # 4 SNPs per byte
+            rows_t[:, b0 // 4: b0 // 4 + packed.shape[0]] = packed.t().cpu().numpy()
+            del blk, codes, packed
+            if bi % 10 == 9:
+                say(f"config4_full_one_copy: staged {b0 + nb} of {snps} SNPs ({time.perf_counter() - t0:.0f} s)")
+        f = dg.init_compressed_end(obj, snps)
+        torch.cuda.empty_cache()
+        held = (free0 - torch.cuda.mem_get_info()[0]) / 1e9
+        res["staging"] = {"seconds_total": round(time.perf_counter() - t0, 1), "seconds_generating_blocks_torch": round(t_gen, 1), "seconds_mxa_plink2compressed_rows": round(t_app, 1),
+                          "device_memory_held_by_the_object_GB": round(held, 1), "single_orientation": int(L.mxa_single_orientation(obj))}
+        say(f"config4_full_one_copy: object holds {held:.1f} GB")
+        sample = dict(snps=snps, indiv=indiv, dev=dev, f=f, ii=ii, ss=ss, rows_t=rows_t, rows_s=rows_s)
+        g = torch.Generator(device=dev); g.manual_seed(3)
+        Y = torch.randn((n, snps), dtype=torch.float64, device=dev, generator=g).t()
+        X = torch.randn((n, indiv), dtype=torch.float64, device=dev, generator=g).t()
+        CN = torch.zeros((n, indiv), dtype=torch.float64, device=dev).t()
+        CT = torch.zeros((n, snps), dtype=torch.float64, device=dev).t()
+        sync = torch.cuda.synchronize
+        flops = 2.0 * snps * indiv * n
+        sp = ctypes.c_int(0)
+        for tname, trans, B, C in (("N", False, Y, CN), ("T", True, X, CT)):
+            dg.dgemm_compressed_main(trans, obj, B, snps, indiv, out=C)             # first call: workspace growth, clock ramp
+            if tname == "N":
+                CN1 = CN.clone()
+            L.mxa_profile_reset()
+            t = timed(lambda: dg.dgemm_compressed_main(trans, obj, B, snps, indiv, out=C), sync, 1)
+            la, ms = kernel_profile(L)
+            L.mxa_last_geometry(None, None, None, ctypes.byref(sp), None, None)
+            res[tname] = {"ms_per_call": round(t * 1e3, 1), "TFLOPs_call": round(flops / t * 1e-12, 2), "frac_of_fp64_mfma_peak_call": round(flops / t * 1e-12 / FP64_MFMA_PEAK_TFLOPS, 4),
+                          "k_gemm_and_group_finishes_ms": round(ms / max(1, la), 1), "k_splits": sp.value, "partial_sum_workspace_GB": round(L.mxa_partial_capacity(obj) * 8 / 1e9, 2)}
+            say(f"config4_full_one_copy: {tname} {t * 1e3:.0f} ms = {flops / t * 1e-12:.1f} TFLOP/s")
+        rep = bool(torch.equal(CN1, CN))
+        del CN1
+        cols = [0, 31, 32, 127] if n >= 128 else [0, n - 1]
+        err_n = check_sample(torch, sample, 0, Y, CN, cols, 1)
+        err_t = check_sample(torch, sample, 1, X, CT, cols, 1)
+        lhs = (X * CN).sum(dim=0)
+        den = (X.abs() * CN.abs()).sum(dim=0)
+        rhs = torch.stack([(CT[:, j] * Y[:, j]).sum() for j in range(n)])             # column by column: a 5 GB temporary would not fit
+        adj = float(((lhs - rhs).abs() / den).max())
+        res["held_while_multiplying_GB"] = round((free0 - torch.cuda.mem_get_info()[0]) / 1e9, 1)
+        res["check"] = {"N_16_sampled_rows_vs_dense_oracle_max_rel_err": err_n, "T_16_sampled_rows_vs_dense_oracle_max_rel_err": err_t,
+                        "centred_adjoint_identity_max_rel_err": adj, "N_bitwise_repeatable": rep, "checker_tolerance": 1e-11}
+        del Y, X, CN, CT
+    finally:
+        dg.free_compressed(obj)
+        torch.cuda.empty_cache()
+    return res
+
+
 # ====================================================================================================== the headline workload
 class Workload:
     """config 2 staged for this process: the SNP block of this rank (one process per GPU) or the whole matrix behind a multi-device
@@ -1099,7 +1207,9 @@ def main():
                 ("config4_shard", lambda: config4_shard_leg(torch, mx, L, W.device, r(625_000, 4), r(200_000, 4))),
                 ("config3_crossprod", lambda: config3_crossprod_leg(torch, mx, L, W.device, r(500_000, 4), r(100_000, 256))),
                 ("config5_full_8_virtual_shards", lambda: config5_full_leg(torch, mx, L, W.device, r(2_000_000, 32), r(100_000, 4))),
-                ("config4_full_extent_8_virtual_shards", lambda: config4_full_extent_leg(torch, mx, L, W.device, r(5_000_000, 32), r(25_000, 4))))
+                ("config4_full_extent_8_virtual_shards", lambda: config4_full_extent_leg(torch, mx, L, W.device, r(5_000_000, 32), r(25_000, 4))),
+                ("config4_full_one_copy", lambda: config4_full_one_copy_leg(torch, mx, L, W.device, r(5_000_000, 32), r(200_000, 4), 128, r(50_000, 4),
+                                                                            log=lambda m: print(m, file=sys.stderr, flush=True))))
         for name, fn in legs:
             t_leg = time.perf_counter()
             try:

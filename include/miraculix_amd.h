@@ -183,6 +183,22 @@ int mxa_bed2compressed(const char *bed_path, int snps, int indiv, int max_n, voi
 int mxa_bed2compressed_range(const char *bed_path, int snps, int indiv, int snp_begin, int snp_end, int max_n, void **compressed,
                              double *f_out);
 
+/* Incremental staging (round 5): plink2compressed (5codesAPI.c:80-96 -> plink2gpu, dgemm_compressed_cuda.cu:43-170) wants the whole PLINK matrix
+ * behind one pointer and the reference gives up when matrix + object exceed the device (dgemm_compressed_cuda.cu:93-100).  Here the object is
+ * allocated first -- ONE packed copy (a single-orientation object, see mxa_single_orientation below) -- and filled by blocks of SNP rows, so that
+ * BASELINE config 4 at its full 5M x 200k (250 GB packed) is staged on one 288 GB device from a generator / reader that holds one block at a time.
+ *   mxa_plink2compressed_begin: allocate (packed matrix zeroed; options as plink2compressed).  *compressed NULL on failure.
+ *   mxa_plink2compressed_rows : SNP rows [snp_begin, snp_begin + nrows) = nrows compact PLINK rows of ceil(indiv/4) bytes, host or device memory;
+ *                               blocks may arrive in any order and must cover every row once.  f_rows: the nrows allele frequencies of the block,
+ *                               or NULL -- then they are counted on the device with mxa_allele_freq's rule.  Returns when the block buffer may be reused.
+ *   mxa_plink2compressed_end  : seal; get_compressed_freq returns the frequencies.  Products are refused (error 19) before this call.
+ * mxa_bed2compressed(_range) use the same path for single-orientation objects: the .bed is streamed into the object in 64 MB chunks.
+ * Products whose split-K partial sums would not fit beside such an object run their K splits in groups with the running sum kept in C
+ * (same pieces, same order of additions: bit-identical to the one-pass product).  Return 0 / 1. */
+int mxa_plink2compressed_begin(long snps, long indiv, int max_n, void **compressed);
+int mxa_plink2compressed_rows(void *compressed, const unsigned char *plink_rows, long snp_begin, long nrows, const double *f_rows);
+int mxa_plink2compressed_end(void *compressed);
+
 /* ---- several GPUs behind the reference ABI (single process).  With MIRACULIX_NUM_GPUS=G (> 1) in the environment,
  * plink2compressed and mxa_bed2compressed return ONE handle that owns G per-device objects over contiguous SNP blocks
  * (boundaries at multiples of 4; devices HIP_DEVICE/CUDA_DEVICE (default 0) + 0..G-1 modulo the visible device count -- more

@@ -255,6 +255,25 @@ static int ensure_partials(Workspace &w, const GemmPlan &p, hipStream_t s) {
   return grow(&w.d_P, &w.cap_P, need);
 }
 
+// How many doubles of split-K partial sums a product may hold (round 5).  A plan cuts K into pieces whose B slabs stay in an XCD's L2 (plan_gemm), and
+// every piece leaves a partial result of the whole output: at BASELINE config 4's full extent (5M SNPs x 200k individuals, n = 128) that is 18 x 5.1 GB
+// for 'T' and 407 x 0.2 GB for 'N' beside 250 GB of packed genotypes.  Products whose partials exceed this budget run their K splits in GROUPS
+// (gemm_device, "GROUPED K splits"): same pieces, same order of additions, the running sum kept in C.  Budget: everything up to 4 GiB; beyond that at
+// most 16 GiB (a group costs one more read + write of C: 18 groups of config 4's 'T' 1.3 % of the call, 6 groups 0.4 %) and at most what the device has
+// free right now (the old buffer counted as free: it is released before the new one is allocated) less 2 GiB; never less than ONE split's partials.
+// MXA_P_BUDGET_MB overrides (tests force the grouped path on small products).
+static size_t partial_budget(const Workspace &w, size_t need, size_t one_split) {
+  const char *e_mb = getenv("MXA_P_BUDGET_MB");   // read per call: the tests switch it
+  const long env_mb = e_mb ? atol(e_mb) : -1L;
+  if (env_mb >= 0) return std::max(one_split, std::min(need, (size_t)env_mb * (1u << 20) / sizeof(double)));
+  if (need * sizeof(double) <= ((size_t)4 << 30) || need <= w.cap_P) return need;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return need; }
+  const size_t avail = free_b + w.cap_P * sizeof(double), margin = (size_t)2 << 30, soft = (size_t)16 << 30;
+  const size_t cap = std::min(soft, avail > margin ? avail - margin : 0) / sizeof(double);
+  return std::max(one_split, std::min(need, std::max(cap, (size_t)w.cap_P)));
+}
+
 static int ensure_workspace(Handle *h, int n) {
   // sized for the larger of the two products, like the reference's size_buffer (dgemm_compressed_cuda.cu:77)
   Workspace &w = h->ws;
@@ -262,9 +281,11 @@ static int ensure_workspace(Handle *h, int n) {
   GemmPlan pn = plan_gemm(h->indiv, h->ind_major.k_pad, n), pt = plan_gemm(h->snps, h->snp_major.k_pad, n);
   const size_t bp = (size_t)kmax_pad * std::max(pn.n_pad, pt.n_pad);
   GemmPlan ln = plan_lut(h->indiv, h->ind_major.k_pad, std::min(n, 4)), lt = plan_lut(h->snps, h->snp_major.k_pad, std::min(n, 4));
-  const size_t pp = std::max(std::max((size_t)pn.splits * pn.n_pad * pn.m_pad, (size_t)pt.splits * pt.n_pad * pt.m_pad),
-                             std::max((size_t)ln.splits * ln.n_pad * ln.m_pad, (size_t)lt.splits * lt.n_pad * lt.m_pad));
+  size_t pp = std::max(std::max((size_t)pn.splits * pn.n_pad * pn.m_pad, (size_t)pt.splits * pt.n_pad * pt.m_pad),
+                       std::max((size_t)ln.splits * ln.n_pad * ln.m_pad, (size_t)lt.splits * lt.n_pad * lt.m_pad));
   if (grow(&w.d_Bp, &w.cap_Bp, bp)) return 1;
+  // very large products keep only a GROUP of their K splits' partial sums at a time (partial_budget, gemm_grouped)
+  pp = partial_budget(w, pp, std::max(std::max((size_t)pn.n_pad * pn.m_pad, (size_t)pt.n_pad * pt.m_pad), std::max((size_t)ln.splits * ln.n_pad * ln.m_pad, (size_t)lt.splits * lt.n_pad * lt.m_pad)));
   if (grow(&w.d_P, &w.cap_P, pp)) return 1;
   if (grow(&w.d_colpart, &w.cap_colpart, (size_t)n * (64 * 2 + 2) + 16)) return 1;
   if (!w.d_denflag) {   // flags + the work-queue counters of k_gemm, one small block for the life of the handle
@@ -359,6 +380,101 @@ int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink
   }
   if (ensure_workspace(h, h->max_n)) { destroy_handle(h); return 1; }
   *out = h;
+  return 0;
+}
+
+// ---- incremental staging (round 5).  plink2compressed wants the whole PLINK matrix behind one pointer; at BASELINE config 4's full extent that is 250 GB
+// next to the 250 GB object it becomes.  Here the object is allocated first (ONE packed copy, SNP-major: Handle::single) and filled by blocks of SNP rows
+// -- from a generator, a file reader, another device -- so that nothing but the object and one block is ever resident.  The .bed reader uses it for
+// single-orientation objects (bed_range_to_handle).
+int begin_handle(long snps, long indiv, int max_n, void **out, int device) {
+  if (out) *out = nullptr;
+  if (!out) { set_error(1, "mxa_plink2compressed_begin: compressed is NULL"); return 1; }
+  if (snps <= 0 || indiv <= 0) { set_error(1, "mxa_plink2compressed_begin: snps and indiv must be positive"); return 1; }
+  Options &o = options();
+  if (!o.set) { o.gpu = true; o.centered = true; o.set = true; }
+  if (!o.gpu) { set_error(14, "mxa_plink2compressed_begin: setOptions_compressed was called with use_gpu=0; this library has no CPU engine"); return 1; }
+  int dev = device;
+  if (dev < 0) dev = select_device();
+  else if (!check_hip(hipSetDevice(dev), __func__, __LINE__)) dev = -1;
+  if (dev < 0) return 1;
+  size_t free_b = 0, total_b = 0;
+  MXA_HIP(hipMemGetInfo(&free_b, &total_b));
+  // the packed copy + B in fragment order + at least one K split of partial sums (partial_budget cuts the rest into groups) + the staged operands' room
+  const size_t need = object_footprint(snps, indiv, max_n, true);
+  if (need > free_b) {
+    set_error(12, "Not enough device memory available. Required %zu GB, free %zu GB, total on device %zu GB", need >> 30, free_b >> 30, total_b >> 30);
+    return 1;
+  }
+  Handle *h = new Handle();
+  h->device = dev; h->snps = snps; h->indiv = indiv; h->max_n = std::max(max_n, 1);
+  h->single = true; h->staging = true;
+  if (!check_hip(hipStreamCreateWithFlags(&h->stream, hipStreamDefault), __func__, __LINE__)) { destroy_handle(h); return 1; }
+  PackedMatrix &M = h->snp_major;
+  describe_matrix(M, snps, indiv);
+  const size_t bytes = (size_t)M.rows_pad * M.pitch;
+  if (!check_hip(hipMalloc(reinterpret_cast<void **>(&M.d), bytes), __func__, __LINE__) ||
+      !check_hip(hipMemsetAsync(M.d, 0, bytes, h->stream), __func__, __LINE__)) { destroy_handle(h); return 1; }
+  describe_matrix(h->ind_major, indiv, snps);
+  if (!check_hip(hipMalloc(reinterpret_cast<void **>(&h->d_f), sizeof(double) * snps), __func__, __LINE__) ||
+      !check_hip(hipMemsetAsync(h->d_f, 0, sizeof(double) * snps, h->stream), __func__, __LINE__)) { destroy_handle(h); return 1; }
+  h->h_f = (double *)calloc((size_t)snps, sizeof(double));
+  h->has_f = true;
+  if (ensure_workspace(h, h->max_n)) { destroy_handle(h); return 1; }
+  *out = h;
+  return 0;
+}
+
+int append_rows(Handle *h, const uint8_t *rows, long snp_begin, long nrows, const double *f_rows) {
+  if (!h->staging) { set_error(19, "mxa_plink2compressed_rows: the object is sealed (or was not made by mxa_plink2compressed_begin)"); return 1; }
+  if (!rows || snp_begin < 0 || nrows <= 0 || snp_begin + nrows > h->snps) {
+    set_error(1, "mxa_plink2compressed_rows: need rows != NULL and 0 <= snp_begin, snp_begin + nrows <= snps (got [%ld, %ld) of %ld)", snp_begin, snp_begin + nrows, h->snps);
+    return 1;
+  }
+  MXA_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const long bps = (h->indiv + 3) / 4;
+  int src_dev = -1;
+  const bool on_dev = ptr_location(rows, &src_dev) == 1;
+  if (f_rows) MXA_HIP(hipMemcpyAsync(h->d_f + snp_begin, f_rows, sizeof(double) * nrows, hipMemcpyDefault, s));
+  if (on_dev) {
+    if (src_dev != h->device) {
+      if (!enable_peer(h->device, src_dev)) { set_error(15, "mxa_plink2compressed_rows: device %d cannot read the rows in the memory of device %d", h->device, src_dev); return 1; }
+      if (sync_foreign_producer(src_dev)) return 1;
+    }
+    if (launch_recode(rows, (size_t)bps, snp_begin, nrows, h->indiv, 0, h->snp_major, s)) return 1;
+    if (!f_rows && launch_allele_freq(rows, nrows, h->indiv, h->d_f + snp_begin, s)) return 1;
+    MXA_HIP(hipStreamSynchronize(s));   // the caller may reuse its block buffer
+  } else {
+    const size_t chunk_bytes = (size_t)256 << 20;
+    const long chunk_rows = std::min<long>(nrows, std::max<long>(1, (long)(chunk_bytes / (size_t)bps)));
+    uint8_t *bounce = nullptr;
+    MXA_HIP(hipMalloc(reinterpret_cast<void **>(&bounce), (size_t)chunk_rows * bps));
+    int rc = 0;
+    for (long r0 = 0; r0 < nrows && !rc; r0 += chunk_rows) {
+      const long nr = std::min(chunk_rows, nrows - r0);
+      if (!check_hip(hipMemcpyAsync(bounce, rows + (size_t)r0 * bps, (size_t)nr * bps, hipMemcpyHostToDevice, s), __func__, __LINE__)) { rc = 1; break; }
+      rc = launch_recode(bounce, (size_t)bps, snp_begin + r0, nr, h->indiv, 0, h->snp_major, s);
+      if (!rc && !f_rows) rc = launch_allele_freq(bounce, nr, h->indiv, h->d_f + snp_begin + r0, s);
+      if (!rc && !check_hip(hipStreamSynchronize(s), __func__, __LINE__)) rc = 1;
+    }
+    (void)hipFree(bounce);
+    if (rc) return 1;
+  }
+  h->staged_rows += nrows;
+  return 0;
+}
+
+int end_handle(Handle *h) {
+  if (!h->staging) { set_error(19, "mxa_plink2compressed_end: the object is already sealed"); return 1; }
+  if (h->staged_rows != h->snps) {
+    set_error(1, "mxa_plink2compressed_end: %ld SNP rows were appended, the object has %ld", h->staged_rows, h->snps);
+    return 1;
+  }
+  MXA_HIP(hipSetDevice(h->device));
+  MXA_HIP(hipStreamSynchronize(h->stream));
+  MXA_HIP(hipMemcpy(h->h_f, h->d_f, sizeof(double) * h->snps, hipMemcpyDeviceToHost));
+  h->staging = false;
   return 0;
 }
 
@@ -584,7 +700,18 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   static const int lut_max_n = [] { const char *e = getenv("MXA_LUT_MAX_N"); return e ? atoi(e) : 2; }();
   const bool use_lut = n <= lut_max_n && n <= 4 && !no_plain;
   GemmPlan p = use_lut ? plan_lut(m, G.k_pad, n) : plan_gemm(m, G.k_pad, n);
-  if (ensure_partials(w, p, s)) return 1;   // the plan of the columns left after a peel may need more than the plan ensure_workspace sized for
+  // K splits per launch group: all of them unless their partial sums exceed the budget (partial_budget)
+  int splits_per_group = p.splits;
+  if (!use_lut) {
+    const size_t one = (size_t)p.n_pad * p.m_pad, need = one * p.splits;
+    const size_t budget = partial_budget(w, need, one);
+    if (budget < need) {
+      splits_per_group = (int)std::max<size_t>(1, budget / one);
+      GemmPlan pg = p; pg.splits = splits_per_group;
+      if (ensure_partials(w, pg, s)) return 1;
+    }
+  }
+  if (splits_per_group == p.splits && ensure_partials(w, p, s)) return 1;   // the plan of the columns left after a peel may need more than the plan ensure_workspace sized for
   {
     std::lock_guard<std::mutex> lk(g_prof_mutex);
     Geometry &geo = last_geometry();
@@ -610,6 +737,27 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   }
   if (!use_lut && launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, d_E, 0, -1, nullptr, mode == 3 && !tr)) return 1;
   if (prof) MXA_HIP(hipEventRecord(pe0, s));
+  if (splits_per_group < p.splits) {
+    // GROUPED K splits (round 5; BASELINE config 4 at its full 5M x 200k x 128 on one device): the launch plan is unchanged -- same pieces, same K
+    // order -- but only `splits_per_group` splits are in flight at a time; each group's partial sums are added to the running sum kept in C (raw: no
+    // scale-back, no centring) and the last group applies the epilogue.  One sequential ascending chain of additions, as in the one-pass k_finish:
+    // bit-identical to it (tests/test_grouped_splits_gpu.py).  Pass 1 = the plain-operand fallback of the denormal-operand mode, gated by the
+    // range flag like the one-pass path: it redoes every group and overwrites C.
+    const size_t stride = (size_t)p.n_pad * p.m_pad;
+    for (int pass = 0; pass < (d_E ? 2 : 1); pass++) {
+      const int *gate = pass ? w.d_denflag : nullptr;
+      if (pass && launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, nullptr, 0, -1, gate)) return 1;
+      for (int sb = 0; sb < p.splits; sb += splits_per_group) {
+        const int se = std::min(p.splits, sb + splits_per_group);
+        // the kernel addresses P by the absolute split index: shift the base so that split sb lands at the start of the buffer
+        if (launch_gemm(GL, w.d_Bp, w.d_P - (size_t)sb * stride, p, pass ? 0 : mode, s, next_ctr(w), sb, se, gate, tr)) return 1;
+        const int group = (sb > 0 ? 1 : 0) | (se < p.splits ? 2 : 0);
+        if (launch_finish(w.d_P, p, m, n, dC, ldc, fill_rows, trans ? 1 : 0, centered, d_sumB, d_sumfB, h->d_f, s, pass ? nullptr : d_E, 0, 0, gate, nullptr, se - sb, group)) return 1;
+      }
+      if (!pass && prof) { MXA_HIP(hipEventRecord(pe1, s)); h->prof_pending[slot] = true; }
+    }
+    return 0;
+  }
   int rc = use_lut ? launch_lut(G, dB, ldb, n, w.d_P, p, s) : launch_gemm(GL, w.d_Bp, w.d_P, p, mode, s, next_ctr(w), 0, -1, nullptr, tr);
   if (prof && !rc) { MXA_HIP(hipEventRecord(pe1, s)); h->prof_pending[slot] = true; }
   if (!rc && d_E) {   // fallback of the denormal-operand mode, run only when the guard raised the flag: unscaled B, two-instruction conversion
@@ -711,6 +859,7 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
   int mode = gemm_default_mode(p.c);
   if (tr) mode = gemm_tr_mode(mode);
   if (mode != 2 && mode != 3) return 2;
+  { const size_t one = (size_t)p.n_pad * p.m_pad; if (partial_budget(w, one * p.splits, one) < one * p.splits) return 2; }   // partial sums beyond the budget: the grouped path of gemm_device
   if (ensure_partials(w, p, s)) return 1;
   { std::lock_guard<std::mutex> lk(g_prof_mutex); Geometry &geo = last_geometry(); geo.m = m; geo.k = k; geo.n = n; geo.splits = p.splits; geo.a = p.a; geo.c = p.c; geo.path = 0; }
   MXA_HIP(hipMemsetAsync(w.d_denflag, 0, sizeof(int), s));   // range guard of the denormal-operand mode, raised by any K group's launch_colexp
@@ -793,7 +942,14 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
   return den ? 2 : 0;
 }
 
+static int refuse_while_staging(const Handle *h, const char *who) {
+  if (!h->staging) return 0;
+  set_error(19, "%s: the object is still being staged (%ld of %ld SNP rows appended); call mxa_plink2compressed_end first", who, h->staged_rows, h->snps);
+  return 1;
+}
+
 int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, double *C, long ldc, long fill_rows, bool sync, bool timing) {
+  if (refuse_while_staging(h, "dgemm_compressed")) return 1;
   MXA_HIP(hipSetDevice(h->device));
   const PackedMatrix &G = trans ? h->snp_major : h->ind_major;
   const long m = G.rows, k = G.k;
@@ -843,6 +999,7 @@ int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, double *C,
 
 // out (indiv x n) = Zc * (Zc^T * V): the 'T' then the 'N' product with the snps x n intermediate kept in HBM
 int gram_any(Handle *h, int n, const double *V, long ldv, double *out, long ldo, bool sync) {
+  if (refuse_while_staging(h, "mxa_gram_matvec")) return 1;
   MXA_HIP(hipSetDevice(h->device));
   const long snps = h->snps, indiv = h->indiv;
   if (n <= 0) return 0;
@@ -934,6 +1091,23 @@ void mxa_plink2compressed_shard(char *plink, char *plink_transposed, int snps_to
   (void)create_handle(p, ps, pt, pi, snp_end - snp_begin, indiv, f ? f + snp_begin : nullptr, max_n, compressed);
 }
 
+int mxa_plink2compressed_begin(long snps, long indiv, int max_n, void **compressed) {
+  clear_error();
+  return begin_handle(snps, indiv, max_n, compressed);
+}
+int mxa_plink2compressed_rows(void *compressed, const unsigned char *plink_rows, long snp_begin, long nrows, const double *f_rows) {
+  clear_error();
+  if (is_multi(compressed)) { set_error(16, "mxa_plink2compressed_rows: not available on a multi-device object"); return 1; }
+  Handle *h = as_handle(compressed, "mxa_plink2compressed_rows");
+  return h ? append_rows(h, plink_rows, snp_begin, nrows, f_rows) : 1;
+}
+int mxa_plink2compressed_end(void *compressed) {
+  clear_error();
+  if (is_multi(compressed)) { set_error(16, "mxa_plink2compressed_end: not available on a multi-device object"); return 1; }
+  Handle *h = as_handle(compressed, "mxa_plink2compressed_end");
+  return h ? end_handle(h) : 1;
+}
+
 static int trans_flag(const char *trans) {  // 5codesAPI.c:73-77
   if (!trans) exit(99);   // the reference dereferences it; a NULL letter is "anything else"
   if (*trans == 'T' || *trans == 't' || *trans == 'Y' || *trans == 'y') return 1;
@@ -958,6 +1132,7 @@ int mxa_dgemm_compressed_device(char trans, void *compressed, int n, const doubl
   Handle *h = as_handle(compressed, "mxa_dgemm_compressed_device");
   if (!h) return 1;
   if (n <= 0) return 0;
+  if (refuse_while_staging(h, "mxa_dgemm_compressed_device")) return 1;
   MXA_HIP(hipSetDevice(h->device));
   hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->stream;
   if (gemm_device(h, t != 0, n, dB, ldb, dC, ldc, ldc, s, sync != 0)) return 1;
@@ -1232,7 +1407,42 @@ int bed_range_to_handle(const char *base_c, long snps_total, long indiv, long sn
     size_t free_b = 0, total_b = 0;
     if (bad(hipMemGetInfo(&free_b, &total_b), __LINE__)) goto out;
     const size_t raw = (size_t)rows * bps, raw_t = (size_t)indiv * bpi;
-    single = policy == 1 || (policy == 2 && raw + raw_t + object_footprint(rows, indiv, max_n, false) > free_b && raw + object_footprint(rows, indiv, max_n, true) <= free_b);
+    single = policy == 1 || (policy == 2 && raw + raw_t + object_footprint(rows, indiv, max_n, false) > free_b && 2 * chunk_bytes + object_footprint(rows, indiv, max_n, true) <= free_b);
+  }
+  if (single) {
+    // ONE packed copy: the file is streamed straight into the object (round 5) -- chunk c + 1 is read from the file while chunk c is uploaded, recoded into
+    // the tiled layout and counted (k_recode, k_allele_freq), all on the object's stream; device memory beyond the object: two 64 MB chunks.  (Round 4 held
+    // the raw matrix on the device beside the object: a 250 GB .bed could not become a 250 GB object.)
+    uint8_t *dchunk[2] = {nullptr, nullptr};
+    Handle *h = nullptr;
+    {
+      void *obj = nullptr;
+      if (begin_handle(rows, indiv, max_n, &obj, dev)) { rc = 1; goto out; }
+      h = reinterpret_cast<Handle *>(obj);
+      *out = obj;
+    }
+    for (int i = 0; i < 2 && !rc; i++)
+      if (bad(hipMalloc((void **)&dchunk[i], chunk_bytes), __LINE__) || bad(hipHostMalloc(&pin[i], chunk_bytes, hipHostMallocDefault), __LINE__) ||
+          bad(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming), __LINE__)) break;
+    {
+      int slot = 0;
+      bool used[2] = {false, false};
+      for (size_t r0 = 0; r0 < (size_t)rows && !rc; r0 += rows_per_chunk, slot ^= 1) {
+        const size_t nr = std::min(rows_per_chunk, (size_t)rows - r0);
+        if (used[slot] && bad(hipEventSynchronize(ev[slot]), __LINE__)) break;     // upload and kernels that last used this pair of buffers are done
+        if (fread(pin[slot], 1, nr * bps, fh) != nr * bps) { set_error(1, "mxa_bed2compressed: %s.bed is shorter than %ld x ceil(%ld/4) bytes", base.c_str(), snps_total, indiv); rc = 1; break; }
+        if (bad(hipMemcpyAsync(dchunk[slot], pin[slot], nr * bps, hipMemcpyHostToDevice, h->stream), __LINE__)) break;
+        if (launch_recode(dchunk[slot], bps, (long)r0, (long)nr, indiv, 0, h->snp_major, h->stream) ||
+            launch_allele_freq(dchunk[slot], (long)nr, indiv, h->d_f + r0, h->stream)) { rc = 1; break; }
+        if (bad(hipEventRecord(ev[slot], h->stream), __LINE__)) break;
+        used[slot] = true;
+      }
+      if (!rc) bad(hipStreamSynchronize(h->stream), __LINE__);
+    }
+    if (!rc) { h->staged_rows = rows; rc = end_handle(h); }
+    if (!rc && f_out_local) memcpy(f_out_local, h->h_f, sizeof(double) * rows);
+    for (int i = 0; i < 2; i++) if (dchunk[i]) (void)hipFree(dchunk[i]);
+    goto out;
   }
   if (bad(hipMalloc((void **)&d_plink, (size_t)rows * bps), __LINE__) || (!single && bad(hipMalloc((void **)&d_plink_t, (size_t)indiv * bpi), __LINE__)) ||
       bad(hipMalloc((void **)&d_f, sizeof(double) * rows), __LINE__) || bad(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking), __LINE__)) goto out;

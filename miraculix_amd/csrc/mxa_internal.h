@@ -75,6 +75,10 @@ struct Handle {
   // ind_major then holds the DIMENSIONS of the missing copy (for the launch plans) with d == nullptr; 'T' products run in the plain form, 'N' products in the
   // transposed-operand forms (k_gemm<..., TR>, k_gemm_i8_tn), both on snp_major.
   bool single = false;
+  // incremental staging (mxa_plink2compressed_begin / _rows / _end, round 5): the object exists, its packed matrix is being filled by SNP-row blocks;
+  // products are refused until _end
+  bool staging = false;
+  long staged_rows = 0;
   double *d_f = nullptr;     // snps
   double *h_f = nullptr;
   bool has_f = false;
@@ -117,6 +121,11 @@ int single_orientation_policy();
 size_t object_footprint(long snps, long indiv, int max_n, bool single);   // device bytes of a staged object: packed copies (tile padding included) + workspace
 extern thread_local int tl_single_override;
 void destroy_handle(Handle *h);
+// incremental staging of a single-orientation object: allocate (packed SNP-major matrix zeroed, workspace), then SNP-row blocks in any order, then seal.
+// rows: compact PLINK rows (pitch ceil(indiv/4)), host or device; f_rows nullable: the block's frequencies are then counted on the device (k_allele_freq).
+int begin_handle(long snps, long indiv, int max_n, void **out, int device = -1);
+int append_rows(Handle *h, const uint8_t *rows, long snp_begin, long nrows, const double *f_rows);
+int end_handle(Handle *h);
 // pointer classification: 0 = host, 1 = device / managed memory (its device in *dev)
 int ptr_location(const void *p, int *dev);
 // One product on one device object, operands anywhere: B (k x n, ld ldb) and C (m x n, ld ldc) may be host memory, memory of this
@@ -214,7 +223,9 @@ int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double 
 // fill_rows: rows [m, fill_rows) of every column are zero-filled (fill_rows <= ldc)
 int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC, long ldc, long fill_rows, int mode_trans,
                   bool centered, const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s, const int *d_E = nullptr, int e_splits = 0,
-                  int e_stride = 0, const int *run_if_set = nullptr, const int *unscaled_if_set = nullptr);
+                  int e_stride = 0, const int *run_if_set = nullptr, const int *unscaled_if_set = nullptr, int group_splits = 0, int group = 0);
+// group_splits > 0: dP holds only that many splits (one GROUP of the plan's K splits); group bit 0: continue the running sum kept in C, bit 1: not the
+// last group -- the raw sum is stored (no scale-back, no centring).  See gemm_grouped (mxa_api.cpp).
 // unscaled_if_set (nullable, device int): when *unscaled_if_set != 0 the partial sums were produced WITHOUT the operand scaling (MODE 0 fallback): d_E is ignored
 // per-device one-time hipFuncSetAttribute(MaxDynamicSharedMemorySize): function attributes are per device, `mask` has one bit per device
 int ensure_dyn_lds(const void *func, int bytes, unsigned long long *mask);

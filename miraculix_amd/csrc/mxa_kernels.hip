@@ -1040,13 +1040,22 @@ __global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, lo
                                                 double *__restrict__ Cout, long ldc, long fill_rows, int mode_trans, int centered,
                                                 const double *__restrict__ sumB, const double *__restrict__ sumfB,
                                                 const double *__restrict__ f, const int *__restrict__ E, int back, int e_splits, int e_stride,
-                                                const int *__restrict__ run_if_set, const int *__restrict__ unscaled_if_set) {
+                                                const int *__restrict__ run_if_set, const int *__restrict__ unscaled_if_set, int group) {
   const int j = blockIdx.y;
   const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (run_if_set && *run_if_set == 0) return;
   if (unscaled_if_set && *unscaled_if_set != 0) E = nullptr;   // the MODE 0 fallback produced these partial sums: nothing to scale back
   if (r >= fill_rows) return;
+  // K-split GROUPS (products whose partial sums would not fit the device: gemm_grouped): `splits` partials of one group are added to the running
+  // sum kept, unscaled and uncentred, in C itself -- bit 0: start from C instead of 0, bit 1: not the last group (store the raw sum).  The
+  // additions run in the same ascending split order as one pass over all splits: bit-identical.
+  const bool acc_in = group & 1, raw_out = group & 2;
   double v = 0.0;
+  if (r < m && acc_in) v = Cout[r + (long)j * ldc];
+  if (r < m && raw_out) {
+    const size_t tile = (size_t)(r / p_rows), within = (size_t)(r % p_rows), ntiles = (size_t)(m_pad / p_rows);
+    for (int s = 0; s < splits; s++) v += __builtin_nontemporal_load(&P[(((size_t)s * ntiles + tile) * n_pad + j) * p_rows + within]);
+  } else
   if (r < m) {
     const size_t tile = (size_t)(r / p_rows), within = (size_t)(r % p_rows), ntiles = (size_t)(m_pad / p_rows);
     if (E && e_splits > 0) {
@@ -1068,10 +1077,10 @@ __global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, lo
 
 int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC, long ldc, long fill_rows, int mode_trans, bool centered,
                   const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s, const int *d_E, int e_splits, int e_stride, const int *run_if_set,
-                  const int *unscaled_if_set) {
+                  const int *unscaled_if_set, int group_splits, int group) {
   dim3 grid((unsigned)((fill_rows + 255) / 256), n);
-  hipLaunchKernelGGL(k_finish, grid, dim3(256), 0, s, dP, p.m_pad, p.p_rows, p.n_pad, p.splits, m, n, dC, ldc, fill_rows, mode_trans, centered ? 1 : 0,
-                     d_sumB, d_sumfB, d_f, d_E, 1074 - kDenUp, e_splits, e_stride, run_if_set, unscaled_if_set);
+  hipLaunchKernelGGL(k_finish, grid, dim3(256), 0, s, dP, p.m_pad, p.p_rows, p.n_pad, group_splits > 0 ? group_splits : p.splits, m, n, dC, ldc, fill_rows, mode_trans,
+                     centered ? 1 : 0, d_sumB, d_sumfB, d_f, d_E, 1074 - kDenUp, e_splits, e_stride, run_if_set, unscaled_if_set, group);
   MXA_HIP(hipGetLastError());
   return 0;
 }

@@ -100,6 +100,38 @@ def init_compressed_from_bed_range(bed_path, snp_begin, snp_end, max_ncol, snps=
     return obj_ref, f
 
 
+def init_compressed_begin(snps, indiv, max_ncol):
+    """Additive (mxa_plink2compressed_begin): allocate a single-orientation object to be filled by SNP-row blocks (append_rows) and sealed
+    (init_compressed_end) -- staging without the whole PLINK matrix behind one pointer (include/miraculix_amd.h)."""
+    obj_ref = ctypes.c_void_p(None)
+    L = _lib.check_library_handle()
+    if L.mxa_plink2compressed_begin(int(snps), int(indiv), int(max_ncol), ctypes.byref(obj_ref)) or not obj_ref.value:
+        raise RuntimeError("mxa_plink2compressed_begin failed: " + _lib.last_error()[1])
+    return obj_ref
+
+
+def append_rows(obj_ref, plink_rows, snp_begin, freq=None):
+    """SNP rows [snp_begin, snp_begin + plink_rows.shape[0]) of the object: compact PLINK rows (uint8, C-contiguous numpy array or torch tensor, host or
+    device); freq: their allele frequencies, or None to have them counted on the device."""
+    check_storage_object(obj_ref)
+    L = _lib.check_library_handle()
+    if freq is not None and not _lib.is_torch_tensor(freq):
+        freq = np.ascontiguousarray(freq, dtype=np.float64)
+    if L.mxa_plink2compressed_rows(obj_ref, _lib.ptr(plink_rows), int(snp_begin), int(plink_rows.shape[0]), _lib.ptr(freq)):
+        raise RuntimeError("mxa_plink2compressed_rows failed: " + _lib.last_error()[1])
+
+
+def init_compressed_end(obj_ref, snps):
+    """seal an incrementally staged object; returns its allele frequencies (numpy)"""
+    check_storage_object(obj_ref)
+    L = _lib.check_library_handle()
+    if L.mxa_plink2compressed_end(obj_ref):
+        raise RuntimeError("mxa_plink2compressed_end failed: " + _lib.last_error()[1])
+    f = np.zeros(snps, dtype=np.float64)
+    L.get_compressed_freq(obj_ref, _lib.ptr(f))
+    return f
+
+
 def num_shards(obj_ref):
     """number of per-device objects behind a handle: > 1 for one created under MIRACULIX_NUM_GPUS > 1 (include/miraculix_amd.h)"""
     return _lib.check_library_handle().mxa_num_shards(obj_ref)

@@ -56,6 +56,12 @@ def load_shared_library():
     L.mxa_bed2compressed.restype = ctypes.c_int
     L.mxa_bed2compressed_range.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]
     L.mxa_bed2compressed_range.restype = ctypes.c_int
+    L.mxa_plink2compressed_begin.argtypes = [ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    L.mxa_plink2compressed_begin.restype = ctypes.c_int
+    L.mxa_plink2compressed_rows.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_void_p]
+    L.mxa_plink2compressed_rows.restype = ctypes.c_int
+    L.mxa_plink2compressed_end.argtypes = [ctypes.c_void_p]
+    L.mxa_plink2compressed_end.restype = ctypes.c_int
     L.mxa_num_shards.argtypes = [ctypes.c_void_p]
     L.mxa_num_shards.restype = ctypes.c_int
     L.mxa_shard_bounds.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]
@@ -113,6 +119,12 @@ def load_shared_library():
     L.mxa_profile_get.restype = None
     L.mxa_last_geometry.argtypes = [ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     L.mxa_last_geometry.restype = None
+    L.mxa_single_orientation.argtypes = [ctypes.c_void_p]
+    L.mxa_single_orientation.restype = ctypes.c_int
+    L.mxa_partial_capacity.argtypes = [ctypes.c_void_p]
+    L.mxa_partial_capacity.restype = ctypes.c_long
+    L.mxa_plan_partial_doubles.argtypes = [ctypes.c_long, ctypes.c_long, ctypes.c_int]
+    L.mxa_plan_partial_doubles.restype = ctypes.c_long
     _LIBRARY_HANDLE[0] = L
     return L
 
