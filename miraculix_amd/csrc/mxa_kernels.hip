@@ -90,6 +90,14 @@ int launch_recode(const uint8_t *d_src, size_t src_pitch, long row0, long nrows,
 // 16S + (blk + 4*k) = 16S + (l>>2) to it; tools/mfma_f64_probe2.hip).  A slab of 8 K-steps of one chunk is one contiguous
 // run of C*4 KiB, so it streams HBM -> LDS as C*4 lane-linear LDS-DMA units for any C.
 // K-steps [S0, S0 + S_cnt) only (the host-operand pipeline packs B in K ranges as they arrive); the whole array: S0 = 0, S_cnt = S_total.
+// K ORDER of k_gemm (round 5).  K-step S = 8 slab + t (t = 0..7) of the MFMA stream, K slot kk = 0..15 of the instruction (lane >> 2)  <->  genotype
+//   c = 128 slab + 16 (kk & 7) + 8 (kk >> 3) + t.
+// A lane's eight K-steps of a slab then take their genotypes from ONE dword of a packed row -- dword kk & 7, fields 8 (kk >> 3) + t -- so the plain form
+// (output rows = packed rows) reads one dword per row and slab (A / 2 ds_read2_b32 per slab) where the natural order c = 16 S + kk needed the row's
+// whole 32 bytes (2 A reads of 16 bytes; every lane used one field in sixteen).  The transposed-operand form keeps its LDS reads: the permutation sits on
+// the global side of its LDS-DMA (k_gemm: tr_voff).  Both forms and k_pack_B share this one map, so they still produce identical sums.
+__host__ __device__ __forceinline__ long gemm_k_index(long S, int kk) { return (S >> 3) * 128 + 16 * (kk & 7) + 8 * (kk >> 3) + (S & 7); }
+
 __global__ void __launch_bounds__(256) k_pack_B(const double *__restrict__ B, long ldb, long k, int n,
                                                 double *__restrict__ Bp, long total, int C, long S_total, const int *__restrict__ E, int up, long S0, long S_cnt,
                                                 const int *__restrict__ run_if_set, int rowscale) {
@@ -101,14 +109,14 @@ __global__ void __launch_bounds__(256) k_pack_B(const double *__restrict__ B, lo
     const long cs = sh / C;
     const long S = S0 + cs % S_cnt;
     const int chunk = (int)(cs / S_cnt);
-    const long row = S * 16 + (l >> 2);
+    const long row = gemm_k_index(S, l >> 2);
     const int col = chunk * 4 * C + 4 * h + (l & 3);
     double v = 0.0;
     if (row < k && col < n) {
       v = B[row + (long)col * ldb];
-      // denormal-operand mode: column scaled to just below 2^up (exact); rowscale (k_gemm MODE 3): row 16 S + j also by 4^-j, because
-      // the genotype operand of that row is z * 4^j (the field is masked where it stands)
-      if (E) v = ldexp(v, up - E[col] - (rowscale ? 2 * (l >> 2) : 0));
+      // denormal-operand mode: column scaled to just below 2^up (exact); rowscale (k_gemm MODE 3, plain form): row c also by 4^-(c & 15), because
+      // the genotype operand of that row is z * 4^(c & 15) (the field is masked where it stands in its dword)
+      if (E) v = ldexp(v, up - E[col] - (rowscale ? 2 * (int)(row & 15) : 0));
     }
     Bp[(((size_t)chunk * S_total + S) * C + h) * 64 + l] = v;
   }
@@ -334,8 +342,9 @@ struct GemmCfg {
 //                     product and sum is the same as with normal operands unless an intermediate would under- or overflow.
 //   MODE 0:           v_bfe_u32 + v_cvt_f64_u32 -- 2 VALU per fragment, all A fragments of a K-step converted first, then
 //                     the A*C MFMAs back to back (pinned with sched_barrier).
-//   MODE 1 (kept for A/B measurement): v_bfe_u32, v_lshl_add_u32, v_cmp, v_cndmask building the high word by integer ops
-//                     -- 4 VALU per fragment, interleaved with the MFMAs by the compiler.
+//   MODE 3:           as MODE 2 with v_and_b32 (VOP2) instead of v_bfe_u32 (VOP3): the field is masked where it stands, the power-of-two scale
+//                     of its position is divided out exactly (plain form: k_pack_B scales the rows of B; transposed form: the epilogue).
+//   (MODE 1, the high word built by four integer VALU instructions, was removed in round 5: 63.6 TFLOP/s against 69.7 for MODE 0.)
 // Why it matters: on gfx950 every VALU instruction in an fp64-MFMA stream costs 6-13 cycles of MFMA time, wherever it
 // is placed and whether or not an MFMA depends on it (tools/mfma_f64_probe5.hip, profiles/r01_mfma_f64_probe.txt): the
 // VALU instruction count per MFMA is the lever, not latency hiding.  Measured on MI355X, 200k x 50k x 32:
@@ -383,6 +392,9 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
   // fp64 MFMA stream (see MODE comment above).
   const uint32_t b_lane = lane * 16;
   const uint32_t a_lane = lane * 16;
+  // TR: lane l of a 1 KiB unit fills LDS row position P = 32 (q & 3) + (l >> 1), half l & 1: K-step t = 2 (q & 3) + (l >> 5), K slot kk = (l >> 1) & 15;
+  // source = packed row 16 (kk & 7) + 8 (kk >> 3) + t of the half tile (32 bytes per row); the 2 (q & 3) rows are the scalar part of the address
+  const uint32_t tr_voff = (uint32_t)((16 * ((lane >> 1) & 7) + 8 * ((lane >> 4) & 1) + (lane >> 5)) * kSlabBytes + (lane & 1) * 16);
   const size_t nslabs_all = pitch / kSlabBytes;
   const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
   struct Unit { int rb, nc, sp, slab0, slab1; const char *Bp_u, *G_u; };
@@ -430,7 +442,8 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
         if (Cfg::kAUnits % kWaves == 0 || q < Cfg::kAUnits) {
           size_t sl = (size_t)u.rb * nsw + (q >> 2);
           if (sl >= nslabs_all) sl = nslabs_all - 1;
-          dma16_p<MXA_NT_GEMM != 0>(arow + sl * kTileBytes + (q & 3) * 1024, a_lane, base + Cfg::kBBytes + q * 1024);
+          // LDS row position P = 32 (q & 3) + lane / 2 = 16 t + kk receives packed row gemm_k_index(t, kk) of the K slab (tr_voff: the lane's part)
+          dma16_p<MXA_NT_GEMM != 0>(arow + sl * kTileBytes + (q & 3) * 64, tr_voff, base + Cfg::kBBytes + q * 1024);
         }
       }
     }
@@ -444,9 +457,15 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
     asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
     ap[g].x = 0; ap[g].y = zero;
   }
-  const int sh = 2 * (lane >> 2);                                 // field of this lane inside a 16-genotype dword
-  const uint32_t fmask = 3u << sh;                                // MODE 3: the field stays where it is
-  const int a_off = (wave * Cfg::kRowsWave + (lane & 3)) * kSlabBytes;  // + g*4 rows -> + g*4*32 bytes
+  // plain form: the lane's dword of a packed row, and its field in K-step kst: 8 (lane >> 5) + kst (gemm_k_index)
+  uint32_t psh[kSlabSteps], pmask[kSlabSteps];
+#pragma unroll
+  for (int t = 0; t < kSlabSteps; t++) {
+    psh[t] = 16 * (lane >> 5) + 2 * t;
+    pmask[t] = 3u << psh[t];
+    asm volatile("" : "+v"(pmask[t]));                            // opaque: kept in a register, not rebuilt by a shift beside the MFMA stream
+  }
+  const int a_off = (wave * Cfg::kRowsWave + (lane & 3)) * kSlabBytes + ((lane >> 2) & 7) * 4;  // + g*4 rows -> + g*4*32 bytes
   const int b_off = lane * 8;
   // TR: packed row (lane >> 2) of the K-step, the wave's A bytes of it; field shifts of the lane's individuals 4 g + i, g & 3 = 0..3
   const int tr_off = ((wave * A) / kSlabBytes) * (kSlabK * kSlabBytes) + (lane >> 2) * kSlabBytes + (wave * A) % kSlabBytes;
@@ -520,58 +539,37 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
             for (int h = 0; h < C; h++) acc[g][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[g], bf[h], acc[g][h], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
-      } else
+      } else {
+        // plain form, permuted K order (gemm_k_index): ONE dword per packed row and slab -- dword (lane >> 2) & 7 of row 4 g + i -- holds the lane's
+        // genotypes of all eight K-steps (fields 8 (lane >> 5) + kst)
+        uint32_t aw[A];
 #pragma unroll
-      for (int ks2 = 0; ks2 < kSlabSteps / 2; ks2++) {
-        uint2 aw[A];
+        for (int g = 0; g < A; g++) aw[g] = *reinterpret_cast<const uint32_t *>(abase + g * 4 * kSlabBytes);
 #pragma unroll
-        for (int g = 0; g < A; g++) aw[g] = *reinterpret_cast<const uint2 *>(abase + g * 4 * kSlabBytes + ks2 * 8);
-#pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-          const int kst = 2 * ks2 + kk;
+        for (int kst = 0; kst < kSlabSteps; kst++) {
           double bf[C];
 #pragma unroll
           for (int h = 0; h < C; h++) bf[h] = *reinterpret_cast<const double *>(bbase + (kst * C + h) * 512);
-          if (MODE == 2 || MODE == 3) {
-            // denormal operand: the pair (low word = z, high word = 0) IS the double z * 2^-1074.  Only the low word is rewritten
-            // (one VALU instruction); the high words were zeroed once and stay in place (loop-carried register pairs).
-            // MODE 2: v_bfe_u32 (VOP3).  MODE 3: v_and_b32 (VOP2) with the lane's field mask -- the field stays at its bit position 2 j, i.e.
-            // the operand is z * 4^j * 2^-1074, and k_pack_B has scaled row (16 S + j) of B by 4^-j (exact): beside the MFMA stream the
-            // two-operand form costs ~4.5 cycles against ~6.5 (tools/mfma_f64_probe6.hip; it matters where one extraction feeds few MFMAs).
-            double af[A];
+          double af[A];
 #pragma unroll
-            for (int g = 0; g < A; g++) {
-              if (MODE == 2) ap[g].x = __builtin_amdgcn_ubfe(kk ? aw[g].y : aw[g].x, sh, 2);
-              else asm volatile("v_and_b32 %0, %1, %2" : "=v"(ap[g].x) : "v"(fmask), "v"(kk ? aw[g].y : aw[g].x));
+          for (int g = 0; g < A; g++) {
+            if (MODE == 3) {
+              // denormal operand, field masked where it stands (v_and_b32, VOP2): the operand is z * 4^field * 2^-1074 and k_pack_B has scaled
+              // row c of B by 4^-(c & 15) (exact).  Only the low word is rewritten; the high words were zeroed once and stay in place.
+              asm volatile("v_and_b32 %0, %1, %2" : "=v"(ap[g].x) : "v"(pmask[kst]), "v"(aw[g]));
               af[g] = __builtin_bit_cast(double, ap[g]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int g = 0; g < A; g++)
-#pragma unroll
-              for (int h = 0; h < C; h++) acc[g][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[g], bf[h], acc[g][h], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-          } else if (MODE == 0) {
-            double af[A];
-#pragma unroll
-            for (int g = 0; g < A; g++) af[g] = (double)__builtin_amdgcn_ubfe(kk ? aw[g].y : aw[g].x, sh, 2);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int g = 0; g < A; g++)
-#pragma unroll
-              for (int h = 0; h < C; h++) acc[g][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[g], bf[h], acc[g][h], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-          } else {
-#pragma unroll
-            for (int g = 0; g < A; g++) {
-              const uint32_t z = __builtin_amdgcn_ubfe(kk ? aw[g].y : aw[g].x, sh, 2);
-              uint32_t hi = (z << 20) + 0x3FE00000u;   // 1.0 -> 0x3FF00000, 2.0 -> 0x40000000
-              hi = z ? hi : 0u;
-              const double af = __hiloint2double((int)hi, 0);
-#pragma unroll
-              for (int h = 0; h < C; h++) acc[g][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(af, bf[h], acc[g][h], 0, 0, 0);
+            } else {
+              const uint32_t z = __builtin_amdgcn_ubfe(aw[g], psh[kst], 2);
+              if (MODE == 0) af[g] = (double)z;
+              else { ap[g].x = z; af[g] = __builtin_bit_cast(double, ap[g]); }
             }
           }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int g = 0; g < A; g++)
+#pragma unroll
+            for (int h = 0; h < C; h++) acc[g][h] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[g], bf[h], acc[g][h], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -640,8 +638,9 @@ int gemm_default_mode(int c) {
   // MODE 2 (v_bfe_u32) / MODE 3 (v_and_b32, field in place, B rows pre-scaled): the two-operand form is cheaper beside the MFMA stream
   // (tools/mfma_f64_probe6.hip: 4.5 against 6.5 cycles per extraction); it shows where one extraction feeds few MFMAs (C <= 4)
   static const int env = [] { const char *e = getenv("MXA_GEMM_MODE"); return e ? atoi(e) : -1; }();
-  if (env >= 0) return env;
-  return c <= 4 ? 3 : 2;
+  if (env == 0 || env == 2 || env == 3) return env;
+  (void)c;
+  return 3;
 }
 
 // resident workgroups of k_gemm per CU by tile: the narrow tiles need few registers (110 / 148 VGPRs for C = 1 / 2 -> 4 / 3 waves per SIMD),
@@ -833,7 +832,6 @@ int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const Gemm
   }
 #define MXA_DISPATCH(AA, CC)                                              \
   if (p.a == AA && p.c == CC) {                                           \
-    if (mode == 1) return launch_gemm_t<AA, CC, 1>(G, dBp, dP, p, s, split_begin, split_end, nullptr, d_ctr);     \
     if (mode == 2) return launch_gemm_t<AA, CC, 2>(G, dBp, dP, p, s, split_begin, split_end, nullptr, d_ctr);     \
     if (mode == 3) return launch_gemm_t<AA, CC, 3>(G, dBp, dP, p, s, split_begin, split_end, nullptr, d_ctr);     \
     return launch_gemm_t<AA, CC, 0>(G, dBp, dP, p, s, split_begin, split_end, run_if_set, d_ctr);                 \
