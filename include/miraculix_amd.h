@@ -18,6 +18,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the entry points declared in this header are exported (no C++ symbol of the
+ * implementation reaches the namespace of the Julia / R / Fortran process that loads it). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* ------------------------------------------------------------------ Part 1: reference ABI */
 
@@ -351,6 +356,9 @@ int mxa_single_orientation(void *compressed);
 /* capacity (doubles) of the partial-sum workspace an object holds right now; -1 for an invalid / multi-device object */
 long mxa_partial_capacity(void *compressed);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

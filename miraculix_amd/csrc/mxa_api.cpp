@@ -484,16 +484,13 @@ int end_handle(Handle *h) {
 // threads of a multi-device object go column by column.  hipMemcpy2DAsync to pageable host memory issued from several threads at the same
 // time leaves device memory behind on ROCm 7.2 (0.2-0.6 MiB per shard and object life cycle; not with HIP_LAUNCH_BLOCKING=1, not from a
 // single thread, not with 1-D copies: tools/soak_lifecycle.py), and a long-lived session must not creep.
-// MXA_COPY_COLUMNS=1 forces the per-column form everywhere, =2 a synchronous hipMemcpy2D (diagnosis).
 static thread_local bool tl_concurrent = false;
 void mark_thread_concurrent() { tl_concurrent = true; }
 static hipError_t copy_columns(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipStream_t s) {
   if (width == 0 || height == 0) return hipSuccess;
   if (dpitch == width && spitch == width) return hipMemcpyAsync(dst, src, width * height, hipMemcpyDefault, s);
   if (height == 1) return hipMemcpyAsync(dst, src, width, hipMemcpyDefault, s);
-  static const int mode = [] { const char *e = getenv("MXA_COPY_COLUMNS"); return e ? atoi(e) : 0; }();
-  if (mode == 2) { hipError_t e = hipStreamSynchronize(s); return e != hipSuccess ? e : hipMemcpy2D(dst, dpitch, src, spitch, width, height, hipMemcpyDefault); }
-  const bool per_column = mode == 1 || (tl_concurrent && ptr_location(dst, nullptr) == 0);
+  const bool per_column = tl_concurrent && ptr_location(dst, nullptr) == 0;
   if (!per_column) return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDefault, s);
   for (size_t j = 0; j < height; j++) {
     const hipError_t e = hipMemcpyAsync(static_cast<char *>(dst) + j * dpitch, static_cast<const char *>(src) + j * spitch, width, hipMemcpyDefault, s);
@@ -565,14 +562,6 @@ static bool gemm_use_tr(const GemmPlan &, const Handle *h, bool trans) {
   if (h->single) return !trans;            // one stored copy (SNP-major): 'N' transposed, 'T' plain
   const char *e = getenv("MXA_GEMM_TR");
   return !e || atoi(e) != 0;
-}
-// conversion variant of a transposed launch: 3 (default) = field masked in place (v_and_b32) with the scale 4^field on the OUTPUT row, undone in the
-// epilogue (no row scaling of B: launch_pack_B gets rowscale = false); 2 = v_bfe_u32.  MXA_GEMM_TR_MODE overrides (A/B).
-static int gemm_tr_mode(int mode) {
-  if (mode != 2 && mode != 3) return mode;
-  const char *e = getenv("MXA_GEMM_TR_MODE");
-  const int m = e ? atoi(e) : 3;
-  return (m == 2 || m == 3) ? m : 3;
 }
 static const PackedMatrix &gemm_operand(const Handle *h, bool trans, bool tr) { return (trans != tr) ? h->snp_major : h->ind_major; }
 
@@ -721,7 +710,6 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   const bool tr = !use_lut && gemm_use_tr(p, h, trans);   // transposed-operand form: from the OTHER stored orientation (gemm_use_tr)
   const PackedMatrix &GL = gemm_operand(h, trans, tr);
   int mode = gemm_default_mode(p.c);
-  if (tr) mode = gemm_tr_mode(mode);
   const int *d_E = nullptr;
   if (!use_lut && (mode == 2 || mode == 3)) {
     if (w.cap_exp < (size_t)n) {
@@ -857,7 +845,6 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
   }
   const PackedMatrix &GL = gemm_operand(h, trans, tr);
   int mode = gemm_default_mode(p.c);
-  if (tr) mode = gemm_tr_mode(mode);
   if (mode != 2 && mode != 3) return 2;
   { const size_t one = (size_t)p.n_pad * p.m_pad; if (partial_budget(w, one * p.splits, one) < one * p.splits) return 2; }   // partial sums beyond the budget: the grouped path of gemm_device
   if (ensure_partials(w, p, s)) return 1;

@@ -634,21 +634,15 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
   }
 }
 
-int gemm_default_mode(int c) {
-  // MODE 2 (v_bfe_u32) / MODE 3 (v_and_b32, field in place, B rows pre-scaled): the two-operand form is cheaper beside the MFMA stream
-  // (tools/mfma_f64_probe6.hip: 4.5 against 6.5 cycles per extraction); it shows where one extraction feeds few MFMAs (C <= 4)
-  static const int env = [] { const char *e = getenv("MXA_GEMM_MODE"); return e ? atoi(e) : -1; }();
-  if (env == 0 || env == 2 || env == 3) return env;
-  (void)c;
+int gemm_default_mode(int) {
+  // MODE 3 (v_and_b32, field masked in place, the scale divided out exactly) for every tile; MODE 0 (plain operands) is the range fallback.  The v_bfe_u32
+  // variant (MODE 2) was removed in round 5: slower on every tile in both forms (profiles/r05_gemm_plain_permuted_k_ab.txt: C2 43.2 against 42.4 ms).
   return 3;
 }
 
 // resident workgroups of k_gemm per CU by tile: the narrow tiles need few registers (110 / 148 VGPRs for C = 1 / 2 -> 4 / 3 waves per SIMD),
 // and more resident waves hide their extraction VALU (n = 4: 55-59 -> 58-64 TFLOP/s); the wide ones fill the register file with 2
-static int gemm_wg_per_cu(int c) {
-  static const int cap = [] { const char *e = getenv("MXA_GEMM_WG_PER_CU"); return e ? atoi(e) : 4; }();
-  return std::max(1, std::min(cap, c == 1 ? 4 : c == 2 ? 3 : 2));
-}
+static int gemm_wg_per_cu(int c) { return c == 1 ? 4 : c == 2 ? 3 : 2; }
 static long device_cus() {
   static const long r = [] {
     int dev = 0; hipDeviceProp_t prop;
@@ -682,8 +676,7 @@ GemmPlan plan_gemm(long m, long k_pad, int n, const GemmPlan *ksplits_like) {
   // slots run dry over about one piece's duration, half a piece of idle time per slot on average (measured with MXA_DIAG stamps at C2:
   // 0.95-1.0 ms of a 44.6 ms launch with equal pieces).  Hence LONG pieces of ~1.5 ms for the bulk and a TAPERED TAIL: the last
   // ~2.5 rounds' worth of pieces ~0.2 ms long.  Durations from the MFMA count of a slab at the waves per SIMD this tile runs with.
-  static const double piece_us = [] { const char *e = getenv("MXA_GEMM_PIECE_US"); return e ? atof(e) : 1500.0; }();
-  static const double tail_us = [] { const char *e = getenv("MXA_GEMM_TAIL_US"); return e ? atof(e) : 200.0; }();   // 0: no taper
+  constexpr double piece_us = 1500.0, tail_us = 200.0;
   const long units = (long)p.rowblocks * p.nchunks;
   const long resident = gemm_wg_per_cu(p.c) * device_cus();
   const double slab_us = (double)kSlabSteps * p.a * p.c * 16.0 * gemm_wg_per_cu(p.c) / 2390.0;
@@ -691,15 +684,10 @@ GemmPlan plan_gemm(long m, long k_pad, int n, const GemmPlan *ksplits_like) {
   // ... and no longer than the K range whose B slabs (C x 4 KiB per slab, streamed by every piece of a group) stay in one XCD's 4 MiB L2 next to
   // the packed rows passing through: 3 MiB.  Measured at C2 (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE per launch): pieces of 1.5 ms (214 / 181 slabs,
   // 6.8 / 5.8 MB of B) 25.3 GB, pieces of 0.66 ms (96 slabs, 3 MB) 18.9 GB against 12.8 GB algorithmic, for 0.3 % of the time.
-  static const long b_l2_bytes = [] { const char *e = getenv("MXA_GEMM_B_L2_BYTES"); return e ? atol(e) : 3L << 20; }();
-  if (b_l2_bytes > 0) {
-    long cap = b_l2_bytes / ((long)p.c * 4096);
-    // a SHORT K (the 'T' product of C2: 391 slabs) would be cut into a handful of pieces per row block only to respect the cap: every cut costs a partial
-    // result in HBM and an epilogue.  With the packed stream loaded non-temporally the slabs of a 4x longer range survive in the L2s well enough
-    // (C2 'T': 43.77-43.80 ms with 2-3 splits against 43.98-44.00 with 5; 'N', K = 7813 slabs, keeps the cap: 44.04 against 44.10-44.16)
-    // OFF by default: the 0.3-0.5 % of the 'T' call (0.2 % of a step) cost 6.5 GB more fabric traffic per 'T' launch (19.7 GB against 13.2; 12.8 algorithmic)
-    static const bool relax_short_k = [] { const char *e = getenv("MXA_GEMM_RELAX_SHORT_K"); return e && atoi(e) != 0; }();
-    if (relax_short_k && p.slabs_total <= 6 * cap && units >= 4 * resident) cap *= 4;   // ... and only with row blocks to spare (the 125k-row shard of C2 loses 1.3 % otherwise)
+  constexpr long b_l2_bytes = 3L << 20;
+  {
+    const long cap = b_l2_bytes / ((long)p.c * 4096);
+    // (relaxing the cap for a short K -- C2 'T' in 2-3 splits instead of 5 -- gained 0.3-0.5 % of that call for 6.5 GB more fabric traffic: removed)
     l1 = std::max<long>(8, std::min<long>(l1, cap));
   }
   while (l1 > 16 && units * ((p.slabs_total + l1 - 1) / l1) < 6 * resident) l1 = l1 * 3 / 4;   // at least ~6 rounds of pieces: the queues balance the slots
@@ -737,7 +725,7 @@ static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, c
     per_cu[dev & 63] = std::max(1, std::min(nb, gemm_wg_per_cu(C))) * prop.multiProcessorCount;
   }
   const long grid = std::min<long>(nunits, per_cu[dev & 63]);
-  static const int xcd_order = [] { const char *e = getenv("MXA_XCD_ORDER"); return e ? atoi(e) : 1; }();   // 0: one queue in plain order (A/B measurement)
+  constexpr int xcd_order = 1;   // per-XCD queues (one common queue in plain order was the A/B baseline of round 2)
   const KSplit ks{p.s1, p.l1, p.r1, p.l2};
   const int long_groups = (std::min(split_end, p.s1) - std::min(split_begin, p.s1)) * p.nchunks;
   const int g8 = xcd_order ? (long_groups & ~7) : 0;
@@ -808,13 +796,12 @@ int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const Gemm
                 const int *run_if_set, bool tr) {
   if (split_end < 0) split_end = p.splits;
   if (tr) {   // transposed operand: output rows = columns of G (its k individuals), K = rows of G in slabs of 128
-    if ((long)p.slabs_total * kSlabK > G.rows_pad || G.nslabs < 1 || (mode != 0 && mode != 2 && mode != 3)) {
+    if ((long)p.slabs_total * kSlabK > G.rows_pad || G.nslabs < 1 || (mode != 0 && mode != 3)) {
       set_error(4, "internal: transposed launch does not fit the packed matrix (K slabs %d x 128 > %ld rows) or mode %d", p.slabs_total, G.rows_pad, mode);
       return 1;
     }
 #define MXA_DISPATCH_TR(AA, CC)                                                                                          \
     if (p.a == AA && p.c == CC) {                                                                                        \
-      if (mode == 2) return launch_gemm_t<AA, CC, 2, true>(G, dBp, dP, p, s, split_begin, split_end, nullptr, d_ctr);     \
       if (mode == 3) return launch_gemm_t<AA, CC, 3, true>(G, dBp, dP, p, s, split_begin, split_end, nullptr, d_ctr);     \
       return launch_gemm_t<AA, CC, 0, true>(G, dBp, dP, p, s, split_begin, split_end, run_if_set, d_ctr);                 \
     }
@@ -832,7 +819,6 @@ int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const Gemm
   }
 #define MXA_DISPATCH(AA, CC)                                              \
   if (p.a == AA && p.c == CC) {                                           \
-    if (mode == 2) return launch_gemm_t<AA, CC, 2>(G, dBp, dP, p, s, split_begin, split_end, nullptr, d_ctr);     \
     if (mode == 3) return launch_gemm_t<AA, CC, 3>(G, dBp, dP, p, s, split_begin, split_end, nullptr, d_ctr);     \
     return launch_gemm_t<AA, CC, 0>(G, dBp, dP, p, s, split_begin, split_end, run_if_set, d_ctr);                 \
   }
@@ -1011,7 +997,7 @@ GemmPlan plan_lut(long m, long k_pad, int n) {
   p.p_rows = p.m_pad;
   p.slabs_total = (int)(k_pad / kLutKS);
   const long units = p.rowblocks;
-  static const long target = [] { const char *e = getenv("MXA_LUT_UNITS"); return e ? atol(e) : 8192L; }();
+  constexpr long target = 8192L;
   long want = (target + units - 1) / units;
   long max_splits = std::max<long>(1, p.slabs_total / 16);
   long splits = std::max<long>(1, std::min<long>(want, max_splits));
@@ -1256,7 +1242,7 @@ int launch_transpose_2bit(const uint8_t *d_in, long rows, long cols, uint8_t *d_
   if (rows <= 0 || cols <= 0) return 0;
   const long bin = (cols + 3) / 4, bout = (rows + 3) / 4;
   const bool aligned = (bin % 4 == 0) && (bout % 4 == 0) && (reinterpret_cast<uintptr_t>(d_in) % 4 == 0) && (reinterpret_cast<uintptr_t>(d_out) % 4 == 0);
-  static const bool no_tiled = getenv("MXA_TRANSPOSE_GENERIC") != nullptr;   // A/B measurement
+  constexpr bool no_tiled = false;
   // a launch may not exceed 2^32 threads: the grid is issued in chunks of 2^23 blocks (found by the 625k x 200k full-size test:
   // 30.5 M blocks x 256 threads were silently truncated to the grid modulo 2^24)
   if (aligned && !no_tiled) {

@@ -35,7 +35,7 @@ def load_shared_library():
             f"miraculix_amd: shared library {path} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C miraculix_amd/csrc`. There is no CPU fallback."
         )
-    L = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    L = ctypes.CDLL(path)   # RTLD_LOCAL: like the dlopen of the Julia binding (miraculix.jl:60-110)
     L.setOptions_compressed.argtypes = [ctypes.c_int] * 10
     L.setOptions_compressed.restype = None
     L.plink2compressed.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]

@@ -25,6 +25,7 @@ def built():
 def _declared_symbols():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"^\s*#.*$", "", text, flags=re.M)          # preprocessor lines
     return sorted(set(re.findall(r"\b(\w+)\s*\([^;{]*\)\s*;", text)))
 
 
@@ -45,6 +46,15 @@ def test_symbols_are_unmangled_c(built):
     names = {l.split()[-1] for l in out.splitlines() if l.strip()}
     for s in _declared_symbols():
         assert s in names
+
+
+def test_library_exports_the_c_abi_and_nothing_else(built):
+    """a drop-in .so is dlopen()ed into Julia / R / Fortran processes: no C++ symbol of the implementation (namespace mxa, kernel handles) may reach
+    their namespace -- the dynamic symbol table is exactly what the header declares (-fvisibility=hidden + csrc/exports.map)"""
+    out = subprocess.check_output(["nm", "-D", "--defined-only", built], text=True)
+    names = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    assert not [x for x in names if x.startswith("_Z")]
+    assert names == set(_declared_symbols()), names ^ set(_declared_symbols())
 
 
 def _run_py(code):
