@@ -4,6 +4,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <functional>
+#include "mxa_plan.h"
 
 namespace mxa {
 
@@ -198,14 +199,6 @@ int launch_pack_B(const double *dB, long ldb, long k, int n, double *dBp, long k
                   long S_cnt = -1, const int *run_if_set = nullptr, bool rowscale = false);
 int launch_colsums(const double *dB, long ldb, long k, int n, const double *d_f /*nullable*/, double *d_part,
                    double *d_sumB, double *d_sumfB, hipStream_t s);
-// p_rows: rows per tile of the partial-result array P[split][m_pad / p_rows][n_pad][p_rows] (k_gemm: the workgroup's row block, so a
-// workgroup writes one contiguous chunk; lookup kernel: m_pad, i.e. plain [split][n_pad][m_pad])
-// K splits (mxa_queue.h: KSplit): [0, s1) are l1 slabs long, the first r1 of them one more; [s1, splits) exactly l2 (tapered tail of
-// k_gemm; elsewhere s1 = splits, r1 = 0); slabs_per_split = l1
-struct GemmPlan { int a, c, nchunks, n_pad, splits, slabs_per_split, slabs_total, rowblocks; long m_pad; long p_rows; int s1, l1, l2, r1; };
-inline long plan_split_begin(const GemmPlan &p, int sp) {
-  return sp < p.s1 ? (long)sp * p.l1 + (sp < p.r1 ? sp : p.r1) : (long)p.s1 * p.l1 + p.r1 + (long)(sp - p.s1) * p.l2;
-}
 // ksplits_like: take the K pieces of another plan (row ranges of one product: identical sums)
 GemmPlan plan_gemm(long m, long k_pad, int n, const GemmPlan *ksplits_like = nullptr);
 // conversion variant of k_gemm for a tile of c column groups: 2 (v_bfe_u32) or 3 (v_and_b32 + B rows pre-scaled); MXA_GEMM_MODE overrides

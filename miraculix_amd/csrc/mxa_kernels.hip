@@ -640,9 +640,6 @@ int gemm_default_mode(int) {
   return 3;
 }
 
-// resident workgroups of k_gemm per CU by tile: the narrow tiles need few registers (110 / 148 VGPRs for C = 1 / 2 -> 4 / 3 waves per SIMD),
-// and more resident waves hide their extraction VALU (n = 4: 55-59 -> 58-64 TFLOP/s); the wide ones fill the register file with 2
-static int gemm_wg_per_cu(int c) { return c == 1 ? 4 : c == 2 ? 3 : 2; }
 static long device_cus() {
   static const long r = [] {
     int dev = 0; hipDeviceProp_t prop;
@@ -652,56 +649,7 @@ static long device_cus() {
   return r > 0 ? r : 256;
 }
 
-GemmPlan plan_gemm(long m, long k_pad, int n, const GemmPlan *ksplits_like) {
-  GemmPlan p{};
-  // tile choice by n: column chunks of at most 32 columns, C = groups of 4 columns per chunk (balanced over the chunks, so at most
-  // 3 padded columns per chunk), A = row groups of 4 per wave: A*C <= 64 accumulators (128 VGPRs)
-  p.nchunks = (n + 31) / 32;
-  const int per = (n + p.nchunks - 1) / p.nchunks;
-  p.c = (per + 3) / 4;
-  p.a = p.c <= 4 ? 16 : 8;
-  const int cols_chunk = 4 * p.c;
-  p.n_pad = p.nchunks * cols_chunk;
-  const int rows_wg = kWaves * 4 * p.a;
-  p.rowblocks = (int)((m + rows_wg - 1) / rows_wg);
-  p.m_pad = (long)p.rowblocks * rows_wg;
-  p.p_rows = rows_wg;
-  p.slabs_total = (int)(k_pad / kSlabK);
-  if (ksplits_like) {   // the same K pieces as another plan (row-range launches of the host-operand pipeline: identical sums)
-    p.splits = ksplits_like->splits; p.s1 = ksplits_like->s1; p.l1 = ksplits_like->l1; p.l2 = ksplits_like->l2; p.r1 = ksplits_like->r1; p.slabs_per_split = ksplits_like->slabs_per_split;
-    return p;
-  }
-  // K pieces.  The persistent workgroups (launch_gemm_t) pull pieces = (row block, column chunk, K split) from queues, so what matters is
-  // (i) the fixed cost per piece (its epilogue and the turn-around, ~8 us) against its duration and (ii) how the launch ends: the
-  // slots run dry over about one piece's duration, half a piece of idle time per slot on average (measured with MXA_DIAG stamps at C2:
-  // 0.95-1.0 ms of a 44.6 ms launch with equal pieces).  Hence LONG pieces of ~1.5 ms for the bulk and a TAPERED TAIL: the last
-  // ~2.5 rounds' worth of pieces ~0.2 ms long.  Durations from the MFMA count of a slab at the waves per SIMD this tile runs with.
-  constexpr double piece_us = 1500.0, tail_us = 200.0;
-  const long units = (long)p.rowblocks * p.nchunks;
-  const long resident = gemm_wg_per_cu(p.c) * device_cus();
-  const double slab_us = (double)kSlabSteps * p.a * p.c * 16.0 * gemm_wg_per_cu(p.c) / 2390.0;
-  long l1 = std::max<long>(8, std::min<long>(p.slabs_total, (long)(piece_us / slab_us + 0.5)));
-  // ... and no longer than the K range whose B slabs (C x 4 KiB per slab, streamed by every piece of a group) stay in one XCD's 4 MiB L2 next to
-  // the packed rows passing through: 3 MiB.  Measured at C2 (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE per launch): pieces of 1.5 ms (214 / 181 slabs,
-  // 6.8 / 5.8 MB of B) 25.3 GB, pieces of 0.66 ms (96 slabs, 3 MB) 18.9 GB against 12.8 GB algorithmic, for 0.3 % of the time.
-  constexpr long b_l2_bytes = 3L << 20;
-  {
-    const long cap = b_l2_bytes / ((long)p.c * 4096);
-    // (relaxing the cap for a short K -- C2 'T' in 2-3 splits instead of 5 -- gained 0.3-0.5 % of that call for 6.5 GB more fabric traffic: removed)
-    l1 = std::max<long>(8, std::min<long>(l1, cap));
-  }
-  while (l1 > 16 && units * ((p.slabs_total + l1 - 1) / l1) < 6 * resident) l1 = l1 * 3 / 4;   // at least ~6 rounds of pieces: the queues balance the slots
-  const long lt = tail_us > 0 ? std::max<long>(8, (long)(tail_us / slab_us + 0.5)) : 0;
-  const bool taper = lt > 0 && units * ((p.slabs_total + l1 - 1) / l1) >= 3 * resident;
-  const long tail = taper ? lt * std::max<long>(1, (5 * resident / 2 + units - 1) / units) : 0;   // short splits: about 2.5 rounds of short pieces
-  KSplit ks;
-  p.splits = ksplit_make(ks, p.slabs_total, l1, lt, tail);
-  p.s1 = ks.s1; p.l1 = ks.l1; p.r1 = ks.r1; p.l2 = ks.l2;
-  l1 = ks.l1;
-  p.slabs_per_split = (int)l1;
-  if (p.splits < 1) p.splits = 1;
-  return p;
-}
+GemmPlan plan_gemm(long m, long k_pad, int n, const GemmPlan *ksplits_like) { return plan_gemm_host(m, k_pad, n, device_cus(), ksplits_like); }
 
 template <int A, int C, int MODE, bool TR = false>
 static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, hipStream_t s, int split_begin, int split_end, const int *run_if_set,
@@ -987,25 +935,10 @@ static int launch_lut_t(const PackedMatrix &G, const double *dB, long ldb, int n
 
 constexpr int kLutKS = 128;   // genotypes per slab of the lookup kernel (= kSlabK, so the staged pitch fits)
 
-GemmPlan plan_lut(long m, long k_pad, int n) {
-  GemmPlan p{};
-  p.a = 0; p.c = 0;
-  p.n_pad = n <= 1 ? 1 : n <= 2 ? 2 : 4;
-  p.nchunks = 1;
-  p.rowblocks = (int)((m + 64 * kLutWaves - 1) / (64 * kLutWaves));
-  p.m_pad = (long)p.rowblocks * 64 * kLutWaves;
-  p.p_rows = p.m_pad;
-  p.slabs_total = (int)(k_pad / kLutKS);
-  const long units = p.rowblocks;
-  constexpr long target = 8192L;
-  long want = (target + units - 1) / units;
-  long max_splits = std::max<long>(1, p.slabs_total / 16);
-  long splits = std::max<long>(1, std::min<long>(want, max_splits));
-  p.slabs_per_split = (int)((p.slabs_total + splits - 1) / splits);
-  p.splits = (p.slabs_total + p.slabs_per_split - 1) / p.slabs_per_split;
-  p.s1 = p.splits; p.l1 = p.l2 = p.slabs_per_split; p.r1 = 0;
-  return p;
-}
+GemmPlan plan_lut(long m, long k_pad, int n) { return plan_lut_host(m, k_pad, n); }
+
+static_assert(kPlanWaves == kWaves && kPlanSlabSteps == kSlabSteps && kPlanSlabK == kSlabK && kPlanLutWaves == kLutWaves && kPlanLutKS == kLutKS,
+              "mxa_plan.h restates the kernels' geometry for the host-only planners");
 
 int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double *dP, const GemmPlan &p, hipStream_t s, const int *run_if_set) {
   if (p.m_pad > G.rows_pad || (size_t)p.slabs_total * (kLutKS / 4) > G.pitch) { set_error(4, "internal: packed matrix smaller than the lookup plan"); return 1; }

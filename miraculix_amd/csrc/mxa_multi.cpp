@@ -196,16 +196,6 @@ int grow_on(int dev, double **p, size_t *cap, size_t elems) {
   return 0;
 }
 
-void shard_blocks(long snps, int want, std::vector<long> &b, std::vector<long> &e) {
-  // contiguous blocks at multiples of 4, the same rule as miraculix_amd/distributed.py:shard_bounds; shards that
-  // would be empty (4 * shards > snps) are dropped
-  const long per = ((snps + want - 1) / want + 3) / 4 * 4;
-  for (int g = 0; g < want; g++) {
-    const long b0 = std::min(snps, g * per), e0 = std::min(snps, b0 + per);
-    if (e0 > b0) { b.push_back(b0); e.push_back(e0); }
-  }
-}
-
 int pick_devices(int nshards, std::vector<int> &dev) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {

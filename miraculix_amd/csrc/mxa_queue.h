@@ -10,6 +10,7 @@
 // the caller broadcasts the result through LDS.  Every workgroup leaves when a fetch returns -1: the grid always drains.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "mxa_plan.h"   // KSplit
 
 namespace mxa {
 
@@ -50,27 +51,5 @@ struct PieceQueue {
     else { const int t = bid - g8 * rowblocks; rb = t % rowblocks; grp = g8 + t / rowblocks; }
   }
 };
-
-// K splits of a launch plan, in units of 128 genotypes (slabs / stages): splits [0, s1) are LONG -- l1 units, the first r1 of them one
-// more, so that the long part is covered exactly -- and the rest are SHORT, exactly l2 units each: the TAPERED TAIL.  The pieces of a launch
-// are handed out in order, so the last ones are much shorter and the resident slots run dry within a fraction of a long piece's duration.
-struct KSplit { int s1, l1, r1, l2; };
-__host__ __device__ __forceinline__ int ksplit_begin(const KSplit &ks, int sp) {
-  return sp < ks.s1 ? sp * ks.l1 + (sp < ks.r1 ? sp : ks.r1) : ks.s1 * ks.l1 + ks.r1 + (sp - ks.s1) * ks.l2;
-}
-__host__ __device__ __forceinline__ int ksplit_len(const KSplit &ks, int sp) { return sp < ks.s1 ? ks.l1 + (sp < ks.r1 ? 1 : 0) : ks.l2; }
-// total units, long pieces of about l1_target units, short ones of lt units covering about `tail_units` of the total (0: no tail);
-// returns the number of splits
-__host__ inline int ksplit_make(KSplit &ks, long total, long l1_target, long lt, long tail_units) {
-  long s2 = 0;
-  if (lt > 0 && tail_units > 0 && 2 * lt <= l1_target) s2 = (tail_units + lt - 1) / lt;
-  while (s2 > 0 && s2 * lt > total / 2) s2--;
-  const long longpart = total - s2 * lt;
-  long s1 = longpart > 0 ? (longpart + l1_target - 1) / l1_target : 0;
-  if (s1 < 1 && longpart > 0) s1 = 1;
-  const long l1 = s1 ? longpart / s1 : 0;
-  ks.s1 = (int)s1; ks.l1 = (int)l1; ks.r1 = (int)(s1 ? longpart - s1 * l1 : 0); ks.l2 = (int)(s2 ? lt : l1);
-  return (int)(s1 + s2);
-}
 
 }  // namespace mxa

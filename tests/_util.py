@@ -13,7 +13,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+ORACLE_SO = os.environ.get("ORACLE_SO", os.path.join(ORACLE_DIR, "liboracle.so"))   # ORACLE_SO: the sanitizer build (tools/run_sanitizers.sh)
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libmiraculix_ref.so")
 REF_DRIVER = os.path.join(ORACLE_DIR, "_ref", "ref_driver")
 

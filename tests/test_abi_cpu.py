@@ -181,3 +181,12 @@ def test_peeled_plan_can_need_more_partials_than_the_unpeeled_one(built):
             if peeled > full:
                 worse.append((m, k, n, full, peeled))
     assert any(m == 30_000 and k == 100_000 and n == 10 for m, k, n, _, _ in worse), worse[:5]
+
+
+def test_planner_sweep_host_build():
+    """the host-only planners (miraculix_amd/csrc/mxa_plan.h: tiles, K splits with the tapered tail, SNP shards) swept over shapes by a plain g++
+    build of tests/host/plan_sweep.cpp; the same sweep runs under ASan + UBSan in tools/run_sanitizers.sh (profiles/r05_sanitizers.txt)"""
+    d = os.path.join(ROOT, "tests", "host")
+    subprocess.check_call(["make", "-C", d, "plan_sweep"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(d, "plan_sweep")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " 0 failures" in r.stdout, r.stdout[-2000:]

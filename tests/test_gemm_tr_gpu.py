@@ -1,6 +1,6 @@
 """Transposed-operand instantiation of k_gemm (round 4): a product computed from the copy whose ROWS are the K index -- 'N' from the SNP-major copy,
-'T' from the individual-major one; output rows = columns of the packed matrix.  It is the default for the widest tile (A = 8: n >= 17, 2 % faster)
-and the A/B of single-orientation storage (one packed copy serving both products).  MXA_GEMM_TR=0 / 1 force the plain /
+'T' from the individual-major one; output rows = columns of the packed matrix.  With the plain form (output rows = packed rows) it lets ONE packed copy
+serve both products; since round 5 both forms share the permuted K order (mxa_kernels.hip: gemm_k_index) and run at the same rate.  MXA_GEMM_TR=0 / 1 force the plain /
 the transposed form.  Same launch plan, same K order, same partial sums: the results must be BIT-IDENTICAL, for every
 tile shape (n = 8 ... 128: C = 2 ... 8, A = 16 / 8; 33 and 10: peeled columns beside it), ragged sizes (individuals not a multiple of the 128-wide
 slab nor of the 256-individual block of the A = 16 tiles: the clamped last slab), centred and not, padded leading dimensions -- and agree with the
@@ -22,15 +22,12 @@ def mx():
     return m
 
 
-def _product(dg, obj, prob, trans, B, tr, tr_mode=None):
+def _product(dg, obj, prob, trans, B, tr):
     os.environ["MXA_GEMM_TR"] = "1" if tr else "0"
-    if tr_mode is not None:
-        os.environ["MXA_GEMM_TR_MODE"] = str(tr_mode)
     try:
         return dg.dgemm_compressed_main(bool(trans), obj, np.asfortranarray(B.T), prob["snps"], prob["indiv"])
     finally:
         os.environ.pop("MXA_GEMM_TR", None)
-        os.environ.pop("MXA_GEMM_TR_MODE", None)
 
 
 @pytest.mark.parametrize("snps,indiv", [(2051, 777), (1003, 130), (4100, 1290), (700, 3001)])
@@ -48,11 +45,9 @@ def test_transposed_operand_is_bit_identical(mx, snps, indiv, n):
                 B = make_B(k, n, seed=7 + centered + 2 * trans)
                 C0 = _product(dg, obj, prob, trans, B, False)
                 assert dg.last_path() == "k_gemm"
-                C1 = _product(dg, obj, prob, trans, B, True, tr_mode=2)
+                C1 = _product(dg, obj, prob, trans, B, True)                   # field masked in place; the plain form has the scale on B's rows, this one on the output rows: exact powers of two
                 assert dg.last_path() == "k_gemm"
                 assert np.array_equal(C0, C1)
-                C3 = _product(dg, obj, prob, trans, B, True, tr_mode=3)        # field masked in place, row scale undone in the epilogue: exact powers of two
-                assert np.array_equal(C0, C3)
                 assert np.array_equal(C0, dg.dgemm_compressed_main(bool(trans), obj, np.asfortranarray(B.T), snps, indiv))   # the default picks one of the two
                 ref = o.dgemm_dense(trans, prob, B, centered)[:, :m]
                 assert np.abs(C1.T - ref).max() <= 1e-11 * np.abs(ref).max()
