@@ -92,8 +92,8 @@ class HostPrefault {
         if (errno == EAGAIN || errno == EINTR) continue;                                // skip this block; the copier's own faults cover it
       } else done_bytes_.fetch_add(len);
     }
-    t_done_ = std::chrono::steady_clock::now();   // the last thread to finish leaves the latest stamp (benign race: timing only)
-    finished_.fetch_add(1);
+    // the LAST thread to finish leaves the stamp: one writer, ordered before join() by the thread exit (no concurrent write of a non-atomic time_point)
+    if (finished_.fetch_add(1) + 1 == (int)threads_) t_done_ = std::chrono::steady_clock::now();
 #endif
   }
   uintptr_t lo_ = 0, hi_ = 0;
