@@ -946,7 +946,7 @@ def opt_in_engine_leg(W, L, args, step, sync, engine, flops_step, description):
     dN = float(((W.C_N - C_N64).abs().amax(dim=0) / C_N64.abs().amax(dim=0)).max())
     dT = float(((W.C_T - C_T64).abs().amax(dim=0) / C_T64.abs().amax(dim=0)).max())
     avg_ms = ms8 / max(1, la8)
-    out = {"engine": description, "kernel_family_of_last_product": {0: "k_gemm", 1: "k_lut", 2: "k_gemm_i8"}.get(path, str(path)),
+    out = {"engine": description, "kernel_family_of_last_product": {0: "k_gemm", 1: "k_lut", 2: "k_gemm_i8", 3: "k_small_n_fp64"}.get(path, str(path)),
            "value": round(flops_step * args.steps / dt8 * 1e-9, 1), "unit": "GFLOP/s (fp64-equivalent: same 2*snps*indiv*ncol count)",
            "ms_per_step": round(dt8 / args.steps * 1e3, 3), "avg_kernel_ms": round(avg_ms, 3), "digits_per_column": digits,
            "int8_ops_per_s_P": round(2.0 * W.snps_loc / W.n_shards * args.indiv * args.ncol * digits / (avg_ms * 1e-3) * 1e-15, 3),

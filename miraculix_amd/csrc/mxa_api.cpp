@@ -565,6 +565,8 @@ static bool gemm_use_tr(const GemmPlan &, const Handle *h, bool trans) {
 }
 static const PackedMatrix &gemm_operand(const Handle *h, bool trans, bool tr) { return (trans != tr) ? h->snp_major : h->ind_major; }
 
+constexpr int kSmallNMaxColsHost = 6;   // widest product that takes the guarded exact int8 route whole (mxa_gemm_i8.hip: kSmallNMaxCols)
+
 // Device operands only; asynchronous on s.  With timing, ev0/ev1 bracket the dominant kernel and harvest_profile() reads them later.
 static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, hipStream_t s, bool timing = true) {
   const PackedMatrix &G = trans ? h->snp_major : h->ind_major;   // reference picks d_plink for 'T' (dgemm_compressed_cuda.cu:270)
@@ -587,28 +589,64 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     h->prof_slot = slot ^ 1;
   }
   hipEvent_t pe0 = prof ? h->ev0[slot] : nullptr, pe1 = prof ? h->ev1[slot] : nullptr;
-  const bool auto_i8_pre = (engine == 0 || engine == 4) && n <= 2 && k >= 128;   // that route computes the column sums in its own statistics pass
-  if (centered && !auto_i8_pre && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
-  // Engine 0 at n <= 2 (the CG / GBLUP iteration, HBM-bound): the exact int8 slicing is used WHEN IT IS EXACT -- every column of B
-  // finite with an exponent span that fits its 32 (n = 1) / 16 (n = 2) digits, checked on the device per call (gemm_i8_device,
-  // guard).  Then B is represented without any error, all dot products are exact integers and the only roundings are the S - 1
-  // additions of the recombination: |error| <= 3.02 (S - 1) 2^-53 sum_k |z_k b_k|, below the K 2^-53 sum |z b| of
-  // an fp64 chain for K >= 128.  Otherwise (and always with engine 3) the fp64 pair-table kernel k_lut runs.
-  const bool auto_i8 = (engine == 0 || engine == 4) && n <= 2 && k >= 128;
-  // Engine 4 (i8-exact, opt-in) at n >= 3: the same exact slicing with the digit count chosen PER CALL from the measured exponent span of B's
-  // columns -- S = ceil((span + 55) / 8), at least 7 -- so that B is represented without error (the condition of the n <= 2 guard); the host reads
-  // three integers (one short sync, irrelevant beside a multi-millisecond product).  Beyond 24 digits (span > 137 binades), for non-finite
-  // entries, values near the underflow threshold or K < 128, the fp64 MFMA path below runs.  Error bound as for n <= 2 with S <= 24.
-  // Engine 0 takes the same route for 3 <= n <= 6 -- the products that would run on the single-group MFMA tile (4 columns per extraction: the
-  // tile the extraction VALU hurts most, MFMA pipe busy 0.82 at best; n = 5, 6 need a peel pass on top).  There the int8 route is bound by the
-  // packed-matrix stream like n <= 2 (1.3-1.9 ms against 3.2-4.4 ms on 500k x 50k), and it is taken only when it is exact.
-  static const int auto_exact_max_n = [] { const char *e = getenv("MXA_AUTO_EXACT_MAX_N"); return e ? atoi(e) : 6; }();
-  // single-orientation object, 'N': the plain int8 kernel needs the individual-major copy; k_gemm_i8_tn multiplies from the SNP-major one, one pass per
-  // tile of 32 expanded columns (n <= 2: one tile; 3 <= n <= 6 and peeled columns: 1-5).  gemm_i8_device declines (2) what would take more passes than
-  // the fp64 MFMA tile in its transposed form costs, and products with several column chunks (the opt-in engines at wide n): those run on the fp64 path.
+  // ---- the guarded exact int8 route of narrow products and of peeled columns (HBM-bound).
+  // B is split exactly into balanced radix-256 digits and multiplied on the int8 matrix cores with exact integer sums WHEN THAT IS EXACT: every column
+  // finite, its exponent span within the digits (e_max - e_min <= 8 S - 55), no underflow in the recombination.  Then no bit of B is dropped and the
+  // only roundings are the S - 1 additions of the recombination: |error| <= 3.02 (S - 1) 2^-53 sum_k |z_k b_k|, below the K 2^-53 sum |z b| of an fp64
+  // chain for K >= 128.  The verdict is formed ON THE DEVICE (round 5: for every n, not only n <= 2) as a class -- class 0: exact with the digits of the
+  // cheapest tile count, class 1: exact with one more tile of digits, class 2: not exact -- and the chains of both classes plus the fp64 kernel behind
+  // them are all enqueued, each testing one flag word: NO product waits for the host (rounds 3-4 read three integers back for 3 <= n <= 6 and peeled
+  // columns).  Digits per column by n: what fits the tiles of 32 expanded columns -- n = 1: 32; 2: 16; 3: 10 | 21; 4: 16 | 24; 5: 12 | 19; 6: 10 | 16.
+  // Single-orientation object, 'N': the plain int8 kernel needs the individual-major copy; k_gemm_i8_tn multiplies from the SNP-major one, one pass per
+  // tile of 32 expanded columns; a class whose passes would cost more than the fp64 MFMA tile is not offered (gemm_i8_reserve returns 2).
   const bool no_plain = h->single && !trans;
   const PackedMatrix *G_tn_single = no_plain ? &gemm_operand(h, trans, true) : nullptr;
-  // columns [c0, c0 + nc) of this product through the exact int8 route with per-call digits: 0 done, 2 declined (not exact within 24 digits), 1 error
+  const bool small_ok = (engine == 0 || engine == 2 || (engine == 4 && n <= 2)) && k >= 128;
+  // columns [c0, c0 + nc), nc <= 6.  0: enqueued (int8 chains + fp64 kernel: the columns are done whatever the verdict), 2: not applicable, 1: error
+  auto guarded_small = [&](int c0, int nc, const PackedMatrix *G_tn, hipEvent_t e0, hipEvent_t e1, int *splits_out, const int **flag_ptr) -> int {
+    static const int S0_of[7] = {0, 32, 16, 10, 16, 12, 10}, S1_of[7] = {0, 0, 0, 21, 24, 19, 16};
+    I8Chain ch; ch.S0 = S0_of[nc]; ch.S1 = S1_of[nc];
+    const int r0 = gemm_i8_reserve(G, nc, ch.S0, G_tn, w, s);
+    if (r0) return r0;
+    if (ch.S1) {
+      const int r1 = gemm_i8_reserve(G, nc, ch.S1, G_tn, w, s);
+      if (r1 == 1) return 1;
+      if (r1 == 2) ch.S1 = 0;   // the larger class is not offered (transposed form: more passes than the fp64 kernel is worth)
+    }
+    const double *dBc = dB + (size_t)c0 * ldb;
+    double *dCc = dC + (size_t)c0 * ldc;
+    const int *d_flag = nullptr;
+    for (int cls = 0; cls < (ch.S1 ? 2 : 1); cls++) {
+      ch.my_class = cls; ch.first = cls == 0;
+      const int rc = gemm_i8_device(G, trans, nc, dBc, ldb, dCc, ldc, fill_rows, centered, d_sumB + c0, d_sumfB + c0, h->d_f, w, s, cls == 0 ? e0 : nullptr, cls == 0 ? e1 : nullptr,
+                                    cls == 0 ? splits_out : nullptr, 2, &d_flag, w.d_colpart, 0, G_tn, nullptr, &ch);
+      if (rc != 3) return 1;
+    }
+    // class 2: plain fp64 chains, one thread per output row (k_small_n_fp64); from the stored copy whose rows are the output rows, or (single-orientation 'N') the K index
+    if (launch_small_n_fp64(G_tn ? *G_tn : G, G_tn != nullptr, m, k, nc, dBc, ldb, dCc, ldc, fill_rows, trans, centered, d_sumB + c0, d_sumfB + c0, h->d_f, d_flag, s)) return 1;
+    if (flag_ptr) *flag_ptr = d_flag;
+    return 0;
+  };
+  if (small_ok && n <= kSmallNMaxColsHost && !(engine == 2 && n <= 4)) {   // (engine 2: the unguarded slicing for n <= 4 below)
+    const char *e_tn = getenv("MXA_I8_TN");   // A/B (read per call): n <= 2 from the copy whose rows are the K index
+    const bool tn_ab = e_tn && atoi(e_tn) != 0;
+    const PackedMatrix *G_tn = no_plain ? G_tn_single : (tn_ab && n <= 2) ? &gemm_operand(h, trans, true) : nullptr;
+    int splits8 = 1;
+    const int *d_flag = nullptr;
+    const int rcx = guarded_small(0, n, G_tn, pe0, pe1, &splits8, &d_flag);
+    if (rcx == 1) return 1;
+    if (rcx == 0) {
+      MXA_HIP(hipMemsetAsync(w.d_denflag, 0, sizeof(int), s));   // mxa_last_range_fallback: this product does not use the denormal-operand mode
+      std::lock_guard<std::mutex> lk(g_prof_mutex);
+      Geometry &geo = last_geometry();
+      geo.m = m; geo.k = k; geo.n = n; geo.splits = splits8; geo.a = 0; geo.c = 0; geo.path = 4; geo.d_flag = d_flag; geo.flag_dev = h->device;
+      h->prof_pending[slot] = prof;
+      return 0;
+    }
+  }
+  if (centered && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
+  // Engine 4 (i8-exact, opt-in): the same exact slicing for EVERY n with the digit count chosen PER CALL from the measured exponent span of B's columns --
+  // S = max(7, ceil((span + 55) / 8)) <= 24 -- by the host: three integers are read back (ONE host synchronisation per call, documented with the engine).
   auto exact_adaptive = [&](int c0, int nc, hipEvent_t e0, hipEvent_t e1, int *splits_out, int *digits_out) -> int {
     int hs[3] = {0, 0, 1};
     const double *dBc = dB + (size_t)c0 * ldb;
@@ -622,12 +660,12 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
                                   nullptr, nullptr, S, G_tn_single, w.d_colpart);
     return rc == 2 ? 2 : rc ? 1 : 0;
   };
-  if ((engine == 4 || ((engine == 0 || (engine == 2 && n > 4)) && n <= auto_exact_max_n)) && n >= 3 && k >= 128) {   // engine 2 = engine 0 for n > 4
+  if (engine == 4 && k >= 128) {
     int splits8 = 1, S = 0;
-    const int rcx = exact_adaptive(0, n, pe0, pe1, &splits8, &S);
+    const int rcx = n <= 2 ? 2 : exact_adaptive(0, n, pe0, pe1, &splits8, &S);
     if (rcx == 1) return 1;
     if (rcx == 0) {
-      MXA_HIP(hipMemsetAsync(w.d_denflag, 0, sizeof(int), s));   // mxa_last_range_fallback: this product does not use the denormal-operand mode
+      MXA_HIP(hipMemsetAsync(w.d_denflag, 0, sizeof(int), s));
       std::lock_guard<std::mutex> lk(g_prof_mutex);
       Geometry &geo = last_geometry();
       geo.m = m; geo.k = k; geo.n = n; geo.splits = splits8; geo.a = S; geo.c = 0; geo.path = 2; geo.d_flag = nullptr; geo.flag_dev = h->device;
@@ -635,59 +673,28 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
       return 0;
     }
   }
-  if (engine == 1 || (engine == 2 && n <= 4) || auto_i8) {   // exact int8 slicing of B on the int8 matrix cores (mxa_gemm_i8.hip)
+  if (engine == 1 || (engine == 2 && n <= 4)) {   // opt-in: the int8 slicing without the exactness check (7 digits; 32 / 16 for n = 1 / 2)
     int splits8 = 1;
-    const int *d_flag = nullptr;
-    // auto_i8: the verdict of the exactness check stays on the device (guard = 2) -- the int8 chain and the fp64 fallback are both enqueued and
-    // test the flag themselves, so the product has no host round trip in its middle (44 us of a 1.2 ms product in the kernel timeline)
-    // MXA_I8_TN=1 (round 4, A/B of single-orientation storage for the CG step): n <= 2 from the copy whose rows are the K index (k_gemm_i8_tn)
-    const char *e_tn = getenv("MXA_I8_TN");
-    const PackedMatrix *G_tn = no_plain ? G_tn_single : (auto_i8 && e_tn && atoi(e_tn) != 0) ? &gemm_operand(h, trans, true) : nullptr;
-    const int rc8 = gemm_i8_device(G, trans, n, dB, ldb, dC, ldc, fill_rows, centered, d_sumB, d_sumfB, h->d_f, w, s, pe0, pe1,
-                                   &splits8, auto_i8 ? 2 : 0, &d_flag, auto_i8 ? w.d_colpart : nullptr, 0, G_tn);
-    if (rc8 == 0 || rc8 == 3) {
-      if (rc8 == 3 && !no_plain) {   // fp64 pair tables, run only if the flag is set
-        const GemmPlan pl = plan_lut(m, G.k_pad, n);
-        if (ensure_partials(w, pl, s)) return 1;
-        if (launch_lut(G, dB, ldb, n, w.d_P, pl, s, d_flag)) return 1;
-        if (launch_finish(w.d_P, pl, m, n, dC, ldc, fill_rows, trans ? 1 : 0, centered, d_sumB, d_sumfB, h->d_f, s, nullptr, 0, 0, d_flag)) return 1;
-      } else if (rc8 == 3) {   // single-orientation 'N': the fp64 fallback is the narrow MFMA tile in its transposed form with plain operands, gated by the same flag
-        const GemmPlan pf = plan_gemm(m, G.k_pad, n);
-        if (ensure_partials(w, pf, s)) return 1;
-        if (launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, pf.n_pad, pf.c, s, nullptr, 0, -1, d_flag)) return 1;
-        if (launch_gemm(h->snp_major, w.d_Bp, w.d_P, pf, 0, s, next_ctr(w), 0, -1, d_flag, true)) return 1;
-        if (launch_finish(w.d_P, pf, m, n, dC, ldc, fill_rows, 0, centered, d_sumB, d_sumfB, h->d_f, s, nullptr, 0, 0, d_flag)) return 1;
-      }
+    const int rc8 = gemm_i8_device(G, trans, n, dB, ldb, dC, ldc, fill_rows, centered, d_sumB, d_sumfB, h->d_f, w, s, pe0, pe1, &splits8, 0, nullptr, nullptr, 0, G_tn_single);
+    if (rc8 == 0) {
       std::lock_guard<std::mutex> lk(g_prof_mutex);
       Geometry &geo = last_geometry();
-      geo.m = m; geo.k = k; geo.n = n; geo.splits = splits8; geo.a = 0; geo.c = 0; geo.path = rc8 == 3 ? 4 : 2; geo.d_flag = d_flag; geo.flag_dev = h->device;
+      geo.m = m; geo.k = k; geo.n = n; geo.splits = splits8; geo.a = 0; geo.c = 0; geo.path = 2; geo.d_flag = nullptr; geo.flag_dev = h->device;
       h->prof_pending[slot] = prof;
       return 0;
     }
-    if (rc8 != 2) return 1;   // 2: the host-checked guard declined (B not exactly representable): fp64 path below
+    if (rc8 != 2) return 1;   // 2: the transposed-operand form declined (single-orientation 'N' at wide n): fp64 path below
   }
-  // Column peel (engine 0, n = 4q + 1 or 4q + 2, q >= 1): the MFMA tile works on groups of 4 columns, so 10 columns cost 12 (the
-  // reference harness's default n = 10: 0.71 of the peak).  The 1-2 odd columns go through the same guarded EXACT int8 route as n <= 2 --
-  // one HBM-bound pass over the packed matrix, 2.4x cheaper than a fourth-full MFMA group -- and the multiple of 4 runs on the fp64
-  // MFMA without padding.  If the guard declines, all n columns take the MFMA path as before.
-  static const bool peel_on = [] { const char *e = getenv("MXA_PEEL"); return !e || atoi(e) != 0; }();
+  // Column peel (engine 0, n = 4q + r > 6, r = 1, 2, 3): the MFMA tile works on groups of 4 columns, so 10 columns would cost 12 (the reference harness's
+  // default n = 10).  The r odd columns go through the guarded route above -- one HBM-bound pass over the packed matrix -- and the multiple of 4 runs on the
+  // fp64 MFMA without padding.
   const int n_odd = n & 3;
-  if (peel_on && (engine == 0 || engine == 2) && n > 4 && (n_odd == 1 || n_odd == 2) && k >= 128) {   // engine 2 = engine 0 for n > 4
-    const int n4 = n - n_odd;
-    const int rc8 = gemm_i8_device(G, trans, n_odd, dB + (size_t)n4 * ldb, ldb, dC + (size_t)n4 * ldc, ldc, fill_rows, centered, d_sumB + n4, d_sumfB + n4, h->d_f, w, s,
-                                   nullptr, nullptr, nullptr, true, nullptr, nullptr, 0, G_tn_single);
-    if (rc8 == 0) n = n4;            // the rest of this function multiplies the first n4 columns
-    else if (rc8 != 2) return 1;
+  if (small_ok && n > kSmallNMaxColsHost && n_odd != 0) {
+    const int rcp = guarded_small(n - n_odd, n_odd, G_tn_single, nullptr, nullptr, nullptr, nullptr);
+    if (rcp == 1) return 1;
+    if (rcp == 0) n -= n_odd;            // the rest of this function multiplies the first 4q columns
   }
-  // n = 4q + 3, q >= 1 (round 3): the three odd columns through the exact route with per-call digits (1.2 ms on 500k x 50k) instead of a
-  // quarter-full MFMA group (2.7-2.9 ms)
-  if (peel_on && (engine == 0 || engine == 2) && n > 6 && n_odd == 3 && k >= 128 && auto_exact_max_n >= 3) {
-    const int rcx = exact_adaptive(n - 3, 3, nullptr, nullptr, nullptr, nullptr);
-    if (rcx == 1) return 1;
-    if (rcx == 0) n -= 3;
-  }
-  static const int lut_max_n = [] { const char *e = getenv("MXA_LUT_MAX_N"); return e ? atoi(e) : 2; }();
-  const bool use_lut = n <= lut_max_n && n <= 4 && !no_plain;
+  const bool use_lut = n <= 2 && !no_plain;   // fp64 pair tables: engine f64-strict, and K < 128
   GemmPlan p = use_lut ? plan_lut(m, G.k_pad, n) : plan_gemm(m, G.k_pad, n);
   // K splits per launch group: all of them unless their partial sums exceed the budget (partial_budget)
   int splits_per_group = p.splits;
@@ -780,13 +787,9 @@ static int pipe_setup(Handle *h) {
 // returns 0 done, 1 error, 2 not applicable (caller takes the plain path)
 static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, long ldb, bool b_host, bool b_local, double *C, long ldc, bool c_host, bool c_local,
                                long fill_rows) {
-  static const bool enabled = [] { const char *e = getenv("MXA_HOST_PIPELINE"); return !e || atoi(e) != 0; }();
   const int engine = g_engine.load();
-  if (!enabled || (engine != 0 && engine != 3) || n < 3 || getenv("MXA_DIAG")) return 2;
-  {   // engine 0 sends 3 <= n <= 6 through the exact int8 route of gemm_device (plain upload; B is at most 6 columns)
-    static const int auto_exact_max_n = [] { const char *e = getenv("MXA_AUTO_EXACT_MAX_N"); return e ? atoi(e) : 6; }();
-    if (engine == 0 && n <= auto_exact_max_n) return 2;
-  }
+  if ((engine != 0 && engine != 3) || n < 3 || getenv("MXA_DIAG")) return 2;
+  if (engine == 0 && n <= kSmallNMaxColsHost) return 2;   // engine 0 sends n <= 6 through the guarded int8 route of gemm_device (plain upload; B is at most 6 columns)
   const PackedMatrix &G = trans ? h->snp_major : h->ind_major;
   const long m = G.rows, k = G.k;
   // b_host / c_host: the operand is not memory of this device -- host memory (PCIe) or memory of another GPU (peer copies over xGMI):
@@ -818,10 +821,9 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
   if (!c_local) { if (grow(&w.d_Cstage, &w.cap_Cstage, (size_t)fill_rows * n)) return 1; dC = w.d_Cstage; dldc = fill_rows; }
   // column peel as in gemm_device: the 1-2 odd columns go first (their part of B is uploaded ahead of the pipeline) through the guarded
   // exact int8 route; the K-range / row-range pipeline then multiplies the multiple of 4
-  static const bool peel_on = [] { const char *e = getenv("MXA_PEEL"); return !e || atoi(e) != 0; }();
   const int n_all = n, n_odd = n & 3;
   bool b_uploaded = false;
-  if (peel_on && engine == 0 && n > 4 && (n_odd == 1 || n_odd == 2) && k >= 128 && !(h->single && !trans)) {
+  if (engine == 0 && n > 4 && (n_odd == 1 || n_odd == 2) && k >= 128 && !(h->single && !trans)) {
     const int n4 = n - n_odd;
     if (!b_local) {
       if (kmode) MXA_HIP(copy_columns(w.d_Bstage + (size_t)n4 * k, sizeof(double) * k, B + (size_t)n4 * ldb, sizeof(double) * ldb, sizeof(double) * k, n_odd, s));
@@ -1286,7 +1288,7 @@ int mxa_last_path(void) {
   (void)hipGetDevice(&prev);
   if (hipSetDevice(g.flag_dev) != hipSuccess || hipMemcpy(&flag, g.d_flag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); flag = 0; }
   (void)hipSetDevice(prev);
-  return flag ? 1 : 2;
+  return flag ? 3 : 2;
 }
 int mxa_last_range_fallback(void *compressed) {
   if (!compressed || is_multi(compressed)) return -1;

@@ -123,40 +123,55 @@ __global__ void __launch_bounds__(256) k_colstats_partial(const double *__restri
   }
 }
 
-// fused-final mode of k_slice_B (guarded n <= 2 route): every block derives the column exponents and the verdict of the exactness guard from
-// the partials of k_colstats_partial itself (same data, same order: same answer in every block); block 0 also publishes them -- E, the flag,
-// and the column sums of the centring term -- for the kernels behind it.  The flag is WRITTEN (0 / 1), so nobody has to clear it first.
+// fused-final mode of k_slice_B (the guarded routes of n <= 6 and of peeled columns): every block derives the column exponents and the verdict of the
+// exactness guard from the partials of k_colstats_partial itself (same data, same order: same answer in every block).  Round 5: the verdict is a CLASS,
+// decided on the device so that no product waits for the host --
+//   class 0: every column is represented exactly by S0 digits (the cheapest tile count for this n),  class 1: by S1 digits (one more tile; S1 = 0: no such
+//   class),  class 2: neither (or a non-finite entry, or the recombination would leave the normal range): the fp64 kernel behind does the product.
+// The chain of class c (this launch: my_class, my digits S) runs iff the class is c.  The publishing launch (the first chain's) writes for the kernels
+// behind it: E, the column sums of the centring term, and three words  flags[0] = (class == 2), flags[1] = (class != 0), flags[2] = (class != 1)  -- so every
+// later kernel keeps its one-word test (skip_if_set / run_if_set).  The words are WRITTEN, nobody has to clear them first.
 struct SliceFused {
   const double *part; const double *sums;     // part == nullptr: legacy mode (E and the flag come from launch_colexp)
-  int *E_out; int *flag_out; double *sumB, *sumfB;
-  int bias, max_span, min_emax, want_sums;
+  int *E_out; int *flags_out; double *sumB, *sumfB;
+  int bias, S0, S1, my_class, publish, want_sums;
 };
+constexpr int kSmallNMaxCols = 6;             // columns of a guarded small-n chain
 
 // tn_map (k_gemm_i8_tn): K-step T covers 32 consecutive K indices, byte 4q+i of lane (h, col) = digit of B[32 T + 16 h + 4 i + q]
 __global__ void __launch_bounds__(256) k_slice_B(const double *__restrict__ B, long ldb, long k, int n, const int *__restrict__ E, int S, int nc, int NT,
                                                  long T_total, int ncols, uint32_t *__restrict__ Bs, long total, const int *__restrict__ skip_if_set,
                                                  SliceFused fu, int tn_map) {
-  __shared__ int sE[2], sflag;
-  if (fu.part) {   // n <= 2
+  __shared__ int sE[kSmallNMaxCols], sflag;
+  if (fu.part) {   // guarded small-n chain (n <= kSmallNMaxCols)
     if (threadIdx.x < 64) {
-      int bad = 0;
+      int bad0 = 0, bad1 = 0;
       for (int j = 0; j < n; j++) {
         double m = fu.part[(size_t)j * 64 + threadIdx.x], lo = fu.part[((size_t)n + j) * 64 + threadIdx.x];
         double s1 = fu.want_sums ? fu.sums[((size_t)j * 64 + threadIdx.x) * 2] : 0.0, s2 = fu.want_sums ? fu.sums[((size_t)j * 64 + threadIdx.x) * 2 + 1] : 0.0;
         for (int o = 32; o > 0; o >>= 1) { m = fmax(m, __shfl_xor(m, o)); lo = fmin(lo, __shfl_xor(lo, o)); }
-        if (fu.want_sums && blockIdx.x == 0) {   // chunk sums in ascending chunk order, like k_colsum_final
+        if (fu.want_sums && fu.publish && blockIdx.x == 0) {   // chunk sums in ascending chunk order, like k_colsum_final
           double t1 = 0.0, t2 = 0.0;
           for (int c = 0; c < 64; c++) { t1 += __shfl(s1, c); t2 += __shfl(s2, c); }
           if (threadIdx.x == 0) { fu.sumB[j] = t1; fu.sumfB[j] = t2; }
         }
         int e = 0;
         if (m > 0.0 && isfinite(m)) (void)frexp(m, &e);
-        bool ok = isfinite(m);
-        if (ok && m > 0.0) { int el = 0; (void)frexp(lo, &el); ok = e >= fu.min_emax && el >= e - fu.max_span; }
-        if (!ok) bad = 1;
-        if (threadIdx.x == 0) { sE[j] = e + fu.bias; if (blockIdx.x == 0) fu.E_out[j] = e + fu.bias; }
+        // exact with S digits iff the span e_max - e_min <= 8 S - 55 and the last digit's weight 2^(e_max + 2 - 8 S) stays normal (e_max >= 8 S - 1023)
+        if (!isfinite(m)) { bad0 = 1; bad1 = 1; }
+        else if (m > 0.0) {
+          int el = 0; (void)frexp(lo, &el);
+          if (!(e >= 8 * fu.S0 - 1023 && el >= e - (8 * fu.S0 - 55))) bad0 = 1;
+          if (!(fu.S1 > 0 && e >= 8 * fu.S1 - 1023 && el >= e - (8 * fu.S1 - 55))) bad1 = 1;
+        }
+        if (threadIdx.x == 0) { sE[j] = e + fu.bias; if (fu.publish && blockIdx.x == 0) fu.E_out[j] = e + fu.bias; }
       }
-      if (threadIdx.x == 0) { sflag = bad; if (blockIdx.x == 0) *fu.flag_out = bad; }
+      if (fu.S1 <= 0) bad1 = 1;
+      if (threadIdx.x == 0) {
+        const int cls = !bad0 ? 0 : !bad1 ? 1 : 2;
+        sflag = cls != fu.my_class;
+        if (fu.publish && blockIdx.x == 0) { fu.flags_out[0] = cls == 2; fu.flags_out[1] = cls != 0; fu.flags_out[2] = cls != 1; }
+      }
     }
     __syncthreads();
     if (sflag) return;
@@ -281,11 +296,7 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
   auto issue = [&](int stage, int buf) {   // stage index relative to st0
     const uint32_t base = lds0 + buf * Cfg::kBufBytes;
     const char *asrc = A_u + (size_t)(st0 + stage) * kTileBytes;
-#if defined(MXA_I8_EXP_CHEAPB)   // experiment (wrong results): every stage loads the digits of stage 0 -- what the digit slabs' trips to L2 cost
-    const char *bsrc = B_u + (size_t)(st0 + (stage & 1)) * ((size_t)4 * NT * 1024);
-#else
     const char *bsrc = B_u + (size_t)(st0 + stage) * ((size_t)4 * NT * 1024);
-#endif
 #pragma unroll
     for (int i = 0; i < (Cfg::kUnits + kI8Waves - 1) / kI8Waves; i++) {
       const int u = wave + i * kI8Waves;
@@ -359,12 +370,8 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
           if (b >= lo && b < hi) bf_nxt[b] = *reinterpret_cast<const v4i *>(bsrc + b * 1024);
 #pragma unroll
         for (int b = 0; b < NTW; b++)
-#if defined(MXA_I8_EXP_NOMFMA)   // experiment (wrong results): the operands are formed, the matrix cores stay idle -- is the stream slowed by the arithmetic?
-          { acc[a][b][0] += af_cur[0] ^ bf_cur[b][0]; acc[a][b][1] += af_cur[1] ^ bf_cur[b][1]; acc[a][b][2] += af_cur[2] ^ bf_cur[b][2]; acc[a][b][3] += af_cur[3] ^ bf_cur[b][3]; }
-#else
           acc[a][b] = kSwap ? __builtin_amdgcn_mfma_i32_32x32x32_i8(bf_cur[b], af_cur, acc[a][b], 0, 0, 0)
                             : __builtin_amdgcn_mfma_i32_32x32x32_i8(af_cur, bf_cur[b], acc[a][b], 0, 0, 0);
-#endif
         SchedIter<0, NTW, (NTW + MT - 1) / MT>::run();
         __builtin_amdgcn_sched_barrier(0);
         af_cur = af_nxt;
@@ -530,10 +537,6 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
     __syncthreads();                                         // ... for every wave; and everybody is done with stage s - 1, whose buffer is refilled now
     if (s + 2 < stages) issue(s + 2, (s + 2) % kTnBufs);
     const char *bufp = smem + (s % kTnBufs) * Cfg::kBufBytes;
-#if defined(MXA_I8_TN_EXP_NOCOMPUTE)   // experiment (wrong results): DMA ring and barriers only -- what the workgroup structure alone delivers
-    if (lane == 0 && bufp[0] == 77) acc[0][0] += 1;
-    continue;
-#endif
 #pragma unroll
     for (int kk = 0; kk < 2; kk++) {
       const int T = 2 * w4 + kk;                             // K-step of this wave inside the row block
@@ -825,12 +828,90 @@ __global__ void __launch_bounds__(256) k_finish_i8_small(const int *__restrict__
   }
 }
 
+// ---- fp64 kernel BEHIND the guarded chains (round 5): runs iff the exactness verdict is class 2 (run_if_set), one launch, no partial sums, no finish.
+// One thread per output row owns its dot products over the whole K range in ascending k -- a plain fp64 FMA chain, the arithmetic of the reference
+// (src/cuda/dgemm_compressed_cuda.h:259-266), deterministic, |error| <= K 2^-53 sum |z b|.  It replaces the gated launch pairs / triples that stood here
+// (k_lut + k_finish; k_pack_B + k_gemm<MODE 0> + k_finish): the verdict almost never asks for it, and an early-out launch costs ~5 us each on a 1 ms product.
+// Plain form (TN = false): thread <-> packed row, 32 bytes per slab of 128 genotypes; the entries of B are wave-uniform (scalar loads).
+// Transposed-operand form (TN = true): thread <-> individual (a packed column), one byte per packed row; K runs over the rows.
+// NC <= 6 columns.  Not fast (a few ms on the config-5 shard) and not meant to be.
+template <int NC, bool TN>
+__global__ void __launch_bounds__(256) k_small_n_fp64(const uint8_t *__restrict__ G, long nslabs, long m, long k, const double *__restrict__ B, long ldb, int n,
+                                                      double *__restrict__ C, long ldc, long fill_rows, int mode_trans, int centered, const double *__restrict__ sumB,
+                                                      const double *__restrict__ sumfB, const double *__restrict__ f, const int *__restrict__ run_if_set) {
+  if (run_if_set && *run_if_set == 0) return;
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= fill_rows) return;
+  double v[NC];
+#pragma unroll
+  for (int j = 0; j < NC; j++) v[j] = 0.0;
+  if (r < m) {
+    if (!TN) {
+      const uint8_t *row = G + (size_t)(r / kTileRows) * nslabs * kTileBytes + (size_t)(r % kTileRows) * kSlabBytes;
+      for (long sl = 0; sl * kSlabK < k; sl++) {
+        const uint4 w0 = *reinterpret_cast<const uint4 *>(row + (size_t)sl * kTileBytes), w1 = *reinterpret_cast<const uint4 *>(row + (size_t)sl * kTileBytes + 16);
+        const uint32_t wd[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+          const long k0 = sl * kSlabK + 16 * d;
+          if (k0 >= k) break;
+#pragma unroll
+          for (int e = 0; e < 16; e++) {
+            const long kk = k0 + e;
+            if (kk < k) {
+              const double z = (double)((wd[d] >> (2 * e)) & 3u);
+#pragma unroll
+              for (int j = 0; j < NC; j++) if (j < n) v[j] = fma(z, B[kk + (long)j * ldb], v[j]);
+            }
+          }
+        }
+      }
+    } else {
+      // packed matrix rows = K; this thread's individual r: byte (r % 128) / 4 of slab r / 128, field r % 4
+      const uint8_t *col = G + (size_t)(r / kSlabK) * kTileBytes + (size_t)(r % kSlabK) / 4;
+      const int sh = 2 * (int)(r & 3);
+      for (long t = 0; t * kTileRows < k; t++) {
+        const uint8_t *tile = col + (size_t)t * nslabs * kTileBytes;
+        const long rows = k - t * kTileRows < kTileRows ? k - t * kTileRows : kTileRows;
+#pragma unroll 8
+        for (long q = 0; q < rows; q++) {
+          const double z = (double)((tile[q * kSlabBytes] >> sh) & 3u);
+          const long kk = t * kTileRows + q;
+#pragma unroll
+          for (int j = 0; j < NC; j++) if (j < n) v[j] = fma(z, B[kk + (long)j * ldb], v[j]);
+        }
+      }
+    }
+    if (centered) {
+#pragma unroll
+      for (int j = 0; j < NC; j++) if (j < n) v[j] = mode_trans ? fma(-2.0 * sumB[j], f[r], v[j]) : v[j] + -2.0 * sumfB[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NC; j++) if (j < n) C[r + (long)j * ldc] = v[j];   // rows [m, fill_rows): zeros
+}
+
+int launch_small_n_fp64(const PackedMatrix &G, bool tn, long m, long k, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool trans, bool centered,
+                        const double *d_sumB, const double *d_sumfB, const double *d_f, const int *run_if_set, hipStream_t s) {
+  if (n < 1 || n > kSmallNMaxCols) { set_error(4, "internal: small-n fp64 kernel with %d columns", n); return 1; }
+  if (tn ? (G.k < m || G.rows < k) : (G.rows < m || G.k < k)) { set_error(4, "internal: small-n fp64 kernel: operand shape"); return 1; }
+  const dim3 grid((unsigned)((fill_rows + 255) / 256));
+#define MXA_SN(NC_)                                                                                                                                              \
+  if (tn) hipLaunchKernelGGL((k_small_n_fp64<NC_, true>), grid, dim3(256), 0, s, G.d, G.nslabs, m, k, dB, ldb, n, dC, ldc, fill_rows, trans ? 1 : 0, centered ? 1 : 0, \
+                             d_sumB, d_sumfB, d_f, run_if_set);                                                                                                  \
+  else hipLaunchKernelGGL((k_small_n_fp64<NC_, false>), grid, dim3(256), 0, s, G.d, G.nslabs, m, k, dB, ldb, n, dC, ldc, fill_rows, trans ? 1 : 0, centered ? 1 : 0,   \
+                          d_sumB, d_sumfB, d_f, run_if_set);
+  if (n <= 2) { MXA_SN(2) } else if (n <= 4) { MXA_SN(4) } else { MXA_SN(6) }
+#undef MXA_SN
+  MXA_HIP(hipGetLastError());
+  return 0;
+}
+
 struct I8Plan { int S, nc, nchunks, NT, e_pad, rowblocks, stages_total, stages_per_split, splits, rows_wg; long m_pad, T_total; };
 
 static I8Plan plan_i8(long m, long k_pad, int n, int S_override) {
   I8Plan p{};
-  static const int S_env0 = [] { const char *e = getenv("MXA_I8_SLICES"); return e ? std::min(32, std::max(3, atoi(e))) : 0; }();
-  const int S_env = S_override > 0 ? std::min(32, std::max(3, S_override)) : S_env0;
+  const int S_env = S_override > 0 ? std::min(32, std::max(3, S_override)) : 0;
   int S = S_env ? S_env : 7;                                     // 8 bits per digit: 7 digits = 56 bits below 2^E_j
   // a tile of 32 expanded columns is the unit of work: for n <= 4 the kernel is HBM-bound with one tile, so the digits that fit the
   // tile are free -- n = 1: 32 digits (256 bits: any entry down to 2^-200 of the column maximum keeps its whole mantissa), n = 2: 16
@@ -855,7 +936,6 @@ static I8Plan plan_i8(long m, long k_pad, int n, int S_override) {
   // prologue worth ~6 stages; plus the partial sums, written once and read once by the finish (none when the single split of an n <= 2
   // product finishes inside the kernel).  Fewest splits within 1 % of the best.  Evaluated for whole-tile workgroups (256 rows) and, under
   // MXA_I8_HALF_TILE=1, for half-tile workgroups (128 rows, five-deep rings; the model for those is a guess that the measurement refuted).
-  static const long search = [] { const char *e = getenv("MXA_I8_SPLIT_SEARCH"); return e ? atol(e) : 1L; }();
   auto evaluate = [&](int rows_wg, long *splits_out) {
     const long rowblocks = (m + rows_wg - 1) / rows_wg, m_pad = rowblocks * rows_wg, units = rowblocks * p.nchunks;
     const bool half = rows_wg < kTileRows;
@@ -865,7 +945,7 @@ static I8Plan plan_i8(long m, long k_pad, int n, int S_override) {
     const double prologue = half ? 12.0 : 6.0;
     double best = 1e300;
     long splits = 1;
-    for (long cand = 1; search && cand <= std::min<long>(max_splits, 64); cand++) {
+    for (long cand = 1; cand <= std::min<long>(max_splits, 64); cand++) {
       const long per = (p.stages_total + cand - 1) / cand, actual = (p.stages_total + per - 1) / per;
       if (actual != cand) continue;
       // Whole rounds of the resident slots.  Exception (round 4): ONE split of a product with at least two full rounds of row tiles -- its thinly
@@ -883,18 +963,14 @@ static I8Plan plan_i8(long m, long k_pad, int n, int S_override) {
     *splits_out = splits;
     return best;
   };
-  long splits = 1, splits_half = 1;
+  long splits = 1;
   (void)evaluate(kTileRows, &splits);
   p.rows_wg = kTileRows;
-  if (direct_possible && p.S * p.nc <= 32) {
-    // MEASURED SLOWER, off unless MXA_I8_HALF_TILE=1 (profiles/r04_i8_half_tile_ab.txt): config-5 shard 'N' 1.36 ms without splits against 0.965 with
-    // five, 'T' 1.11 against 0.94 -- the digit slabs then cross L2 -> LDS as 2x the packed bytes and the DMA path, not HBM, sets the pace.
-    const char *e_half = getenv("MXA_I8_HALF_TILE");   // read per call: the tests switch it
-    if (e_half && atoi(e_half) == 1) { (void)evaluate(kTileRows / 2, &splits_half); p.rows_wg = kTileRows / 2; splits = splits_half; }
-  }
+  // (half-tile workgroups -- 128 rows, no K splits, the product finished inside the kernel -- were built in round 4 and removed in round 5: config-5 shard 'N'
+  // 1.36 ms against 0.965 with five splits: the digit slabs then cross L2 -> LDS as 2x the packed bytes and the DMA path sets the pace;
+  // profiles/r04_i8_half_tile_ab.txt)
   p.rowblocks = (int)((m + p.rows_wg - 1) / p.rows_wg);
   p.m_pad = (long)p.rowblocks * p.rows_wg;
-  if (const char *e = getenv("MXA_I8_SPLITS")) splits = std::max<long>(1, std::min<long>(max_splits, atol(e)));   // A/B measurement
   splits = std::max<long>(splits, (p.stages_total + 32767) / 32768);   // int32 accumulators: 2 * 128 * (K per split) < 2^31
   p.stages_per_split = (int)((p.stages_total + splits - 1) / splits);
   p.splits = (p.stages_total + p.stages_per_split - 1) / p.stages_per_split;
@@ -904,27 +980,9 @@ static I8Plan plan_i8(long m, long k_pad, int n, int S_override) {
 template <int NT, int MT, int WC, bool SWAP1 = false>
 static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const I8Plan &p, hipStream_t s, const int *skip_if_set, const I8Direct &dir) {
   using Cfg = I8Cfg<NT, MT * (4 / WC) * 32>;
-  static unsigned long long attr_a = 0, attr_b = 0;   // function attributes are per device
-  if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8<NT, MT, WC, false, SWAP1>), Cfg::kLds, &attr_a) ||
-      ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8<NT, MT, WC, true, SWAP1>), Cfg::kLds, &attr_b)) return 1;
+  static unsigned long long attr_a = 0;   // function attributes are per device
+  if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8<NT, MT, WC, false, SWAP1>), Cfg::kLds, &attr_a)) return 1;
   const long grid = (long)p.rowblocks * p.nchunks * p.splits;
-  static const bool diag_on = getenv("MXA_DIAG") != nullptr;
-  if (diag_on) {   // in-kernel clocks: shader cycles and 100 MHz ticks per workgroup K loop
-    unsigned long long *d_diag = nullptr;
-    MXA_HIP(hipMalloc((void **)&d_diag, sizeof(unsigned long long) * 2 * grid));
-    hipLaunchKernelGGL((k_gemm_i8<NT, MT, WC, true, SWAP1>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBs, p.T_total, dP, p.m_pad, p.e_pad,
-                       p.rowblocks, p.nchunks, p.stages_total, p.stages_per_split, d_diag, skip_if_set, dir);
-    std::vector<unsigned long long> h(2 * grid);
-    MXA_HIP(hipStreamSynchronize(s));
-    MXA_HIP(hipMemcpy(h.data(), d_diag, sizeof(unsigned long long) * 2 * grid, hipMemcpyDeviceToHost));
-    (void)hipFree(d_diag);
-    std::vector<double> ghz, cyc;
-    for (long i = 0; i < grid; i++) if (h[2 * i + 1] > 0) { ghz.push_back((double)h[2 * i] / ((double)h[2 * i + 1] * 10.0)); cyc.push_back((double)h[2 * i] / p.stages_per_split); }
-    std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end());
-    if (!ghz.empty()) printf("MXA_DIAG k_gemm_i8<%d,%d,%d>: %ld workgroups, in-kernel clock median %.3f GHz (min %.3f max %.3f); shader cycles per stage median %.0f (ideal %d)\n",
-                             NT, MT, WC, grid, ghz[ghz.size() / 2], ghz.front(), ghz.back(), cyc[cyc.size() / 2], 4 * 2 * NT * 32);
-    return 0;
-  }
   hipLaunchKernelGGL((k_gemm_i8<NT, MT, WC, false, SWAP1>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBs, p.T_total, dP, p.m_pad, p.e_pad,
                      p.rowblocks, p.nchunks, p.stages_total, p.stages_per_split, (unsigned long long *)nullptr, skip_if_set, dir);
   MXA_HIP(hipGetLastError());
@@ -951,7 +1009,9 @@ static void plan_i8_tn(long indiv_slabs, long snp_rows, int slabs_wg, int *strip
     const double cost = rounds * ((double)per + 35.0) + (double)actual * (double)*strips * slabs_wg * kSlabK * 128.0 / 3.0e6;
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cand; }
   }
-  if (const char *e = getenv("MXA_I8_TN_SPLITS")) best = std::max(1, std::min(*stages_total, atoi(e)));
+  // int32 accumulators: at most 2047 stages (2047 x 256 x 128 x 32 < 2^31) per split, whatever the search found (more than 64 x 2047 row blocks -- 33.5 M
+  // SNPs in one object -- have no candidate above and would otherwise keep best = 1)
+  best = std::max(best, (*stages_total + 2046) / 2047);
   *stages_per_split = (*stages_total + best - 1) / best;
   *splits = (*stages_total + *stages_per_split - 1) / *stages_per_split;
 }
@@ -967,38 +1027,70 @@ static int launch_i8_tn(const PackedMatrix &G_tn, const int8_t *d_Bs, int *d_P, 
   return 0;
 }
 
-int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool centered, double *d_sumB,
-                   double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out, int guard,
-                   const int **flag_out, double *colsum_scratch, int S_override, const PackedMatrix *G_tn, double *stats_part) {
+// plan of one product (plain or transposed-operand form) and the bytes of workspace it needs; returns 2 when the transposed form declines
+struct I8Full { I8Plan p; bool tn; int tn_slabs, tn_strips, tn_stages, tn_sps, tn_splits; size_t part_bytes, e_bytes, bs_bytes, p_bytes, need; };
+static int plan_i8_full(const PackedMatrix &G, int n, int S_override, const PackedMatrix *G_tn, I8Full &f) {
   const long m = G.rows, k = G.k;
-  I8Plan p = plan_i8(m, G.k_pad, n, S_override);
+  f.p = plan_i8(m, G.k_pad, n, S_override);
+  I8Plan &p = f.p;
   if (p.m_pad > G.rows_pad) { set_error(4, "internal: packed matrix smaller than the i8 plan"); return 1; }
   // transposed-operand form (G_tn = the copy whose ROWS are the K index): same digits, same exactness guard, other main kernel and P layout
   // (several tiles of 32 expanded columns: one pass over the matrix per tile -- 3 <= n <= 6 and peeled columns of single-orientation objects; beyond what the
   // fp64 MFMA tile would take, or with several column chunks, the caller's fp64 path is the better choice: declined with 2 before anything is enqueued)
   if (G_tn != nullptr && (p.nchunks != 1 || p.NT > (n <= 4 ? 2 : 5))) return 2;
-  const bool tn = G_tn != nullptr;
-  int tn_strips = 0, tn_stages = 0, tn_sps = 0, tn_splits = 0;
-  const char *e_slabs = getenv("MXA_I8_TN_SLABS");             // strip width of the transposed kernel: 2 (256 individuals, two workgroups per CU) or 4 (512, one)
-  const int tn_slabs = e_slabs && atoi(e_slabs) == 4 ? 4 : 2;
-  if (tn) {
+  f.tn = G_tn != nullptr;
+  f.tn_slabs = 2; f.tn_strips = f.tn_stages = f.tn_sps = f.tn_splits = 0;
+  if (f.tn) {
     if (G_tn->k != m || G_tn->rows != k) { set_error(4, "internal: transposed operand has the wrong shape"); return 1; }
-    plan_i8_tn(G_tn->nslabs, G_tn->rows, tn_slabs, &tn_strips, &tn_stages, &tn_sps, &tn_splits);
-    if ((long)tn_stages * kTileRows > G_tn->rows_pad) { set_error(4, "internal: packed matrix smaller than the transposed i8 plan"); return 1; }
-    p.T_total = (long)tn_stages * 8; p.splits = tn_splits; p.m_pad = (long)tn_strips * tn_slabs * kSlabK; p.e_pad = p.NT * 32;
+    plan_i8_tn(G_tn->nslabs, G_tn->rows, f.tn_slabs, &f.tn_strips, &f.tn_stages, &f.tn_sps, &f.tn_splits);
+    if ((long)f.tn_stages * kTileRows > G_tn->rows_pad) { set_error(4, "internal: packed matrix smaller than the transposed i8 plan"); return 1; }
+    p.T_total = (long)f.tn_stages * 8; p.splits = f.tn_splits; p.m_pad = (long)f.tn_strips * f.tn_slabs * kSlabK; p.e_pad = p.NT * 32;
   }
-  if (splits_out) *splits_out = p.splits;
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
-  const size_t part_bytes = up(sizeof(double) * 128 * n), e_bytes = up(sizeof(int) * (n + 1));   // column maxima + minima; exponents + the guard flag
-  const size_t bs_bytes = up((size_t)p.nchunks * p.T_total * p.NT * 1024);
-  const size_t p_bytes = up(sizeof(int) * (size_t)p.splits * p.m_pad * p.e_pad);
-  const size_t need = part_bytes + e_bytes + bs_bytes + p_bytes;
-  if (w.cap_i8 < need) {
-    MXA_HIP(hipStreamSynchronize(s));
-    if (w.d_i8) { MXA_HIP(hipFree(w.d_i8)); w.d_i8 = nullptr; w.cap_i8 = 0; }
-    MXA_HIP(hipMalloc(&w.d_i8, need));
-    w.cap_i8 = need;
+  f.part_bytes = up(sizeof(double) * 128 * n); f.e_bytes = up(sizeof(int) * (n + 1));   // column maxima + minima; exponents
+  f.bs_bytes = up((size_t)p.nchunks * p.T_total * p.NT * 1024);
+  f.p_bytes = up(sizeof(int) * (size_t)p.splits * p.m_pad * p.e_pad);
+  f.need = f.part_bytes + f.e_bytes + f.bs_bytes + f.p_bytes;
+  return 0;
+}
+static int i8_grow(Workspace &w, size_t need, hipStream_t s) {
+  if (w.cap_i8 >= need) return 0;
+  MXA_HIP(hipStreamSynchronize(s));
+  if (w.d_i8) { MXA_HIP(hipFree(w.d_i8)); w.d_i8 = nullptr; w.cap_i8 = 0; }
+  MXA_HIP(hipMalloc(&w.d_i8, need));
+  w.cap_i8 = need;
+  return 0;
+}
+// room for the chains of a guarded product BEFORE the first one is enqueued (growing the workspace waits for the stream: once per object and shape)
+int gemm_i8_reserve(const PackedMatrix &G, int n, int S, const PackedMatrix *G_tn, Workspace &w, hipStream_t s) {
+  I8Full f;
+  const int rc = plan_i8_full(G, n, S, G_tn, f);
+  if (rc) return rc;
+  return i8_grow(w, f.need, s);
+}
+
+int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool centered, double *d_sumB,
+                   double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out, int guard,
+                   const int **flag_out, double *colsum_scratch, int S_override, const PackedMatrix *G_tn, double *stats_part, const I8Chain *chain) {
+  const long m = G.rows, k = G.k;
+  I8Chain ch1;
+  if (guard == 2) {   // device-side verdict: this launch sequence is the chain of one class
+    if (!chain) { ch1.S0 = plan_i8(m, G.k_pad, n, S_override).S; ch1.S1 = 0; ch1.my_class = 0; ch1.first = true; chain = &ch1; }
+    if (n > kSmallNMaxCols || !colsum_scratch) { set_error(4, "internal: guarded int8 chain with %d columns", n); return 1; }
+    S_override = chain->my_class ? chain->S1 : chain->S0;
   }
+  I8Full pf;
+  {
+    const int rcp = plan_i8_full(G, n, S_override, G_tn, pf);
+    if (rcp) return rcp;
+  }
+  I8Plan &p = pf.p;
+  const bool tn = pf.tn;
+  const int tn_slabs = pf.tn_slabs, tn_strips = pf.tn_strips, tn_stages = pf.tn_stages, tn_sps = pf.tn_sps, tn_splits = pf.tn_splits;
+  if (splits_out) *splits_out = p.splits;
+  const size_t part_bytes = pf.part_bytes, e_bytes = pf.e_bytes, bs_bytes = pf.bs_bytes;
+  if (chain && !chain->first && w.cap_i8 < pf.need) { set_error(4, "internal: the second chain of a guarded product outgrows the workspace (gemm_i8_reserve)"); return 1; }
+  if (i8_grow(w, pf.need, s)) return 1;
   char *base = static_cast<char *>(w.d_i8);
   double *d_part = (stats_part && !guard) ? stats_part : reinterpret_cast<double *>(base);
   int *d_E = reinterpret_cast<int *>(base + part_bytes);
@@ -1018,19 +1110,18 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
     // i.e. the exponent span e_max - e_min <= 8S - 55; the recombination ldexp(t, E_j - 8(s+1)) stays normal iff e_max + 2 - 8S >= -1021.
     // the flag lives in the handle's small flag block (never reallocated while the handle lives: mxa_last_path() may read it later)
     if (!w.d_denflag) { set_error(4, "internal: flag block missing"); return 1; }
-    int *d_flag = w.d_denflag + 1, h_flag = 1;
-    fused = guard == 2 && colsum_scratch && n <= 2;
-    if (fused) {   // one statistics pass; exponents, verdict and column sums are finished inside k_slice_B
-      hipLaunchKernelGGL(k_colstats_partial, dim3(64, n), dim3(256), 0, s, dB, ldb, k, n, trans ? nullptr : d_f, centered ? 1 : 0, d_part, colsum_scratch);
-      fu = SliceFused{d_part, colsum_scratch, d_E, d_flag, d_sumB, d_sumfB, 2, 8 * p.S - 55, 8 * p.S - 1023, centered ? 1 : 0};
-    } else if (launch_colexp(dB, ldb, k, n, d_part, d_E, 2, s, d_flag, 8 * p.S - 55, 8 * p.S - 1023)) return 1;
-    if (guard == 1) {
+    int *d_flag = w.d_denflag + 1, h_flag = 1;   // three words: (class == 2), (class != 0), (class != 1)   [SliceFused]
+    fused = guard == 2;
+    if (fused) {   // one statistics pass (the first chain's); exponents, verdict and column sums are finished inside k_slice_B
+      if (chain->first) hipLaunchKernelGGL(k_colstats_partial, dim3(64, n), dim3(256), 0, s, dB, ldb, k, n, trans ? nullptr : d_f, centered ? 1 : 0, d_part, colsum_scratch);
+      fu = SliceFused{d_part, colsum_scratch, d_E, d_flag, d_sumB, d_sumfB, 2, chain->S0, chain->S1, chain->my_class, chain->first ? 1 : 0, centered ? 1 : 0};
+      skip = d_flag + 1 + chain->my_class;     // (class != my_class)
+      if (flag_out) *flag_out = d_flag;        // (class == 2): the fp64 kernel behind runs iff it is set
+    } else {
+      if (launch_colexp(dB, ldb, k, n, d_part, d_E, 2, s, d_flag, 8 * p.S - 55, 8 * p.S - 1023)) return 1;
       MXA_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
       MXA_HIP(hipStreamSynchronize(s));
       if (h_flag) return 2;
-    } else {
-      skip = d_flag;
-      if (flag_out) *flag_out = d_flag;
     }
   }
   if (p.NT * 32 != p.nc * p.S) MXA_HIP(hipMemsetAsync(d_Bs, 0, bs_bytes, s));   // expanded columns beyond nc*S are never written
@@ -1044,10 +1135,10 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   if (ev0) MXA_HIP(hipEventRecord(ev0, s));
   int rc = 0;
   const bool small_tile = p.nchunks == 1 && p.NT == 1 && p.nc * p.S <= 32 && (p.nc == 1 || p.nc == 2);   // n <= 2: one tile
-  static const bool direct_on = [] { const char *e = getenv("MXA_I8_DIRECT"); return !e || atoi(e) != 0; }();
   I8Direct dir{};
   if (tn) {
-    if (tn_slabs == 4 ? launch_i8_tn<4>(*G_tn, d_Bs, d_P, p, tn_strips, tn_stages, tn_sps, tn_splits, s, skip) : launch_i8_tn<2>(*G_tn, d_Bs, d_P, p, tn_strips, tn_stages, tn_sps, tn_splits, s, skip)) return 1;
+    (void)tn_slabs;
+    if (launch_i8_tn<2>(*G_tn, d_Bs, d_P, p, tn_strips, tn_stages, tn_sps, tn_splits, s, skip)) return 1;
     if (ev1) MXA_HIP(hipEventRecord(ev1, s));
     dim3 grid((unsigned)((fill_rows + kFinTBlockRows - 1) / kFinTBlockRows), (unsigned)n);
     hipLaunchKernelGGL(k_finish_i8_t, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, d_part, dC, ldc, fill_rows, trans ? 1 : 0,
@@ -1055,13 +1146,12 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
     MXA_HIP(hipGetLastError());
     return guard == 2 ? 3 : 0;
   }
-  if (direct_on && small_tile && p.splits == 1)
+  if (small_tile && p.splits == 1)
     dir = I8Direct{1, d_E, d_part, dC, ldc, m, fill_rows, n, p.S, p.nc, trans ? 1 : 0, centered ? 1 : 0, d_sumB, d_sumfB, d_f};
   // one tile, three or more columns (n = 3; n = 4 with few digits), one chunk: transposed partial sums like the wider launches (k_finish_i8_t)
   const bool swap1 = p.NT == 1 && !small_tile && p.nchunks == 1 && p.rows_wg == kTileRows;
   switch (p.NT) {
-    case 1: rc = swap1 ? launch_i8_t<1, 2, 1, true>(G, d_Bs, d_P, p, s, skip, dir)
-                      : p.rows_wg == kTileRows ? launch_i8_t<1, 2, 1>(G, d_Bs, d_P, p, s, skip, dir) : launch_i8_t<1, 1, 1>(G, d_Bs, d_P, p, s, skip, dir); break;
+    case 1: rc = swap1 ? launch_i8_t<1, 2, 1, true>(G, d_Bs, d_P, p, s, skip, dir) : launch_i8_t<1, 2, 1>(G, d_Bs, d_P, p, s, skip, dir); break;
     case 2: rc = launch_i8_t<2, 2, 1>(G, d_Bs, d_P, p, s, skip, dir); break;
     case 3: rc = launch_i8_t<3, 2, 1>(G, d_Bs, d_P, p, s, skip, dir); break;
     case 4: rc = launch_i8_t<4, 2, 1>(G, d_Bs, d_P, p, s, skip, dir); break;

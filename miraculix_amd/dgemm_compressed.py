@@ -36,8 +36,9 @@ def set_engine(name):
 
 
 def last_path():
-    """kernel family of the most recent product: 'k_gemm' (fp64 MFMA), 'k_lut' (fp64 pair tables) or 'k_gemm_i8' (int8 slicing)"""
-    return {0: "k_gemm", 1: "k_lut", 2: "k_gemm_i8"}[_lib.check_library_handle().mxa_last_path()]
+    """kernel family of the most recent product: 'k_gemm' (fp64 MFMA), 'k_lut' (fp64 pair tables: engine f64-strict, K < 128), 'k_gemm_i8' (exact int8
+    slicing) or 'k_small_n_fp64' (the fp64 chains behind the exactness guard of the int8 route: the device-side verdict declined it)"""
+    return {0: "k_gemm", 1: "k_lut", 2: "k_gemm_i8", 3: "k_small_n_fp64"}[_lib.check_library_handle().mxa_last_path()]
 
 
 def check_dimensions(plink, snps, indiv):

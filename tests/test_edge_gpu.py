@@ -158,7 +158,7 @@ def test_column_span_around_the_denormal_window(mx, decades, expect_fallback):
     long-double oracle either way."""
     from _util import synth_genotypes
     o = Oracle()
-    snps, indiv, n = 1500, 600, 6
+    snps, indiv, n = 1500, 600, 8   # n = 8: the fp64 MFMA path (n <= 6 takes the guarded int8 route, whose fallback is the fp64 chain kernel)
     Z, _ = synth_genotypes(snps, indiv, seed=5)
     Z[:12, :48] = 0          # 'N': individuals 0..11 carry no allele at SNPs 0..47
     Z[:40, :9] = 0           # 'T': SNPs 0..8 are zero in individuals 0..39

@@ -31,17 +31,9 @@ def _product(dg, obj, prob, trans, B, tn):
         os.environ.pop("MXA_I8_TN", None)
 
 
-@pytest.fixture(params=[2, 4])
-def slabs(request):
-    """strip width of k_gemm_i8_tn: 2 slabs (256 individuals, 4 waves, two workgroups per CU: the default) or 4 (512 individuals, 8 waves)"""
-    os.environ["MXA_I8_TN_SLABS"] = str(request.param)
-    yield request.param
-    os.environ.pop("MXA_I8_TN_SLABS", None)
-
-
 @pytest.mark.parametrize("snps,indiv", [(3001, 1037), (2050, 1301), (700, 3001), (5000, 600), (1300, 130)])
 @pytest.mark.parametrize("n", [1, 2])
-def test_transposed_int8_route_matches_plain_and_oracle(mx, snps, indiv, n, slabs):
+def test_transposed_int8_route_matches_plain_and_oracle(mx, snps, indiv, n):
     o = Oracle()
     prob = make_problem(snps, indiv, n, seed=snps + 3 * n, missing_frac=0.03)
     dg = mx.dgemm_compressed
@@ -82,7 +74,7 @@ def test_transposed_int8_route_guard_declines_like_the_plain_one(mx):
         B[0, ::3] *= 1e-80                                       # 265 binades: beyond 8 * 32 - 55
         os.environ["MXA_I8_TN"] = "1"
         C = dg.dgemm_compressed_main(False, obj, np.asfortranarray(B.T), snps, indiv)
-        assert dg.last_path() == "k_lut"
+        assert dg.last_path() == "k_small_n_fp64"
         ref = o.dgemm_dense(0, prob, B, 1)[:, :indiv]
         assert np.abs(C.T - ref).max() <= 1e-11 * np.abs(ref).max()
     finally:

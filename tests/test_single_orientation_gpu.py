@@ -91,7 +91,7 @@ def test_fallbacks_ld_padding_and_gram(mx):
             B = make_B(k, 1, seed=4 + trans)
             B[0, ::3] *= 1e-80                                               # 265 binades: the exactness guard declines
             C = dg.dgemm_compressed_main(bool(trans), obj, np.asfortranarray(B.T), snps, indiv)
-            assert dg.last_path() == "k_lut"                                 # "the fp64 fallback ran" (mxa_last_path reads the device flag)
+            assert dg.last_path() == "k_small_n_fp64"                                 # "the fp64 fallback ran" (mxa_last_path reads the device flag)
             ref = o.dgemm_dense(trans, prob, B, 1)[:, :m]
             err, abssum = np.abs(C.T - ref), o.dgemm_dense(trans, prob, np.abs(B), 0)[:, :m]
             assert np.all(err <= k * 2.0 ** -52 * abssum + 8 * 2.0 ** -53 * np.abs(ref - o.dgemm_dense(trans, prob, B, 0)[:, :m]) + 1e-300)
