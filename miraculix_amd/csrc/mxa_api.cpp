@@ -622,8 +622,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
                                     cls == 0 ? splits_out : nullptr, 2, &d_flag, w.d_colpart, 0, G_tn, nullptr, &ch);
       if (rc != 3) return 1;
     }
-    // class 2: plain fp64 chains, one thread per output row (k_small_n_fp64); from the stored copy whose rows are the output rows, or (single-orientation 'N') the K index
-    if (launch_small_n_fp64(G_tn ? *G_tn : G, G_tn != nullptr, m, k, nc, dBc, ldb, dCc, ldc, fill_rows, trans, centered, d_sumB + c0, d_sumfB + c0, h->d_f, d_flag, s)) return 1;
+    // (class 2: plain fp64 chains, one thread per output row, inside the first chain's k_slice_B launch)
     if (flag_ptr) *flag_ptr = d_flag;
     return 0;
   };
@@ -635,8 +634,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     const int *d_flag = nullptr;
     const int rcx = guarded_small(0, n, G_tn, pe0, pe1, &splits8, &d_flag);
     if (rcx == 1) return 1;
-    if (rcx == 0) {
-      MXA_HIP(hipMemsetAsync(w.d_denflag, 0, sizeof(int), s));   // mxa_last_range_fallback: this product does not use the denormal-operand mode
+    if (rcx == 0) {   // (the range flag of the denormal-operand mode -- mxa_last_range_fallback -- is cleared by the chain's k_slice_B)
       std::lock_guard<std::mutex> lk(g_prof_mutex);
       Geometry &geo = last_geometry();
       geo.m = m; geo.k = k; geo.n = n; geo.splits = splits8; geo.a = 0; geo.c = 0; geo.path = 4; geo.d_flag = d_flag; geo.flag_dev = h->device;

@@ -138,11 +138,75 @@ struct SliceFused {
 };
 constexpr int kSmallNMaxCols = 6;             // columns of a guarded small-n chain
 
+// ---- fp64 chains BEHIND the guarded int8 chains (round 5): when the exactness verdict is class 2 the product is done in plain fp64 -- one thread per
+// output row owns its dot products over the whole K range in ascending k: a plain FMA chain, the arithmetic of the reference
+// (src/cuda/dgemm_compressed_cuda.h:259-266), deterministic, |error| <= K 2^-53 sum |z b|.  The work rides in the launch of k_slice_B (the publishing
+// chain's): its blocks, which would return at once under that verdict, walk the output rows instead -- no launch of its own (the gated launch pairs /
+// triples that stood here -- k_lut + k_finish; k_pack_B + k_gemm<MODE 0> + k_finish -- cost ~5 us each on a 1 ms product whether or not they ran).
+// Plain form (tn = 0): thread <-> packed row, 32 bytes per slab of 128 genotypes; the entries of B are wave-uniform.
+// Transposed-operand form (tn = 1): thread <-> individual (a packed column), one byte per packed row; K runs over the rows.
+// n <= kSmallNMaxCols columns.  Not fast (a few ms on the config-5 shard) and not meant to be.
+struct SmallNFallback {
+  const uint8_t *G;                 // nullptr: no fallback in this launch
+  long nslabs, m, k;
+  double *C; long ldc, fill_rows;
+  int tn, mode_trans, centered;
+  const double *f;
+};
+__device__ __forceinline__ void small_n_fp64_row(const SmallNFallback &a, const double *__restrict__ B, long ldb, int n, long r, const double *sumB, const double *sumfB) {
+  double v[kSmallNMaxCols];
+#pragma unroll
+  for (int j = 0; j < kSmallNMaxCols; j++) v[j] = 0.0;
+  if (r < a.m) {
+    if (!a.tn) {
+      const uint8_t *row = a.G + (size_t)(r / kTileRows) * a.nslabs * kTileBytes + (size_t)(r % kTileRows) * kSlabBytes;
+      for (long sl = 0; sl * kSlabK < a.k; sl++) {
+        const uint4 w0 = *reinterpret_cast<const uint4 *>(row + (size_t)sl * kTileBytes), w1 = *reinterpret_cast<const uint4 *>(row + (size_t)sl * kTileBytes + 16);
+        const uint32_t wd[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+#pragma unroll
+          for (int e = 0; e < 16; e++) {
+            const long kk = sl * kSlabK + 16 * d + e;
+            if (kk < a.k) {
+              const double z = (double)((wd[d] >> (2 * e)) & 3u);
+#pragma unroll
+              for (int j = 0; j < kSmallNMaxCols; j++) if (j < n) v[j] = fma(z, B[kk + (long)j * ldb], v[j]);
+            }
+          }
+        }
+      }
+    } else {
+      // packed matrix rows = K; this thread's individual r: byte (r % 128) / 4 of slab r / 128, field r % 4
+      const uint8_t *col = a.G + (size_t)(r / kSlabK) * kTileBytes + (size_t)(r % kSlabK) / 4;
+      const int sh = 2 * (int)(r & 3);
+      for (long t = 0; t * kTileRows < a.k; t++) {
+        const uint8_t *tile = col + (size_t)t * a.nslabs * kTileBytes;
+        const long rows = a.k - t * kTileRows < kTileRows ? a.k - t * kTileRows : kTileRows;
+#pragma unroll 8
+        for (long q = 0; q < rows; q++) {
+          const double z = (double)((tile[q * kSlabBytes] >> sh) & 3u);
+          const long kk = t * kTileRows + q;
+#pragma unroll
+          for (int j = 0; j < kSmallNMaxCols; j++) if (j < n) v[j] = fma(z, B[kk + (long)j * ldb], v[j]);
+        }
+      }
+    }
+    if (a.centered) {
+#pragma unroll
+      for (int j = 0; j < kSmallNMaxCols; j++) if (j < n) v[j] = a.mode_trans ? fma(-2.0 * sumB[j], a.f[r], v[j]) : v[j] + -2.0 * sumfB[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kSmallNMaxCols; j++) if (j < n) a.C[r + (long)j * a.ldc] = v[j];   // rows [m, fill_rows): zeros
+}
+
 // tn_map (k_gemm_i8_tn): K-step T covers 32 consecutive K indices, byte 4q+i of lane (h, col) = digit of B[32 T + 16 h + 4 i + q]
 __global__ void __launch_bounds__(256) k_slice_B(const double *__restrict__ B, long ldb, long k, int n, const int *__restrict__ E, int S, int nc, int NT,
                                                  long T_total, int ncols, uint32_t *__restrict__ Bs, long total, const int *__restrict__ skip_if_set,
-                                                 SliceFused fu, int tn_map) {
-  __shared__ int sE[kSmallNMaxCols], sflag;
+                                                 SliceFused fu, int tn_map, SmallNFallback fb) {
+  __shared__ int sE[kSmallNMaxCols], sflag, scls;
+  __shared__ double sSum[2][kSmallNMaxCols];
   if (fu.part) {   // guarded small-n chain (n <= kSmallNMaxCols)
     if (threadIdx.x < 64) {
       int bad0 = 0, bad1 = 0;
@@ -150,10 +214,10 @@ __global__ void __launch_bounds__(256) k_slice_B(const double *__restrict__ B, l
         double m = fu.part[(size_t)j * 64 + threadIdx.x], lo = fu.part[((size_t)n + j) * 64 + threadIdx.x];
         double s1 = fu.want_sums ? fu.sums[((size_t)j * 64 + threadIdx.x) * 2] : 0.0, s2 = fu.want_sums ? fu.sums[((size_t)j * 64 + threadIdx.x) * 2 + 1] : 0.0;
         for (int o = 32; o > 0; o >>= 1) { m = fmax(m, __shfl_xor(m, o)); lo = fmin(lo, __shfl_xor(lo, o)); }
-        if (fu.want_sums && fu.publish && blockIdx.x == 0) {   // chunk sums in ascending chunk order, like k_colsum_final
+        if (fu.want_sums && fu.publish) {   // chunk sums in ascending chunk order, like k_colsum_final (every block: the fp64 rows below need them; block 0 publishes)
           double t1 = 0.0, t2 = 0.0;
           for (int c = 0; c < 64; c++) { t1 += __shfl(s1, c); t2 += __shfl(s2, c); }
-          if (threadIdx.x == 0) { fu.sumB[j] = t1; fu.sumfB[j] = t2; }
+          if (threadIdx.x == 0) { sSum[0][j] = t1; sSum[1][j] = t2; if (blockIdx.x == 0) { fu.sumB[j] = t1; fu.sumfB[j] = t2; } }
         }
         int e = 0;
         if (m > 0.0 && isfinite(m)) (void)frexp(m, &e);
@@ -169,12 +233,17 @@ __global__ void __launch_bounds__(256) k_slice_B(const double *__restrict__ B, l
       if (fu.S1 <= 0) bad1 = 1;
       if (threadIdx.x == 0) {
         const int cls = !bad0 ? 0 : !bad1 ? 1 : 2;
-        sflag = cls != fu.my_class;
-        if (fu.publish && blockIdx.x == 0) { fu.flags_out[0] = cls == 2; fu.flags_out[1] = cls != 0; fu.flags_out[2] = cls != 1; }
+        sflag = cls != fu.my_class; scls = cls;
+        // flags_out[-1] is the range flag of the denormal-operand mode (mxa_last_range_fallback): this product does not use that mode
+        if (fu.publish && blockIdx.x == 0) { fu.flags_out[-1] = 0; fu.flags_out[0] = cls == 2; fu.flags_out[1] = cls != 0; fu.flags_out[2] = cls != 1; }
       }
     }
     __syncthreads();
-    if (sflag) return;
+    if (sflag) {
+      if (fu.publish && scls == 2 && fb.G)   // not exact in any class: the fp64 chains, one thread per output row
+        for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < fb.fill_rows; r += (long)gridDim.x * blockDim.x) small_n_fp64_row(fb, B, ldb, n, r, sSum[0], sSum[1]);
+      return;
+    }
     E = sE;
   } else if (skip_if_set && *skip_if_set) return;   // guarded route: B is not exactly representable, the fp64 fallback does this product
   // one thread per (q, column cj = chunk*nc + jj, h, T): reads the 4 values k = 128(T/4) + 64h + 16(T%4) + 4i + q (i = 0..3), writes dword q of
@@ -202,6 +271,31 @@ __global__ void __launch_bounds__(256) k_slice_B(const double *__restrict__ B, l
       Bs[((((size_t)chunk * T_total + T) * NT + nt) * 64 + (size_t)(h * 32 + col)) * 4 + q] = w;
     }
   }
+}
+
+// K splits of a launch as a table of stage boundaries (round 5).  The integer partial sums are exact, so ANY partition of K gives the same result bit for
+// bit -- which frees the lengths: the splits are dealt in DECREASING length (the workgroups of split 0 are dispatched first), so the resident slots run dry
+// over a fraction of the shortest piece instead of a whole uniform one (391 strips x 5 splits on 512 slots: 3.82 rounds used to cost 4).
+constexpr int kMaxI8Splits = 64;
+struct SplitTab { int begin[kMaxI8Splits + 1]; };
+static SplitTab make_split_tab(int stages_total, int splits, int max_len) {
+  SplitTab t{};
+  static const double taper = [] { const char *e = getenv("MXA_I8_TAPER"); return e ? atof(e) : 0.0; }();   // A/B (measured: no gain for k_gemm_i8_tn, a loss for k_gemm_i8, whose XCD-dealt groups want equal work): uniform lengths
+  const double mean = (double)stages_total / splits;
+  double acc = 0.0;
+  t.begin[0] = 0;
+  for (int i = 0; i < splits; i++) {
+    const double w = splits >= 3 ? 1.0 + taper * (1.0 - 2.0 * i / (double)(splits - 1)) : 1.0;   // 1 + a ... 1 - a
+    acc += w * mean;
+    int b = i + 1 == splits ? stages_total : (int)(acc + 0.5);
+    b = std::max(b, t.begin[i] + 1);
+    b = std::min(b, std::min(stages_total - (splits - 1 - i), t.begin[i] + max_len));
+    t.begin[i + 1] = b;
+  }
+  // (max_len clipped a piece: push the remainder onto the later ones; they are shorter than the mean, so there is room unless mean itself is at the bound)
+  for (int i = splits; i > 0 && t.begin[i] > t.begin[i - 1] + max_len; i--) t.begin[i - 1] = t.begin[i] - max_len;
+  t.begin[splits] = stages_total;
+  return t;
 }
 
 // ---- main kernel
@@ -256,7 +350,7 @@ struct I8Direct {
 template <int NT, int MT, int WC, bool DIAG, bool SWAP1 = false>
 __global__ void __launch_bounds__(256, 1)
 k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict__ Bs, long T_total, int *__restrict__ P, long m_pad, int e_pad,
-          int rowblocks, int nchunks, int stages_total, int stages_per_split, unsigned long long *__restrict__ diag, const int *__restrict__ skip_if_set,
+          int rowblocks, int nchunks, int stages_total, SplitTab tab, unsigned long long *__restrict__ diag, const int *__restrict__ skip_if_set,
           I8Direct dir) {
   constexpr int ROWS = MT * (4 / WC) * 32;             // rows of the packed tile this workgroup multiplies: the whole tile, or one half
   using Cfg = I8Cfg<NT, ROWS>;
@@ -284,7 +378,7 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
   else { const int t = bid - g8 * rowblocks; rb = t % rowblocks; grp = g8 + t / rowblocks; }
   const int nc = grp % nchunks;
   const int sp = grp / nchunks;
-  const int st0 = sp * stages_per_split, st1 = min(st0 + stages_per_split, stages_total);
+  const int st0 = tab.begin[sp], st1 = tab.begin[sp + 1];
   const int stages = st1 - st0;
   const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
   const uint32_t v_lane = lane * 16;
@@ -463,109 +557,141 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
 // (bank = dword of the column group (8) + 8 * khalf + 16 * slab).
 // Partial sums go to P[split][e][individual] like the operand-swapped plain instantiations: k_finish_i8_t finishes them (exact int64 over the splits).
 constexpr int kTnSlabStride = kTileBytes + 64;                // LDS bytes between the slab regions of a stage
-constexpr int kTnBufs = 3;
-// SLABS = slabs (128 individuals) per workgroup strip; workgroup = 2 SLABS waves.
-//   SLABS = 4 (first version): 512 individuals, 8 waves, one workgroup per CU (LDS 121 KiB).  Wave (w4 = wave & 3, fh = wave >> 2): K-steps {2 w4, 2 w4 + 1} of
-//              every row block, MFMA groups f = 8 fh .. 8 fh + 7 (the bytes 2 fh, 2 fh + 1 of the gathered words; the two waves of a pair read the same dwords).
-//   SLABS = 2: 256 individuals, 4 waves, TWO workgroups per CU (72 KiB each) that fill each other's barrier and DMA waits, and twice as many, half as long
-//              workgroups for the rounds.  Only 16 column groups exist, so the byte-pair split moves from the waves INTO the lanes: lane (cg = lane & 15,
-//              fh = (lane >> 4) & 1, khalf = lane >> 5) -- the two lanes of a column group read the same dword (an LDS broadcast) and gather different byte
-//              pairs (the v_perm selector is per lane); MFMA group j multiplies the individuals 16 cg + 8 fh + j.  Wave w: K-steps {2 w, 2 w + 1}.
-template <int SLABS>
+// Workgroup = a strip of 256 individuals (2 slabs) x a range of row blocks, 4 waves.  Only 16 column groups exist, so the byte-pair split sits in the lanes:
+// lane (cg = lane & 15, fh = (lane >> 4) & 1, khalf = lane >> 5) -- the two lanes of a column group read the same dword (an LDS broadcast) and gather
+// different byte pairs (the v_perm selector is per lane); MFMA group j multiplies the individuals 16 cg + 8 fh + j.  Wave w: K-steps {2 w, 2 w + 1}.
+// (The first version -- 512 individuals, 8 waves, one workgroup per CU -- was no faster and was removed in round 5.)
+// Round 5: the digit fragments no longer pass through LDS.  A wave needs 2 KiB of them per stage (its two K-steps; the same for every strip, L2-resident):
+// each lane loads its 2 x 16 bytes straight into registers, BUFS - 1 stages ahead like the packed tiles.  A stage's LDS buffer shrinks from 24 to 16 KiB, so
+// the ring holds BUFS - 1 = 3 stages in flight per workgroup (was 2) with two workgroups per CU: 96 KiB of packed bytes on their way per CU instead of 64 --
+// the kernel is bound by the packed stream's latency, not by its arithmetic (DMA ring alone: 0.93 ms where the full kernel took 1.03, profiles/r04).
+constexpr int kTnSlabs = 2;
+constexpr int kTnMaxPieces = 64;              // partial-sum slots per strip at most
+struct TnPieces { int c_lo, n_lo, nitems; };  // strips [0, n_lo): c_lo pieces each, the others c_lo + 1 (plan_i8_tn)
+template <int BUFS>
 struct TnCfg {
-  static constexpr int kWaves = 2 * SLABS;
-  static constexpr int kDigitOff = SLABS * kTnSlabStride;     // digit fragments of the stage's 8 K-steps (8 KiB) behind the slab regions
-  static constexpr int kBufBytes = kDigitOff + 8 * 1024;
-  static constexpr int kLds = kTnBufs * kBufBytes;            // 123 648 B (SLABS = 4), 74 112 B (SLABS = 2)
-  static constexpr int kUnitsPerWave = (SLABS * 8 + 8) / kWaves;   // DMA units per wave and stage: 5 / 6
-  static_assert((SLABS == 4 || SLABS == 2) && (SLABS * 8 + 8) % kWaves == 0, "strip shape");
+  static constexpr int kWaves = 4;
+  static constexpr int kBufBytes = kTnSlabs * kTnSlabStride;        // packed rows of one stage: 2 slabs x 8 KiB (+ the bank offset)
+  static constexpr int kLds = BUFS * kBufBytes < 4 * 8192 ? 4 * 8192 : BUFS * kBufBytes;   // at least the 32 KiB of the final reduction
+  static constexpr int kPackedPerWave = kTnSlabs * 8 / kWaves;      // 4 DMA units per wave and stage
+  static constexpr int kOpsPerWave = kPackedPerWave + 2;            // + the wave's two digit loads: what vmcnt counts per stage
+  static constexpr int kDepth = BUFS - 1;                           // stages in flight
 };
 
-template <int SLABS>
-__global__ void __launch_bounds__(128 * SLABS, SLABS == 2 ? 2 : 1)
+template <int BUFS>
+__global__ void __launch_bounds__(256, 2)
 k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__restrict__ Ad, int digit_tiles, int *__restrict__ P, long m_pad, int e_pad, int e_off,
-             int strips, int stages_total, int stages_per_split, const int *__restrict__ skip_if_set) {
+             int strips, int stages_total, TnPieces pc, const int *__restrict__ skip_if_set) {
   // Ad: the digit fragments of THIS launch's tile of 32 expanded columns, K-steps digit_tiles KiB apart (k_slice_B interleaves the tiles of a K-step);
   // the sums go to rows e_off .. e_off + 31 of P[split][e_pad][m_pad].  A product with several tiles (3 <= n <= 6, the opt-in engines) is one launch per tile.
-  using Cfg = TnCfg<SLABS>;
+  using Cfg = TnCfg<BUFS>;
+  constexpr int D = Cfg::kDepth, NSET = D + 1;
   if (skip_if_set && *skip_if_set) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int w4 = wave & 3;
-  const int fh = SLABS == 4 ? wave >> 2 : (lane >> 4) & 1;    // field half: wave-uniform (8 waves) or per lane (4 waves)
-  const int strip = blockIdx.x % strips, sp = blockIdx.x / strips;
-  const int st0 = sp * stages_per_split, st1 = min(st0 + stages_per_split, stages_total);
-  const int stages = st1 - st0;
+  const int fh = (lane >> 4) & 1;                             // field half
   const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
+  // PERSISTENT workgroups over a list of ITEMS = (strip, piece of its K range), longest first (round 5; TnPieces).  Integer sums are exact, so the result
+  // does not depend on where the cuts fall -- which frees them: strips are cut into c or c + 1 equal pieces such that the items fill whole rounds of the
+  // resident slots (391 strips x 5 equal splits on 512 slots took 4 rounds for 3.82 rounds of work; 307 strips x 5 + 84 x 6 pieces take 3 rounds of 195
+  // stages + 1 of 163), and a slot is never re-dispatched (a replaced workgroup cost ~10 us of idle slot).  The items of a round start together and sweep
+  // their K ranges in step: the digit fragments they share stay in the L2s (an even cut of the strip-major stage sequence, tried first, scattered the
+  // workgroups over all row blocks: 1.20 ms against 1.04).  A piece's sums go to slot = piece index of P[slot][e][individual].
+  int strip = 0, st0 = 0, stages = 0, slot = 0;
   // DMA: LDS granule `lane` of a packed unit takes the global granule sigma(lane): rows 16..31 land rotated by one row
   const int rho = (lane - 32) >> 1;
   const uint32_t v_pack = lane < 32 ? (uint32_t)lane * 16 : (uint32_t)(2 * (16 + ((rho + 15) & 15)) + (lane & 1)) * 16;
   const uint32_t v_lin = (uint32_t)lane * 16;
-  auto issue = [&](int stage, int buf) {   // stage relative to st0
+  v4i dig[NSET][2];                                           // digit fragments of this wave's two K-steps, one register set per stage in flight (+ the one in use)
+#pragma unroll
+  for (int i = 0; i < NSET; i++) { dig[i][0] = v4i{0, 0, 0, 0}; dig[i][1] = v4i{0, 0, 0, 0}; }
+  // all global traffic of one stage: 4 packed DMA units, then the two digit loads (asm: the compiler does not see the DMA, so it must not count vmcnt either)
+  auto issue_packed = [&](int stage, int buf) {               // stage relative to st0
     const uint32_t base = lds0 + buf * Cfg::kBufBytes;
     const size_t rb = (size_t)(st0 + stage);
 #pragma unroll
-    for (int i = 0; i < Cfg::kUnitsPerWave; i++) {
-      const int u = wave + i * Cfg::kWaves;                  // packed units first (slab j = u >> 3, K-step u & 7), then the 8 digit units
-      if (u < SLABS * 8) {
-        long sl = (long)strip * SLABS + (u >> 3);
-        if (sl >= nslabs_all) sl = nslabs_all - 1;           // individuals beyond the matrix: rows of P nobody reads
-        idma16_stream(reinterpret_cast<const char *>(G) + (rb * (size_t)nslabs_all + (size_t)sl) * kTileBytes + (u & 7) * 1024, v_pack, base + (u >> 3) * kTnSlabStride + (u & 7) * 1024);
-      } else {
-        idma16_s(reinterpret_cast<const char *>(Ad) + (rb * 8 + (size_t)(u - SLABS * 8)) * ((size_t)digit_tiles * 1024), v_lin, base + Cfg::kDigitOff + (u - SLABS * 8) * 1024);
-      }
+    for (int i = 0; i < Cfg::kPackedPerWave; i++) {
+      const int u = wave + i * Cfg::kWaves;                  // slab j = u >> 3, K-step u & 7
+      long sl = (long)strip * kTnSlabs + (u >> 3);
+      if (sl >= nslabs_all) sl = nslabs_all - 1;             // individuals beyond the matrix: rows of P nobody reads
+      idma16_stream(reinterpret_cast<const char *>(G) + (rb * (size_t)nslabs_all + (size_t)sl) * kTileBytes + (u & 7) * 1024, v_pack, base + (u >> 3) * kTnSlabStride + (u & 7) * 1024);
     }
   };
+  auto issue_digits = [&](int stage, v4i &d0, v4i &d1) {
+    const char *src = reinterpret_cast<const char *>(Ad) + ((size_t)(st0 + stage) * 8 + (size_t)(2 * wave)) * ((size_t)digit_tiles * 1024);
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d0) : "v"(v_lin), "s"(src) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d1) : "v"(v_lin), "s"(src + (size_t)digit_tiles * 1024) : "memory");
+  };
   v16i acc[8];
-#pragma unroll
-  for (int f = 0; f < 8; f++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[f][r] = 0;
-  const int cg = SLABS == 4 ? lane & 31 : lane & 15, khalf = lane >> 5;
+  const int cg = lane & 15, khalf = lane >> 5;
   // byte offset of W[r] inside a packed unit: slab region + row position (rotated for the upper half) * 32 + dword of the column group
   int w_off[16];
 #pragma unroll
   for (int r = 0; r < 16; r++) w_off[r] = (cg >> 3) * kTnSlabStride + (khalf ? 16 + ((r + 1) & 15) : r) * kSlabBytes + (cg & 7) * 4;
   const uint32_t sel1 = fh ? 0x07030602u : 0x05010400u;     // first gather stage: byte pairs (2 fh, 2 fh + 1) of the two rows
 
-  if (stages > 0) issue(0, 0);
-  if (stages > 1) issue(1, 1);
-  for (int s = 0; s < stages; s++) {
-    if (s + 1 < stages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::kUnitsPerWave) : "memory");   // stage s has landed (stage s + 1 may be in flight)
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                         // ... for every wave; and everybody is done with stage s - 1, whose buffer is refilled now
-    if (s + 2 < stages) issue(s + 2, (s + 2) % kTnBufs);
-    const char *bufp = smem + (s % kTnBufs) * Cfg::kBufBytes;
+  for (int item = blockIdx.x; item < pc.nitems; item += gridDim.x) {
+  {
+  // ---- one item: stages [st0, st0 + stages) of `strip`
+  {
+    int c, piece;
+    if (item < pc.n_lo * pc.c_lo) { c = pc.c_lo; piece = item / pc.n_lo; strip = item - piece * pc.n_lo; }                       // piece-major: the strips' p-th pieces are neighbours
+    else { const int j = item - pc.n_lo * pc.c_lo, n_hi = strips - pc.n_lo; c = pc.c_lo + 1; piece = j / n_hi; strip = pc.n_lo + j - piece * n_hi; }
+    st0 = (int)((long)piece * stages_total / c);
+    stages = (int)((long)(piece + 1) * stages_total / c) - st0;
+    slot = piece;
+  }
 #pragma unroll
-    for (int kk = 0; kk < 2; kk++) {
-      const int T = 2 * w4 + kk;                             // K-step of this wave inside the row block
-      const v4i af = *reinterpret_cast<const v4i *>(bufp + Cfg::kDigitOff + T * 1024 + lane * 16);
-      uint32_t W[16];
+  for (int f = 0; f < 8; f++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) W[r] = *reinterpret_cast<const uint32_t *>(bufp + T * 1024 + w_off[r]);
-      // byte gather, this wave's / lane's half: Pq[q][bb] byte i = byte (2 fh + bb) of W[4 i + q]
-      uint32_t Pq[4][2];
+    for (int r = 0; r < 16; r++) acc[f][r] = 0;
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const uint32_t t = __builtin_amdgcn_perm(W[4 + q], W[q], sel1), u = __builtin_amdgcn_perm(W[12 + q], W[8 + q], sel1);
-        Pq[q][0] = __builtin_amdgcn_perm(u, t, 0x05040100u); Pq[q][1] = __builtin_amdgcn_perm(u, t, 0x07060302u);
-      }
+  for (int i = 0; i < D; i++) if (i < stages) { issue_packed(i, i); issue_digits(i, dig[i][0], dig[i][1]); }
+  for (int s0 = 0; s0 < stages; s0 += NSET) {
 #pragma unroll
-      for (int f = 0; f < 8; f++) {
-        const int bb = f >> 2, g = f & 3;
-        v4i bf;
+    for (int u = 0; u < NSET; u++) {
+      const int s = s0 + u;
+      if (s < stages) {
+        // stage s has landed; the stages behind it (at most D - 1, fewer near the end: then everything is waited for) may be in flight
+        if (s + D - 1 < stages) asm volatile("s_waitcnt vmcnt(%0)" : : "n"((D - 1) * Cfg::kOpsPerWave) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        // (an empty volatile asm that "rewrites" the registers: volatile asms keep their order, so whatever reads the digits -- and any copy the register
+        // allocator makes for this statement -- comes after the wait.  Tying the registers to the wait itself put such copies BEFORE it.)
+        asm volatile("" : "+v"(dig[u][0]), "+v"(dig[u][1]));
+        __syncthreads();                                     // ... for every wave; and everybody is done with stage s - 1, whose buffer is refilled now
+        if (s + D < stages) { issue_packed(s + D, (s + D) % BUFS); issue_digits(s + D, dig[(u + D) % NSET][0], dig[(u + D) % NSET][1]); }
+        const char *bufp = smem + (s % BUFS) * Cfg::kBufBytes;
 #pragma unroll
-        for (int q = 0; q < 4; q++) bf[q] = (int)(g < 3 ? (Pq[q][bb] & (0x03030303u << (2 * g))) : ((Pq[q][bb] >> 2) & 0x30303030u));
-        acc[f] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[f], 0, 0, 0);
+        for (int kk = 0; kk < 2; kk++) {
+          const int T = 2 * wave + kk;                       // K-step of this wave inside the row block
+          const v4i af = dig[u][kk];
+          uint32_t W[16];
+#pragma unroll
+          for (int r = 0; r < 16; r++) W[r] = *reinterpret_cast<const uint32_t *>(bufp + T * 1024 + w_off[r]);
+          // byte gather, this lane's half: Pq[q][bb] byte i = byte (2 fh + bb) of W[4 i + q]
+          uint32_t Pq[4][2];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const uint32_t t = __builtin_amdgcn_perm(W[4 + q], W[q], sel1), v = __builtin_amdgcn_perm(W[12 + q], W[8 + q], sel1);
+            Pq[q][0] = __builtin_amdgcn_perm(v, t, 0x05040100u); Pq[q][1] = __builtin_amdgcn_perm(v, t, 0x07060302u);
+          }
+#pragma unroll
+          for (int f = 0; f < 8; f++) {
+            const int bb = f >> 2, g = f & 3;
+            v4i bf;
+#pragma unroll
+            for (int q = 0; q < 4; q++) bf[q] = (int)(g < 3 ? (Pq[q][bb] & (0x03030303u << (2 * g))) : ((Pq[q][bb] >> 2) & 0x30303030u));
+            acc[f] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[f], 0, 0, 0);
+          }
+        }
       }
     }
   }
-  // ---- add the accumulators of the four waves that split the K-steps (per field half) through LDS, two MFMA groups per pass, and store P[split][e][individual]
+  // ---- add the accumulators of the four waves that split the K-steps through LDS, two MFMA groups per pass, and store P[split][e][individual]
   __syncthreads();
   int *red = reinterpret_cast<int *>(smem);                  // [wave][group in pass (2)][reg (16)][lane (64)] ints = 8 KiB per wave
-  int *Pb = P + ((size_t)sp * e_pad + e_off) * m_pad;
-  const int wbase = SLABS == 4 ? 4 * (wave >> 2) : 0;        // the four waves whose sums belong together
+  int *Pb = P + ((size_t)slot * e_pad + e_off) * m_pad;
 #pragma unroll
   for (int pass = 0; pass < 4; pass++) {
 #pragma unroll
@@ -574,22 +700,24 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
       for (int r = 0; r < 16; r++) red[((wave * 2 + gq) * 16 + r) * 64 + lane] = acc[pass * 2 + gq][r];
     __syncthreads();
     {
-      const int gq = w4 & 1, r0 = 8 * (w4 >> 1);             // this wave finishes group gq of its field half, registers r0 .. r0 + 7
+      const int gq = wave & 1, r0 = 8 * (wave >> 1);         // this wave finishes group gq, registers r0 .. r0 + 7
       const int f = 8 * fh + 2 * pass + gq;                  // field of the dword = individual 16 cg + f
       const int sh = (f & 3) == 3 ? 4 : 2 * (f & 3);         // the in-place field scale of the group: 4^g, 16 for the top field
-      const long indiv = (long)strip * (SLABS * kSlabK) + 16 * cg + f;
+      const long indiv = (long)strip * (kTnSlabs * kSlabK) + 16 * cg + f;
 #pragma unroll
       for (int rr = 0; rr < 8; rr++) {
         const int r = r0 + rr;
         int v = 0;
 #pragma unroll
-        for (int w = 0; w < 4; w++) v += red[(((wbase + w) * 2 + gq) * 16 + r) * 64 + lane];
+        for (int w = 0; w < 4; w++) v += red[((w * 2 + gq) * 16 + r) * 64 + lane];
         const int e = (r & 3) + 8 * (r >> 2) + 4 * khalf;
         Pb[(size_t)e * m_pad + indiv] = v >> sh;             // exact: every product carried the factor
       }
     }
     __syncthreads();
   }
+  }
+  }   // items of this workgroup
 }
 
 // ---- finish: sum the splits exactly (int64), combine the slices smallest scale first, centring, ldc store.
@@ -698,8 +826,11 @@ constexpr int kFinTBlockRows = 64 * kFinTRows;
 __global__ void __launch_bounds__(256) k_finish_i8_t(const int *__restrict__ P, long m_pad, int e_pad, int splits, long m, int n, int S, int nc, int NT,
                                                      const int *__restrict__ E, const double *__restrict__ colmax_part, double *__restrict__ Cout, long ldc,
                                                      long fill_rows, int mode_trans, int centered, const double *__restrict__ sumB, const double *__restrict__ sumfB,
-                                                     const double *__restrict__ f, const int *__restrict__ skip_if_set) {
+                                                     const double *__restrict__ f, const int *__restrict__ skip_if_set, int tn_c_lo, int tn_n_lo) {
   if (skip_if_set && *skip_if_set) return;
+  // partial sums of the transposed-operand kernel (tn_c_lo > 0): this block's 256 rows are ONE strip of k_gemm_i8_tn, which was cut into c_lo pieces (strips
+  // [0, n_lo)) or c_lo + 1: one slot of P per piece
+  if (tn_c_lo > 0) splits = tn_c_lo + (((int)blockIdx.x >= tn_n_lo && (long)blockIdx.x < m_pad / kFinTBlockRows) ? 1 : 0);   // (blocks beyond the last strip: ld padding rows, zeros)
   const int j = blockIdx.y, chunk = j / nc, jj = j - chunk * nc;
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const long rbase = (long)blockIdx.x * kFinTBlockRows + lane;
@@ -828,85 +959,6 @@ __global__ void __launch_bounds__(256) k_finish_i8_small(const int *__restrict__
   }
 }
 
-// ---- fp64 kernel BEHIND the guarded chains (round 5): runs iff the exactness verdict is class 2 (run_if_set), one launch, no partial sums, no finish.
-// One thread per output row owns its dot products over the whole K range in ascending k -- a plain fp64 FMA chain, the arithmetic of the reference
-// (src/cuda/dgemm_compressed_cuda.h:259-266), deterministic, |error| <= K 2^-53 sum |z b|.  It replaces the gated launch pairs / triples that stood here
-// (k_lut + k_finish; k_pack_B + k_gemm<MODE 0> + k_finish): the verdict almost never asks for it, and an early-out launch costs ~5 us each on a 1 ms product.
-// Plain form (TN = false): thread <-> packed row, 32 bytes per slab of 128 genotypes; the entries of B are wave-uniform (scalar loads).
-// Transposed-operand form (TN = true): thread <-> individual (a packed column), one byte per packed row; K runs over the rows.
-// NC <= 6 columns.  Not fast (a few ms on the config-5 shard) and not meant to be.
-template <int NC, bool TN>
-__global__ void __launch_bounds__(256) k_small_n_fp64(const uint8_t *__restrict__ G, long nslabs, long m, long k, const double *__restrict__ B, long ldb, int n,
-                                                      double *__restrict__ C, long ldc, long fill_rows, int mode_trans, int centered, const double *__restrict__ sumB,
-                                                      const double *__restrict__ sumfB, const double *__restrict__ f, const int *__restrict__ run_if_set) {
-  if (run_if_set && *run_if_set == 0) return;
-  const long r = (long)blockIdx.x * 256 + threadIdx.x;
-  if (r >= fill_rows) return;
-  double v[NC];
-#pragma unroll
-  for (int j = 0; j < NC; j++) v[j] = 0.0;
-  if (r < m) {
-    if (!TN) {
-      const uint8_t *row = G + (size_t)(r / kTileRows) * nslabs * kTileBytes + (size_t)(r % kTileRows) * kSlabBytes;
-      for (long sl = 0; sl * kSlabK < k; sl++) {
-        const uint4 w0 = *reinterpret_cast<const uint4 *>(row + (size_t)sl * kTileBytes), w1 = *reinterpret_cast<const uint4 *>(row + (size_t)sl * kTileBytes + 16);
-        const uint32_t wd[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-        for (int d = 0; d < 8; d++) {
-          const long k0 = sl * kSlabK + 16 * d;
-          if (k0 >= k) break;
-#pragma unroll
-          for (int e = 0; e < 16; e++) {
-            const long kk = k0 + e;
-            if (kk < k) {
-              const double z = (double)((wd[d] >> (2 * e)) & 3u);
-#pragma unroll
-              for (int j = 0; j < NC; j++) if (j < n) v[j] = fma(z, B[kk + (long)j * ldb], v[j]);
-            }
-          }
-        }
-      }
-    } else {
-      // packed matrix rows = K; this thread's individual r: byte (r % 128) / 4 of slab r / 128, field r % 4
-      const uint8_t *col = G + (size_t)(r / kSlabK) * kTileBytes + (size_t)(r % kSlabK) / 4;
-      const int sh = 2 * (int)(r & 3);
-      for (long t = 0; t * kTileRows < k; t++) {
-        const uint8_t *tile = col + (size_t)t * nslabs * kTileBytes;
-        const long rows = k - t * kTileRows < kTileRows ? k - t * kTileRows : kTileRows;
-#pragma unroll 8
-        for (long q = 0; q < rows; q++) {
-          const double z = (double)((tile[q * kSlabBytes] >> sh) & 3u);
-          const long kk = t * kTileRows + q;
-#pragma unroll
-          for (int j = 0; j < NC; j++) if (j < n) v[j] = fma(z, B[kk + (long)j * ldb], v[j]);
-        }
-      }
-    }
-    if (centered) {
-#pragma unroll
-      for (int j = 0; j < NC; j++) if (j < n) v[j] = mode_trans ? fma(-2.0 * sumB[j], f[r], v[j]) : v[j] + -2.0 * sumfB[j];
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < NC; j++) if (j < n) C[r + (long)j * ldc] = v[j];   // rows [m, fill_rows): zeros
-}
-
-int launch_small_n_fp64(const PackedMatrix &G, bool tn, long m, long k, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool trans, bool centered,
-                        const double *d_sumB, const double *d_sumfB, const double *d_f, const int *run_if_set, hipStream_t s) {
-  if (n < 1 || n > kSmallNMaxCols) { set_error(4, "internal: small-n fp64 kernel with %d columns", n); return 1; }
-  if (tn ? (G.k < m || G.rows < k) : (G.rows < m || G.k < k)) { set_error(4, "internal: small-n fp64 kernel: operand shape"); return 1; }
-  const dim3 grid((unsigned)((fill_rows + 255) / 256));
-#define MXA_SN(NC_)                                                                                                                                              \
-  if (tn) hipLaunchKernelGGL((k_small_n_fp64<NC_, true>), grid, dim3(256), 0, s, G.d, G.nslabs, m, k, dB, ldb, n, dC, ldc, fill_rows, trans ? 1 : 0, centered ? 1 : 0, \
-                             d_sumB, d_sumfB, d_f, run_if_set);                                                                                                  \
-  else hipLaunchKernelGGL((k_small_n_fp64<NC_, false>), grid, dim3(256), 0, s, G.d, G.nslabs, m, k, dB, ldb, n, dC, ldc, fill_rows, trans ? 1 : 0, centered ? 1 : 0,   \
-                          d_sumB, d_sumfB, d_f, run_if_set);
-  if (n <= 2) { MXA_SN(2) } else if (n <= 4) { MXA_SN(4) } else { MXA_SN(6) }
-#undef MXA_SN
-  MXA_HIP(hipGetLastError());
-  return 0;
-}
-
 struct I8Plan { int S, nc, nchunks, NT, e_pad, rowblocks, stages_total, stages_per_split, splits, rows_wg; long m_pad, T_total; };
 
 static I8Plan plan_i8(long m, long k_pad, int n, int S_override) {
@@ -984,7 +1036,7 @@ static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const 
   if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8<NT, MT, WC, false, SWAP1>), Cfg::kLds, &attr_a)) return 1;
   const long grid = (long)p.rowblocks * p.nchunks * p.splits;
   hipLaunchKernelGGL((k_gemm_i8<NT, MT, WC, false, SWAP1>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBs, p.T_total, dP, p.m_pad, p.e_pad,
-                     p.rowblocks, p.nchunks, p.stages_total, p.stages_per_split, (unsigned long long *)nullptr, skip_if_set, dir);
+                     p.rowblocks, p.nchunks, p.stages_total, make_split_tab(p.stages_total, p.splits, 32767), (unsigned long long *)nullptr, skip_if_set, dir);
   MXA_HIP(hipGetLastError());
   return 0;
 }
@@ -993,42 +1045,55 @@ static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const 
 // handle and only grows.
 // K splits of the transposed-operand kernel: workgroups = strips x splits on one resident workgroup per CU; the split count whose last round of
 // workgroups is fullest, counting a start-up worth a few stages per workgroup; at most 2047 stages per split (int32 accumulators)
-static void plan_i8_tn(long indiv_slabs, long snp_rows, int slabs_wg, int *strips, int *stages_total, int *stages_per_split, int *splits) {
-  *strips = (int)((indiv_slabs + slabs_wg - 1) / slabs_wg);
-  *stages_total = (int)((snp_rows + kTileRows - 1) / kTileRows);
-  const double slots = 256.0 * (slabs_wg == 2 ? 2 : 1);      // resident workgroups
-  // Cost in stage times: whole rounds of the resident slots (a workgroup keeps two stages in flight and does not run faster when its neighbours have
-  // finished, so a thinly filled last round costs a whole one) x (stages per workgroup + 35 stages' worth of start-up, LDS reduction and stores -- the value
-  // that ranks the measured sweeps right: config-5 shard 'N' 2 .. 13 splits = 1.17, 1.05, 1.09, 1.03 (5: chosen), 1.11, 1.07, 1.07, 1.05 ms; 'T' 1 split
-  // 1.00 against 1.08 with 2; tools/gpu_r4_tn_splits.sh) + the finish kernel's pass over the partial sums.
-  double best_cost = -1.0; int best = 1;
-  for (int cand = 1; cand <= 64 && cand <= *stages_total; cand++) {
-    const long per = (*stages_total + cand - 1) / cand, actual = (*stages_total + per - 1) / per;
-    if (actual != cand || per > 2047) continue;
-    const double rounds = std::ceil((double)*strips * actual / slots);
-    const double cost = rounds * ((double)per + 35.0) + (double)actual * (double)*strips * slabs_wg * kSlabK * 128.0 / 3.0e6;
-    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cand; }
+constexpr int kTnBufs = 4;   // 4 buffers x 2 workgroups per CU: 3 stages in flight (3 x 3 would need <= 170 VGPRs: the kernel holds 220)
+// Items of the transposed-operand kernel: the first n_lo strips are cut into c_lo equal pieces of their K range, the other strips into c_lo + 1; the items of
+// the c_lo-piece strips (the longer ones) come first, piece-major.  Chosen so that the items fill whole rounds of the resident slots with (nearly) equal
+// lengths inside every round: cost = sum over the rounds of (longest item of the round + a few stages of start-up and flush), fewest pieces among equals.
+static void plan_i8_tn(long indiv_slabs, long snp_rows, int *strips_out, int *stages_out, TnPieces *pc) {
+  const int n = (int)((indiv_slabs + kTnSlabs - 1) / kTnSlabs), K = (int)((snp_rows + kTileRows - 1) / kTileRows);
+  *strips_out = n; *stages_out = K;
+  static const long slots = [] {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) { (void)hipGetLastError(); return 512L; }
+    return 2L * prop.multiProcessorCount;
+  }();
+  const int c_min = std::max(1, (K + 2046) / 2047);               // int32 accumulators: at most 2047 stages per piece
+  const int c_max = std::max(c_min, std::min(kTnMaxPieces - 1, K / 24));   // pieces shorter than ~24 stages are mostly start-up
+  double best = -1.0; int best_c = c_min, best_nlo = n;
+  for (long R = 1; R <= 64; R++) {
+    const long T = R * slots;
+    int c = (int)std::min<long>(c_max, std::max<long>(c_min, T / n));
+    long n_hi = std::min<long>(n, std::max<long>(0, T - (long)n * c));
+    if (c >= c_max) n_hi = 0;
+    const long n_lo = n - n_hi, items_lo = n_lo * c, items = items_lo + n_hi * (c + 1);
+    const double len_lo = (double)K / c, len_hi = (double)K / (c + 1);
+    double cost = 0.0;
+    for (long i0 = 0; i0 < items; i0 += slots) cost += (i0 < items_lo ? len_lo : len_hi) + 20.0;   // a round lasts as long as its first (longest) item + ~20 stages of start-up and flush (fits the measured shapes)
+    cost += 0.35 * (double)(items) / (double)n;                                                    // the finish kernel reads one slot per piece
+    if (best < 0 || cost < best * 0.995) { best = cost; best_c = c; best_nlo = (int)n_lo; }
+    if (c >= c_max) break;
   }
-  // int32 accumulators: at most 2047 stages (2047 x 256 x 128 x 32 < 2^31) per split, whatever the search found (more than 64 x 2047 row blocks -- 33.5 M
-  // SNPs in one object -- have no candidate above and would otherwise keep best = 1)
-  best = std::max(best, (*stages_total + 2046) / 2047);
-  *stages_per_split = (*stages_total + best - 1) / best;
-  *splits = (*stages_total + *stages_per_split - 1) / *stages_per_split;
+  pc->c_lo = best_c; pc->n_lo = best_nlo; pc->nitems = best_nlo * best_c + (n - best_nlo) * (best_c + 1);
 }
 
-template <int SLABS>
-static int launch_i8_tn(const PackedMatrix &G_tn, const int8_t *d_Bs, int *d_P, const I8Plan &p, int strips, int stages, int sps, int splits, hipStream_t s, const int *skip) {
+template <int BUFS>
+static int launch_i8_tn(const PackedMatrix &G_tn, const int8_t *d_Bs, int *d_P, const I8Plan &p, int strips, int stages, const TnPieces &pc, hipStream_t s, const int *skip) {
   static unsigned long long attr_tn = 0;
-  if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8_tn<SLABS>), TnCfg<SLABS>::kLds, &attr_tn)) return 1;
+  if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8_tn<BUFS>), TnCfg<BUFS>::kLds, &attr_tn)) return 1;
+  static int per_dev[64] = {};
+  int dev = 0;
+  MXA_HIP(hipGetDevice(&dev));
+  if (!per_dev[dev & 63]) { hipDeviceProp_t prop; MXA_HIP(hipGetDeviceProperties(&prop, dev)); per_dev[dev & 63] = 2 * std::max(1, prop.multiProcessorCount); }
+  const unsigned grid = (unsigned)std::min(pc.nitems, per_dev[dev & 63]);   // persistent: one workgroup per resident slot, fewer if there are fewer items
   for (int nt = 0; nt < p.NT; nt++)
-    hipLaunchKernelGGL(k_gemm_i8_tn<SLABS>, dim3((unsigned)(strips * splits)), dim3(128 * SLABS), TnCfg<SLABS>::kLds, s, G_tn.d, G_tn.nslabs, d_Bs + (size_t)nt * 1024, p.NT, d_P, p.m_pad, p.e_pad,
-                       nt * 32, strips, stages, sps, skip);
+    hipLaunchKernelGGL(k_gemm_i8_tn<BUFS>, dim3(grid), dim3(256), TnCfg<BUFS>::kLds, s, G_tn.d, G_tn.nslabs, d_Bs + (size_t)nt * 1024, p.NT, d_P, p.m_pad, p.e_pad,
+                       nt * 32, strips, stages, pc, skip);
   MXA_HIP(hipGetLastError());
   return 0;
 }
 
 // plan of one product (plain or transposed-operand form) and the bytes of workspace it needs; returns 2 when the transposed form declines
-struct I8Full { I8Plan p; bool tn; int tn_slabs, tn_strips, tn_stages, tn_sps, tn_splits; size_t part_bytes, e_bytes, bs_bytes, p_bytes, need; };
+struct I8Full { I8Plan p; bool tn; int tn_strips, tn_stages; TnPieces tn_pc; size_t part_bytes, e_bytes, bs_bytes, p_bytes, need; };
 static int plan_i8_full(const PackedMatrix &G, int n, int S_override, const PackedMatrix *G_tn, I8Full &f) {
   const long m = G.rows, k = G.k;
   f.p = plan_i8(m, G.k_pad, n, S_override);
@@ -1039,12 +1104,14 @@ static int plan_i8_full(const PackedMatrix &G, int n, int S_override, const Pack
   // fp64 MFMA tile would take, or with several column chunks, the caller's fp64 path is the better choice: declined with 2 before anything is enqueued)
   if (G_tn != nullptr && (p.nchunks != 1 || p.NT > (n <= 4 ? 2 : 5))) return 2;
   f.tn = G_tn != nullptr;
-  f.tn_slabs = 2; f.tn_strips = f.tn_stages = f.tn_sps = f.tn_splits = 0;
+  f.tn_strips = f.tn_stages = 0; f.tn_pc = TnPieces{1, 0, 0};
   if (f.tn) {
     if (G_tn->k != m || G_tn->rows != k) { set_error(4, "internal: transposed operand has the wrong shape"); return 1; }
-    plan_i8_tn(G_tn->nslabs, G_tn->rows, f.tn_slabs, &f.tn_strips, &f.tn_stages, &f.tn_sps, &f.tn_splits);
+    plan_i8_tn(G_tn->nslabs, G_tn->rows, &f.tn_strips, &f.tn_stages, &f.tn_pc);
     if ((long)f.tn_stages * kTileRows > G_tn->rows_pad) { set_error(4, "internal: packed matrix smaller than the transposed i8 plan"); return 1; }
-    p.T_total = (long)f.tn_stages * 8; p.splits = f.tn_splits; p.m_pad = (long)f.tn_strips * f.tn_slabs * kSlabK; p.e_pad = p.NT * 32;
+    if ((f.tn_stages + f.tn_pc.c_lo - 1) / f.tn_pc.c_lo > 2047) return 2;   // K beyond 64 x 2047 row blocks (33.5 M SNPs in one object): the fp64 path
+    // splits = partial-sum slots per strip
+    p.T_total = (long)f.tn_stages * 8; p.splits = f.tn_pc.c_lo + (f.tn_pc.n_lo < f.tn_strips ? 1 : 0); p.m_pad = (long)f.tn_strips * kTnSlabs * kSlabK; p.e_pad = p.NT * 32;
   }
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
   f.part_bytes = up(sizeof(double) * 128 * n); f.e_bytes = up(sizeof(int) * (n + 1));   // column maxima + minima; exponents
@@ -1086,7 +1153,7 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   }
   I8Plan &p = pf.p;
   const bool tn = pf.tn;
-  const int tn_slabs = pf.tn_slabs, tn_strips = pf.tn_strips, tn_stages = pf.tn_stages, tn_sps = pf.tn_sps, tn_splits = pf.tn_splits;
+  const int tn_strips = pf.tn_strips, tn_stages = pf.tn_stages;
   if (splits_out) *splits_out = p.splits;
   const size_t part_bytes = pf.part_bytes, e_bytes = pf.e_bytes, bs_bytes = pf.bs_bytes;
   if (chain && !chain->first && w.cap_i8 < pf.need) { set_error(4, "internal: the second chain of a guarded product outgrows the workspace (gemm_i8_reserve)"); return 1; }
@@ -1128,8 +1195,15 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   {
     const int ncols = p.nchunks * p.nc;
     const long total = (long)p.T_total * 2 * ncols * 4;
-    hipLaunchKernelGGL(k_slice_B, dim3((unsigned)std::min<long>((total + 255) / 256, 256L * 64)), dim3(256), 0, s, dB, ldb, k, n, d_E, p.S, p.nc, p.NT,
-                       p.T_total, ncols, reinterpret_cast<uint32_t *>(d_Bs), total, skip, fu, tn ? 1 : 0);
+    SmallNFallback fb{};
+    long blocks = (total + 255) / 256;
+    if (fused && chain->first) {   // the fp64 rows of verdict class 2 ride in this launch: a thread per output row
+      const PackedMatrix &GF = tn ? *G_tn : G;
+      fb = SmallNFallback{GF.d, GF.nslabs, m, k, dC, ldc, fill_rows, tn ? 1 : 0, trans ? 1 : 0, centered ? 1 : 0, d_f};
+      blocks = std::max(blocks, (fill_rows + 255) / 256);
+    }
+    hipLaunchKernelGGL(k_slice_B, dim3((unsigned)std::min<long>(blocks, 256L * 64)), dim3(256), 0, s, dB, ldb, k, n, d_E, p.S, p.nc, p.NT,
+                       p.T_total, ncols, reinterpret_cast<uint32_t *>(d_Bs), total, skip, fu, tn ? 1 : 0, fb);
   }
   MXA_HIP(hipGetLastError());
   if (ev0) MXA_HIP(hipEventRecord(ev0, s));
@@ -1137,12 +1211,12 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   const bool small_tile = p.nchunks == 1 && p.NT == 1 && p.nc * p.S <= 32 && (p.nc == 1 || p.nc == 2);   // n <= 2: one tile
   I8Direct dir{};
   if (tn) {
-    (void)tn_slabs;
-    if (launch_i8_tn<2>(*G_tn, d_Bs, d_P, p, tn_strips, tn_stages, tn_sps, tn_splits, s, skip)) return 1;
+    if (launch_i8_tn<kTnBufs>(*G_tn, d_Bs, d_P, p, tn_strips, tn_stages, pf.tn_pc, s, skip)) return 1;
     if (ev1) MXA_HIP(hipEventRecord(ev1, s));
+    static_assert(kFinTBlockRows == kTnSlabs * kSlabK, "a block of k_finish_i8_t = one strip of k_gemm_i8_tn: it adds that strip's slots");
     dim3 grid((unsigned)((fill_rows + kFinTBlockRows - 1) / kFinTBlockRows), (unsigned)n);
     hipLaunchKernelGGL(k_finish_i8_t, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, d_part, dC, ldc, fill_rows, trans ? 1 : 0,
-                       centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip);
+                       centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip, pf.tn_pc.c_lo, pf.tn_pc.n_lo);
     MXA_HIP(hipGetLastError());
     return guard == 2 ? 3 : 0;
   }
@@ -1170,7 +1244,7 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   } else if (p.NT >= 2 || swap1) {   // operand-swapped instantiations: transposed partial sums
     dim3 grid((unsigned)((fill_rows + kFinTBlockRows - 1) / kFinTBlockRows), (unsigned)n);
     hipLaunchKernelGGL(k_finish_i8_t, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, d_part, dC, ldc, fill_rows, trans ? 1 : 0,
-                       centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip);
+                       centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip, 0, 0);
   } else {
     dim3 grid((unsigned)((fill_rows + 31) / 32), p.nchunks);
     hipLaunchKernelGGL(k_finish_i8, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, d_part, dC, ldc, fill_rows, trans ? 1 : 0,

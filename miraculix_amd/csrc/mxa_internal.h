@@ -244,8 +244,8 @@ int launch_sparse_times_plink(const uint8_t *dP, size_t pitch, long entries, int
 // the exponents and the guard (k_colstats_partial; finished inside k_slice_B) -- the caller must not have launched launch_colsums for them
 // chain (guard = 2, round 5): the verdict is a CLASS decided on the device (mxa_gemm_i8.hip: SliceFused) -- class 0 / 1: B is represented exactly by S0 / S1
 // digits per column (S1 = 0: no second class), class 2: neither.  One call enqueues the chain of ONE class (my_class; its kernels do nothing unless the
-// verdict is that class); `first`: this call also launches the statistics pass and publishes E, the column sums and the three flag words.  The caller enqueues
-// the chains of all classes and the fp64 kernel (launch_small_n_fp64, run_if_set = *flag_out) back to back; nothing waits for the host.
+// verdict is that class); `first`: this call also launches the statistics pass, publishes E, the column sums and the three flag words, and carries the fp64
+// chains of class 2 inside its k_slice_B launch.  The caller enqueues the chains of all classes back to back; nothing waits for the host.
 struct I8Chain { int S0 = 0, S1 = 0, my_class = 0; bool first = true; };
 int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool centered, double *d_sumB,
                    double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out, int guard = 0,
@@ -253,10 +253,6 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
                    double *stats_part = nullptr, const I8Chain *chain = nullptr);
 // workspace for a chain with S digits (0: the default of n), before anything is enqueued; 2: the transposed-operand form declines this tile count
 int gemm_i8_reserve(const PackedMatrix &G, int n, int S, const PackedMatrix *G_tn, Workspace &w, hipStream_t s);
-// the fp64 kernel behind the guarded chains: C = G B (plain form: output rows = G's rows; tn: G's columns, K over its rows), n <= 6 columns, centring and ld
-// padding included; runs iff *run_if_set != 0 (nullptr: always)
-int launch_small_n_fp64(const PackedMatrix &G, bool tn, long m, long k, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool trans, bool centered,
-                        const double *d_sumB, const double *d_sumfB, const double *d_f, const int *run_if_set, hipStream_t s);
 // stats_part (guard = 0): the column maxima / minima of B are already there (k_colmax_partial's layout, 128 n doubles; the caller's launch_colspan made them to
 // choose S): only the exponents are derived, no second pass over B
 // G_tn: the OTHER stored orientation (rows = the K index); the main kernel then runs in the transposed-operand form k_gemm_i8_tn, one launch per tile of 32

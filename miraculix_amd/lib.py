@@ -35,7 +35,11 @@ def load_shared_library():
             f"miraculix_amd: shared library {path} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C miraculix_amd/csrc`. There is no CPU fallback."
         )
-    L = ctypes.CDLL(path)   # RTLD_LOCAL: like the dlopen of the Julia binding (miraculix.jl:60-110)
+    # RTLD_GLOBAL on purpose, for this PYTHON mirror only: PyTorch bundles its own libamdhip64 and the library links the system one.  Whichever HIP runtime
+    # enters the global scope first serves both, so device pointers of torch tensors are valid in the library whatever the import order (with RTLD_LOCAL and
+    # the library loaded first, torch's runtime fails to initialise: "No HIP GPUs are available").  What becomes global is the C ABI only -- the library
+    # exports nothing else (csrc/exports.map).  A Julia / R / Fortran host dlopen()s it the ordinary way.
+    L = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
     L.setOptions_compressed.argtypes = [ctypes.c_int] * 10
     L.setOptions_compressed.restype = None
     L.plink2compressed.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
