@@ -2,7 +2,7 @@
 """bench.py -- headline benchmark: effective GFLOP/s of dgemm_compressed (2-bit SNP x fp64) on N MI355X.
 
 Structure: setup_process / stage_headline / make_step_and_sync / run_timed (the timed region and `value`), then legs that never feed
-`value`: per_rank (launcher) or per_shard + rccl_reduction / p2p_reduction (the one --reduce did not select) + hub_operands_on_first_device (in-process N > 1), opt_in_engine,
+`value`: per_rank (launcher) or per_shard + p2p_reduction / rccl_reduction (the one that was not timed as `value`: RCCL is, wherever every shard has its own device) + hub_operands_on_first_device (in-process N > 1), opt_in_engine,
 abi_end_to_end, cpu_baseline + check, and at N = 1 the other BASELINE configs under their own checkers: config5_cg_step,
 config4_shard, config3_crossprod (reference harness shape: utils/benchmark/benchmark.f90:182-254).
 
@@ -943,9 +943,12 @@ def opt_in_engine_leg(W, L, args, step, sync, engine, flops_step, description):
     finally:
         L.mxa_set_engine(0)
     digits = ga.value if engine == 4 else 7          # of the last product of the step ('T'); engine 4 reports its per-call choice
+    one_copy = bool(L.mxa_single_orientation(W.eng.obj) == 1)
     dN = float(((W.C_N - C_N64).abs().amax(dim=0) / C_N64.abs().amax(dim=0)).max())
     dT = float(((W.C_T - C_T64).abs().amax(dim=0) / C_T64.abs().amax(dim=0)).max())
     avg_ms = ms8 / max(1, la8)
+    if one_copy:   # the headline object keeps one packed copy (the default): at wide n the opt-in engines then apply to 'T' only
+        description += "; NOTE: one-copy object -- at this n the int8 engines multiply 'T' only, 'N' runs the fp64 engine (both copies: MXA_SINGLE_ORIENTATION=0)"
     out = {"engine": description, "kernel_family_of_last_product": {0: "k_gemm", 1: "k_lut", 2: "k_gemm_i8", 3: "k_small_n_fp64"}.get(path, str(path)),
            "value": round(flops_step * args.steps / dt8 * 1e-9, 1), "unit": "GFLOP/s (fp64-equivalent: same 2*snps*indiv*ncol count)",
            "ms_per_step": round(dt8 / args.steps * 1e3, 3), "avg_kernel_ms": round(avg_ms, 3), "digits_per_column": digits,
@@ -964,9 +967,10 @@ def main():
     ap.add_argument("--indiv", type=int, default=50_000)
     ap.add_argument("--ncol", type=int, default=32)
     ap.add_argument("--centered", type=int, default=0)
-    ap.add_argument("--reduce", choices=["p2p", "rccl"], default="p2p",
-                    help="in-process N > 1 (no launcher): the reduction of the 'N' partials that is TIMED -- p2p = peer-to-peer pushes + one fixed-order addition "
-                         "kernel (default, bitwise reproducible), rccl = ncclReduce over xGMI (the collective north_star names); the other one is reported beside it. "
+    ap.add_argument("--reduce", choices=["auto", "p2p", "rccl"], default="auto",
+                    help="in-process N > 1 (no launcher): the reduction of the 'N' partials that is TIMED and reported as `value` -- rccl = ncclReduce over xGMI (the "
+                         "collective north_star names), p2p = peer-to-peer pushes + one fixed-order addition kernel (bitwise reproducible); auto (default) = rccl when "
+                         "every shard has a device of its own, else p2p, and p2p with the reason in the line if RCCL fails.  The other one is reported beside it.  "
                          "Under the torch.distributed launcher the reduction is always RCCL's all-reduce.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-engine", action="store_true", help="skip the extra (untimed, informational) pass with the opt-in int8 engine")
@@ -1004,25 +1008,48 @@ def main():
     # ---- the timed region: W untimed steps, then exactly K steps between barrier + synchronize on both sides
     step, sync = make_step_and_sync(W, mx)
     reduction = "none (one GPU)"
+    reduction_info = {}
     if dist.is_initialized():
         reduction = "rccl all-reduce (torch.distributed, one process per GPU)" if os.environ.get("MXA_BENCH_BACKEND", "nccl") == "nccl" else "gloo all-reduce (rehearsal)"
+        reduction_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0}
     elif W.inprocess:
         reduction = "p2p"
-        if args.reduce == "rccl":
+        if args.reduce in ("auto", "rccl"):   # the timed reduction is RCCL's wherever RCCL applies; any failure falls back to p2p and is said in the line
             try:
                 if dg.multi_set_reduction(W.eng.obj, "rccl"):
                     reduction = "rccl"
                 else:
-                    reduction = "p2p (--reduce rccl not applicable: several shards share a device, RCCL needs one rank per device)"
+                    reduction = "p2p (rccl not applicable: several shards share a device, RCCL needs one rank per device)"
             except RuntimeError as ex:
-                reduction = f"p2p (--reduce rccl failed: {ex})"
+                reduction = f"p2p (rccl failed: {ex})"
+                try:
+                    dg.multi_set_reduction(W.eng.obj, "p2p")
+                except RuntimeError:
+                    pass
     for _ in range(args.warmup):
         step()
     sync()
     L.mxa_profile_reset()
     if W.inprocess:
         L.mxa_multi_reset_profile(W.eng.obj)
-    dt = run_timed(W, step, sync, 0, args.steps)
+    try:
+        dt = run_timed(W, step, sync, 0, args.steps)
+    except RuntimeError as ex:
+        if not (W.inprocess and reduction == "rccl"):
+            raise
+        # RCCL came up but a reduction failed (the first one is cross-checked against the peer-to-peer sum inside the library): p2p, said in the line
+        reduction = f"p2p (rccl failed in the timed region: {ex})"
+        dg.multi_set_reduction(W.eng.obj, "p2p")
+        for _ in range(max(1, args.warmup)):
+            step()
+        sync()
+        L.mxa_profile_reset()
+        L.mxa_multi_reset_profile(W.eng.obj)
+        dt = run_timed(W, step, sync, 0, args.steps)
+    if W.inprocess:
+        info0 = dg.multi_info(W.eng.obj)
+        reduction_info = {"rccl_ranks": info0["shards"] if reduction == "rccl" else 0, "rccl_checked": bool(info0["rccl_checked"]),
+                          "rccl_vs_p2p_max_rel_diff": info0["rccl_vs_p2p_max_rel_diff"], "devices": info0["devices"]}
     launches, total_ms = kernel_profile(L)
     adj_err = adjoint_check(W)
     flops_step = 2 * 2.0 * snps * indiv * n
@@ -1157,7 +1184,7 @@ def main():
             "metric": "effective GFLOP/s for dgemm_compressed (2-bit SNP x fp64)",
             "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": W.n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic", "reduction": reduction,
+            "dtype": "f64", "data": "synthetic", "reduction": reduction, **reduction_info,
             "config": {"workload": f"{snps} SNPs x {indiv} indiv, ncol={n}, dgemm_compressed 'N' + 'T' per step, "
                                    f"{'centred' if args.centered else 'uncentred'}, SNP-sharded over {W.n_gpus} GPU(s)"
                                    + (" inside one process behind the C ABI (MIRACULIX_NUM_GPUS), operands per shard on the shards' devices" if W.inprocess else ""),

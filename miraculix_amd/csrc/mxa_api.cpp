@@ -299,9 +299,13 @@ static int ensure_workspace(Handle *h, int n) {
 thread_local int tl_single_override = -1;
 
 int single_orientation_policy() {
+  // Round 5: ONE packed copy (SNP-major) is the default -- both products read it at the rate two copies reach (fp64 MFMA: plain form = transposed form =
+  // 0.957-0.962 of the peak; the CG step within 2 %), for half the HBM and half the staging.  MXA_SINGLE_ORIENTATION=0 asks for both copies (the opt-in: 'N'
+  // with 4 <= n <= 6 columns then runs the plain int8 kernel in one pass instead of two); they are kept when they fit the device's free memory, otherwise
+  // one copy is kept and a line on stderr says so (the reference reports "Not enough device memory" there, cuda_utils.cu:162-185).
   const char *e = getenv("MXA_SINGLE_ORIENTATION");
-  if (!e || !*e || !strcmp(e, "auto")) return 2;
-  return atoi(e) != 0 ? 1 : 0;
+  if (!e || !*e) return 1;
+  return atoi(e) != 0 ? 1 : 2;
 }
 
 size_t object_footprint(long snps, long indiv, int max_n, bool single) {
@@ -345,8 +349,8 @@ int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink
   const size_t bounce = ptr_location(plink, &src_dev0) == 1 ? 0 : (size_t)256 << 20;
   const size_t tmp_two = one_pointer ? (size_t)indiv * (((size_t)snps + 3) / 4) + bounce : bounce, tmp_one = bounce;
   const bool single0 = policy == 1 || (policy == 2 && need_two + tmp_two > free_b && need_one + tmp_one <= free_b);
-  if (single0 && policy == 2 && (env_print_level() > 0 || o.print_level > 0))
-    printf("miraculix_amd - dgemm_compressed: two packed copies need %.1f GB, %.1f GB are free: keeping the SNP-major copy only (%.1f GB).\n", need_two / 1e9, free_b / 1e9, need_one / 1e9);
+  if (single0 && policy == 2)   // always said: the caller asked for two copies (mxa_single_orientation() reports what the object holds)
+    fprintf(stderr, "miraculix_amd - dgemm_compressed: two packed copies need %.1f GB, %.1f GB are free: keeping the SNP-major copy only (%.1f GB).\n", need_two / 1e9, free_b / 1e9, need_one / 1e9);
   const size_t need = single0 ? need_one : need_two;
   if (need > free_b) {
     set_error(12, "Not enough device memory available. Required %zu GB, free %zu GB, total on device %zu GB", need >> 30, free_b >> 30, total_b >> 30);
@@ -629,7 +633,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   if (small_ok && n <= kSmallNMaxColsHost && !(engine == 2 && n <= 4)) {   // (engine 2: the unguarded slicing for n <= 4 below)
     const char *e_tn = getenv("MXA_I8_TN");   // A/B (read per call): n <= 2 from the copy whose rows are the K index
     const bool tn_ab = e_tn && atoi(e_tn) != 0;
-    const PackedMatrix *G_tn = no_plain ? G_tn_single : (tn_ab && n <= 2) ? &gemm_operand(h, trans, true) : nullptr;
+    const PackedMatrix *G_tn = no_plain ? G_tn_single : (tn_ab && n <= 2 && !h->single) ? &gemm_operand(h, trans, true) : nullptr;   // (the A/B needs both stored copies)
     int splits8 = 1;
     const int *d_flag = nullptr;
     const int rcx = guarded_small(0, n, G_tn, pe0, pe1, &splits8, &d_flag);
@@ -817,11 +821,12 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
   if (!b_local) { if (grow(&w.d_Bstage, &w.cap_Bstage, (size_t)k * n)) return 1; dB = w.d_Bstage; dldb = k; }
   double *dC = C; long dldc = ldc;
   if (!c_local) { if (grow(&w.d_Cstage, &w.cap_Cstage, (size_t)fill_rows * n)) return 1; dC = w.d_Cstage; dldc = fill_rows; }
-  // column peel as in gemm_device: the 1-2 odd columns go first (their part of B is uploaded ahead of the pipeline) through the guarded
-  // exact int8 route; the K-range / row-range pipeline then multiplies the multiple of 4
+  // column peel as in gemm_device: the 1-3 odd columns go first (their part of B is uploaded ahead of the pipeline) through the same guarded exact int8
+  // route -- gemm_device itself on those columns, so that the host path stays bitwise the device path --; the K-range / row-range pipeline then multiplies
+  // the multiple of 4
   const int n_all = n, n_odd = n & 3;
   bool b_uploaded = false;
-  if (engine == 0 && n > 4 && (n_odd == 1 || n_odd == 2) && k >= 128 && !(h->single && !trans)) {
+  if (engine == 0 && n > kSmallNMaxColsHost && n_odd != 0 && k >= 128) {
     const int n4 = n - n_odd;
     if (!b_local) {
       if (kmode) MXA_HIP(copy_columns(w.d_Bstage + (size_t)n4 * k, sizeof(double) * k, B + (size_t)n4 * ldb, sizeof(double) * ldb, sizeof(double) * k, n_odd, s));
@@ -831,11 +836,8 @@ static int gemm_host_pipelined(Handle *h, bool trans, int n, const double *B, lo
         b_uploaded = true;
       }
     }
-    if (centered && launch_colsums(dB + (size_t)n4 * dldb, dldb, k, n_odd, trans ? nullptr : h->d_f, d_sumscratch, d_sumB + n4, d_sumfB + n4, s)) return 1;
-    const int rc8 = gemm_i8_device(G, trans, n_odd, dB + (size_t)n4 * dldb, dldb, dC + (size_t)n4 * dldc, dldc, fill_rows, centered, d_sumB + n4, d_sumfB + n4, h->d_f, w, s,
-                                   nullptr, nullptr, nullptr, true);
-    if (rc8 == 0) n = n4;
-    else if (rc8 != 2) return 1;
+    if (gemm_device(h, trans, n_odd, dB + (size_t)n4 * dldb, dldb, dC + (size_t)n4 * dldc, dldc, fill_rows, s, false)) return 1;
+    n = n4;
   }
   const GemmPlan p = plan_gemm(m, G.k_pad, n);
   bool tr = gemm_use_tr(p, h, trans);

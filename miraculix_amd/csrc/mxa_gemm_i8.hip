@@ -1104,6 +1104,8 @@ static int plan_i8_full(const PackedMatrix &G, int n, int S_override, const Pack
   // fp64 MFMA tile would take, or with several column chunks, the caller's fp64 path is the better choice: declined with 2 before anything is enqueued)
   if (G_tn != nullptr && (p.nchunks != 1 || p.NT > (n <= 4 ? 2 : 5))) return 2;
   f.tn = G_tn != nullptr;
+  // host-side operand check before anything is enqueued: a kernel must never be handed the dimensions-only descriptor of a copy that is not stored
+  if ((f.tn ? G_tn->d : G.d) == nullptr) { set_error(4, "internal: the int8 route was given a packed matrix that is not stored (single-orientation object)"); return 1; }
   f.tn_strips = f.tn_stages = 0; f.tn_pc = TnPieces{1, 0, 0};
   if (f.tn) {
     if (G_tn->k != m || G_tn->rows != k) { set_error(4, "internal: transposed operand has the wrong shape"); return 1; }

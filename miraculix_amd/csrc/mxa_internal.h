@@ -115,9 +115,9 @@ Geometry &last_geometry();
 // device < 0: taken from HIP_DEVICE / CUDA_DEVICE / the current device
 int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink_t, size_t plink_t_pitch, long snps, long indiv,
                   const double *f, int max_n, void **out, int device = -1);
-// MXA_SINGLE_ORIENTATION: 0 = always both copies, 1 = always the SNP-major copy alone, unset / "auto" (2) = both copies unless they do not fit the
-// device's free memory while one copy does.  mxa_multi.cpp decides once per object (all shards alike) and tells its workers' create_handle calls
-// through tl_single_override (-1: decide here).
+// MXA_SINGLE_ORIENTATION (round 5): unset / 1 = the SNP-major copy alone (default), 0 = both copies while they fit the device's free memory (returned as
+// policy 2: if they do not fit and one copy does, one copy is kept and a line on stderr says so).  mxa_multi.cpp decides once per object (all shards alike)
+// and tells its workers' create_handle calls through tl_single_override (-1: decide here).
 int single_orientation_policy();
 size_t object_footprint(long snps, long indiv, int max_n, bool single);   // device bytes of a staged object: packed copies (tile padding included) + workspace
 extern thread_local int tl_single_override;

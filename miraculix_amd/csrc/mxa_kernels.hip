@@ -743,6 +743,7 @@ static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, c
 int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, int mode, hipStream_t s, int *d_ctr, int split_begin, int split_end,
                 const int *run_if_set, bool tr) {
   if (split_end < 0) split_end = p.splits;
+  if (!G.d) { set_error(4, "internal: k_gemm was given a packed matrix that is not stored (single-orientation object)"); return 1; }
   if (tr) {   // transposed operand: output rows = columns of G (its k individuals), K = rows of G in slabs of 128
     if ((long)p.slabs_total * kSlabK > G.rows_pad || G.nslabs < 1 || (mode != 0 && mode != 3)) {
       set_error(4, "internal: transposed launch does not fit the packed matrix (K slabs %d x 128 > %ld rows) or mode %d", p.slabs_total, G.rows_pad, mode);
@@ -941,6 +942,7 @@ static_assert(kPlanWaves == kWaves && kPlanSlabSteps == kSlabSteps && kPlanSlabK
               "mxa_plan.h restates the kernels' geometry for the host-only planners");
 
 int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double *dP, const GemmPlan &p, hipStream_t s, const int *run_if_set) {
+  if (!G.d) { set_error(4, "internal: k_lut was given a packed matrix that is not stored (single-orientation object)"); return 1; }
   if (p.m_pad > G.rows_pad || (size_t)p.slabs_total * (kLutKS / 4) > G.pitch) { set_error(4, "internal: packed matrix smaller than the lookup plan"); return 1; }
   if (p.n_pad == 1) return launch_lut_t<1, kLutKS>(G, dB, ldb, n, dP, p, s, run_if_set);
   if (p.n_pad == 2) return launch_lut_t<2, kLutKS>(G, dB, ldb, n, dP, p, s, run_if_set);

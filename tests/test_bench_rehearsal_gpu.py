@@ -23,6 +23,7 @@ def test_bench_two_ranks_one_gpu_gloo():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "strong" and out["dtype"] == "f64"
     assert "all-reduce" in out["reduction"] and out["predicted_ms_per_step_from_per_shard"]["from_this_run"] > 0
+    assert out["world_size"] == 2 and out["backend"] == "gloo" and out["rccl_ranks"] == 0          # the line records what ran the collective (rehearsal: gloo)
     assert out["unit"] == "GFLOP/s" and out["value"] > 0 and out["higher_is_better"] is True
     assert out["check"]["adjoint_identity_max_rel_err"] <= 1e-10          # 'N' (all-reduced over the ranks) against 'T' (sharded)
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
@@ -97,6 +98,8 @@ def test_bench_inprocess_two_shards_behind_the_c_abi():
         assert s["k_gemm_launches"] == 4 and s["avg_k_gemm_ms"] > 0 and s["operand_copies_in"] == 0 and s["result_copies_out"] == 0
         assert s["peer_access_to_root"] == -1 and s["partial_pushes"] == 0      # one device: nothing to push
     assert "skipped" in out["rccl_reduction"]
-    assert out["reduction"] == "p2p" and out["predicted_ms_per_step_from_per_shard"]["from_this_run"] > 0
+    # --reduce auto: RCCL is the timed reduction wherever every shard has a device of its own; here the two shards share one, and the line says so
+    assert out["reduction"].startswith("p2p (rccl not applicable") and out["rccl_ranks"] == 0 and out["devices"] == 1
+    assert out["predicted_ms_per_step_from_per_shard"]["from_this_run"] > 0
     hub = out["hub_operands_on_first_device"]
     assert hub["value"] > 0 and len(hub["avg_copy_in_ms_per_shard"]) == 2

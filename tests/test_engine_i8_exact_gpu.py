@@ -15,6 +15,16 @@ pytestmark = pytest.mark.gpu
 U = 2.0 ** -53
 
 
+@pytest.fixture(autouse=True)
+def _both_copies():
+    """the opt-in engines at wide n multiply 'N' on the plain int8 kernel, which reads the individual-major copy: the objects of this module store BOTH
+    copies (MXA_SINGLE_ORIENTATION=0; a default object keeps the SNP-major copy alone and sends such an 'N' to the fp64 engine)"""
+    import os
+    os.environ["MXA_SINGLE_ORIENTATION"] = "0"
+    yield
+    os.environ.pop("MXA_SINGLE_ORIENTATION", None)
+
+
 @pytest.fixture(scope="module")
 def mx():
     import miraculix_amd as m

@@ -96,8 +96,24 @@ def test_sampled_rows_vs_dense_oracle(big):
 def test_exact_int8_engine_at_full_size(big):
     """engine i8-exact at 1M x 50k x 32: taken (standard-normal B needs 10-11 digits), adjoint identity, agreement with the fp64 engine, and the stated
     element-wise bound |error| <= 3.02 (S - 1) 2^-53 sum_k |z_k b_k| on 32 sampled individuals against the long-double dense oracle"""
+    import os
     torch, dg, mx = big["torch"], big["dg"], big["mx"]
     o = Oracle()
+    # the opt-in engines at wide n multiply 'N' on the plain int8 kernel, which reads the individual-major copy: an object with BOTH copies
+    # (MXA_SINGLE_ORIENTATION=0; the default object keeps the SNP-major copy alone and sends such an 'N' to the fp64 engine)
+    os.environ["MXA_SINGLE_ORIENTATION"] = "0"
+    try:
+        obj2 = dg.init_compressed(big["plink"], big["plink_t"], SNPS, INDIV, big["f"], N)
+    finally:
+        os.environ.pop("MXA_SINGLE_ORIENTATION", None)
+    big = dict(big, obj=obj2)
+    try:
+        _exact_int8_engine_body(big, torch, dg, mx, o)
+    finally:
+        dg.free_compressed(obj2)
+
+
+def _exact_int8_engine_body(big, torch, dg, mx, o):
     g = torch.Generator(device=big["dev"]); g.manual_seed(11)
     Y = torch.randn((N, SNPS), dtype=torch.float64, device=big["dev"], generator=g).t()
     X = torch.randn((N, INDIV), dtype=torch.float64, device=big["dev"], generator=g).t()

@@ -15,6 +15,15 @@ from _util import Oracle, make_B, make_problem
 pytestmark = pytest.mark.gpu
 
 
+def _two_copies(dg, prob, snps, indiv, n):
+    """an object that stores BOTH packed copies (MXA_SINGLE_ORIENTATION=0: the opt-in since round 5), so that each product can be computed in either form"""
+    os.environ["MXA_SINGLE_ORIENTATION"] = "0"
+    try:
+        return dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], n)
+    finally:
+        os.environ.pop("MXA_SINGLE_ORIENTATION", None)
+
+
 @pytest.fixture(scope="module")
 def mx():
     import miraculix_amd as m
@@ -36,7 +45,7 @@ def test_transposed_operand_is_bit_identical(mx, snps, indiv, n):
     o = Oracle()
     prob = make_problem(snps, indiv, n, seed=snps + n, missing_frac=0.05)
     dg = mx.dgemm_compressed
-    obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], n)
+    obj = _two_copies(dg, prob, snps, indiv, n)
     try:
         for centered in (0, 1):
             dg.set_options(use_gpu=True, not_center=not centered, verbose=0)
@@ -64,7 +73,7 @@ def test_transposed_operand_range_fallback_and_ld_padding(mx):
     dg = mx.dgemm_compressed
     L = mx.check_library_handle()
     dg.set_options(use_gpu=True, not_center=False, verbose=0)
-    obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], n)
+    obj = _two_copies(dg, prob, snps, indiv, n)
     try:
         ldb, ldc = snps + 3, indiv + 5
         B = make_B(snps, n, seed=4, ldb=ldb)

@@ -14,6 +14,15 @@ pytestmark = pytest.mark.gpu
 U = 2.0 ** -53
 
 
+def _two_copies(dg, prob, snps, indiv, n):
+    """an object that stores BOTH packed copies (MXA_SINGLE_ORIENTATION=0: the opt-in since round 5), so that each product can be computed in either form"""
+    os.environ["MXA_SINGLE_ORIENTATION"] = "0"
+    try:
+        return dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], n)
+    finally:
+        os.environ.pop("MXA_SINGLE_ORIENTATION", None)
+
+
 @pytest.fixture(scope="module")
 def mx():
     import miraculix_amd as m
@@ -37,7 +46,7 @@ def test_transposed_int8_route_matches_plain_and_oracle(mx, snps, indiv, n):
     o = Oracle()
     prob = make_problem(snps, indiv, n, seed=snps + 3 * n, missing_frac=0.03)
     dg = mx.dgemm_compressed
-    obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], n)
+    obj = _two_copies(dg, prob, snps, indiv, n)
     try:
         for centered in (0, 1):
             dg.set_options(use_gpu=True, not_center=not centered, verbose=0)

@@ -37,7 +37,11 @@ def _make(mx, prob, n, single, plink_t="given"):
         with _single():
             obj = dg.init_compressed(prob["plink"], None if plink_t is None else prob["plink_t"], prob["snps"], prob["indiv"], prob["f"], n)
     else:
-        obj = dg.init_compressed(prob["plink"], prob["plink_t"], prob["snps"], prob["indiv"], prob["f"], n)
+        os.environ["MXA_SINGLE_ORIENTATION"] = "0"            # both copies: the opt-in since round 5
+        try:
+            obj = dg.init_compressed(prob["plink"], prob["plink_t"], prob["snps"], prob["indiv"], prob["f"], n)
+        finally:
+            os.environ.pop("MXA_SINGLE_ORIENTATION", None)
     L = mx.check_library_handle()
     L.mxa_single_orientation.argtypes = [ctypes.c_void_p]
     assert L.mxa_single_orientation(obj) == (1 if single else 0)
@@ -167,9 +171,9 @@ def test_half_the_device_memory_shards_and_bed(mx, tmp_path):
 
 
 def test_two_copies_that_do_not_fit_keep_one(mx):
-    """MXA_SINGLE_ORIENTATION unset (auto): where the reference's pre-flight stops with "Not enough device memory" (cuda_utils.cu:162-185) because the two
-    packed copies do not fit, the object keeps the SNP-major copy alone if that fits -- same results (bit-identical on the fp64 MFMA path); with
-    MXA_SINGLE_ORIENTATION=0 the call fails like the reference's; a sharded object decides once for all its shards.  The device is filled with a
+    """MXA_SINGLE_ORIENTATION=0 (both copies asked for; one copy is the default since round 5): where the reference's pre-flight stops with "Not enough device
+    memory" (cuda_utils.cu:162-185) because the two packed copies do not fit, the object keeps the SNP-major copy alone if that fits and says so on stderr --
+    same results (bit-identical on the fp64 MFMA path); a sharded object decides once for all its shards.  The device is filled with a
     ballast tensor so that the case costs megabytes, not hundreds of gigabytes."""
     import torch
     from bench import synth_genotypes_device
@@ -184,7 +188,7 @@ def test_two_copies_that_do_not_fit_keep_one(mx):
     Bn = torch.randn((n, snps), dtype=torch.float64, device=dev, generator=g).t()
     Bt = torch.randn((n, indiv), dtype=torch.float64, device=dev, generator=g).t()
     dg.set_options(use_gpu=True, not_center=False, verbose=0)
-    os.environ.pop("MXA_SINGLE_ORIENTATION", None)
+    os.environ["MXA_SINGLE_ORIENTATION"] = "0"
 
     def products(obj):
         out = [dg.dgemm_compressed_main(False, obj, Bn, snps, indiv).clone(), dg.dgemm_compressed_main(True, obj, Bt, snps, indiv).clone()]
@@ -207,12 +211,6 @@ def test_two_copies_that_do_not_fit_keep_one(mx):
             assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
         finally:
             dg.free_compressed(obj)
-        os.environ["MXA_SINGLE_ORIENTATION"] = "0"
-        try:
-            with pytest.raises(RuntimeError, match="Not enough device memory"):
-                dg.init_compressed(plink, None, snps, indiv, f, n)
-        finally:
-            os.environ.pop("MXA_SINGLE_ORIENTATION", None)
         os.environ["MIRACULIX_NUM_GPUS"] = "3"
         try:
             obj = dg.init_compressed(plink, None, snps, indiv, f, n)
@@ -227,6 +225,7 @@ def test_two_copies_that_do_not_fit_keep_one(mx):
         finally:
             dg.free_compressed(obj)
     finally:
+        os.environ.pop("MXA_SINGLE_ORIENTATION", None)
         del ballast
         torch.cuda.empty_cache()
 
@@ -253,7 +252,7 @@ def test_bed_staging_under_a_memory_squeeze_keeps_one_copy(mx, tmp_path):
     Bn = torch.randn((n, snps), dtype=torch.float64, device=dev, generator=g).t()
     Bt = torch.randn((n, indiv), dtype=torch.float64, device=dev, generator=g).t()
     dg.set_options(use_gpu=True, not_center=False, verbose=0)
-    os.environ.pop("MXA_SINGLE_ORIENTATION", None)
+    os.environ["MXA_SINGLE_ORIENTATION"] = "0"
 
     def products(obj):
         out = [dg.dgemm_compressed_main(False, obj, Bn, snps, indiv).clone(), dg.dgemm_compressed_main(True, obj, Bt, snps, indiv).clone()]
@@ -287,5 +286,6 @@ def test_bed_staging_under_a_memory_squeeze_keeps_one_copy(mx, tmp_path):
             finally:
                 dg.free_compressed(obj)
     finally:
+        os.environ.pop("MXA_SINGLE_ORIENTATION", None)
         del ballast
         torch.cuda.empty_cache()

@@ -110,7 +110,8 @@ def test_guard_declines_and_fp64_tables_take_over(mx, case, n):
                 B = np.random.default_rng(1).standard_normal((n, k))
                 prev = dg.set_engine("f64-strict")
             C = _run(mx, obj, prob, trans, B)
-            assert dg.last_path() == ("k_lut" if case == "strict" else "k_small_n_fp64"), (case, trans)   # engine f64-strict: pair tables; else the fp64 chains behind the declined guard
+            # engine f64-strict: pair tables ('T'; 'N' of a one-copy object: the MFMA tile in its transposed form); else the fp64 chains behind the declined guard
+            assert dg.last_path() == (("k_lut" if trans else "k_gemm") if case == "strict" else "k_small_n_fp64"), (case, trans)
             with np.errstate(invalid="ignore", over="ignore"):
                 ref = o.dgemm_dense(trans, prob, B, 0)[:, :m]
                 abssum = o.dgemm_dense(trans, prob, np.abs(B), 0)[:, :m]
@@ -139,7 +140,7 @@ def test_zero_vector_short_k_and_mixed_columns(mx):
     try:
         B = np.random.default_rng(0).standard_normal((1, 100))
         C = _run(mx, obj, prob, 0, B)
-        assert dg.last_path() == "k_lut"
+        assert dg.last_path() == "k_gemm"                                # K < 128, 'N' of a one-copy object: the MFMA tile, transposed form ('T': the pair tables)
         ref = o.dgemm_dense(0, prob, B, 0)[:, :333]
         assert np.abs(C - ref).max() <= 1e-11 * np.abs(ref).max()
     finally:
