@@ -239,8 +239,9 @@ struct FragI8 { v4i lo, hi; };
 template <bool I8> struct XFrag { using type = v4i; using acc = v16f; };
 template <> struct XFrag<true> { using type = FragI8; using acc = v16i; };
 
-// second meeting point of a gang (round 4 experiment, MXA_XPROD_GANG_MID=1): the tiles of a gang start together but drift apart inside a 2.6 ms tile;
-// half way through the K range every member adds to the gang's counter and waits (bounded) for the others, so that the second half streams in step again
+// second meeting point of a gang (round 4; MXA_XPROD_GANG_MID = parts of the K range: 1 = no meeting, 2 = one meeting half way, the default): the tiles of a
+// gang start together but drift apart inside a 2.6 ms tile; half way through the K range every member adds to the gang's counter and waits for the others --
+// bounded by the join time and by 4 % of the tile's own duration, whichever is shorter -- so that the second half streams in step again
 struct GangMid { int *ctr; int target; unsigned ticks; int parts; int stride; };   // parts - 1 meetings inside a tile, meeting q uses ctr[(q - 1) * stride]
 template <bool DIAG, int EXP, bool I8, int POST>
 __device__ __forceinline__ void xprod_tile(const uint8_t *__restrict__ X, long nslabs, int stages, const int4 t, size_t tile_index, long n, double *__restrict__ ans,
@@ -472,7 +473,9 @@ k_crossprod_gang(const uint8_t *__restrict__ X, long nslabs, int stages, const i
       // (everything the stage loop's bounds depend on must be provably wave-uniform: the DMA bases and LDS addresses live in SGPRs)
       const int Pu = __builtin_amdgcn_readfirstlane(P), g = slot / Pu, members = __builtin_amdgcn_readfirstlane(min((g + 1) * Pu, slots_per_xcd) - g * Pu);
       const int idx = __builtin_amdgcn_readfirstlane(xcc * slots_per_xcd + g);
-      gm = GangMid{mid + idx, members, join_ticks, mid_parts, 8 * slots_per_xcd};
+      // the meeting's wait: at most the join bound, and at most ~4 % of this tile (stages x 0.66 us at the FP4 rate = 66 ticks of 10 ns per stage)
+      const unsigned mid_ticks = min(join_ticks, (unsigned)(2.64f * (float)stages));
+      gm = GangMid{mid + idx, members, mid_ticks, mid_parts, 8 * slots_per_xcd};
       if (!t.z && threadIdx.x == 0)   // a padding entry never reaches the meetings: counted here
         for (int q = 0; q + 1 < mid_parts; q++) __hip_atomic_fetch_add(gm.ctr + (size_t)q * gm.stride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -497,7 +500,7 @@ int launch_plink_lut(uint8_t *d, size_t nbytes, hipStream_t s) {
 // for 8 * sr tiles.  MXA_XPROD_XCD=0 keeps the plain order (A/B measurement).
 // Returns true when the list has the interleaved per-XCD form (false: left in plain order).
 static bool xcd_order_tiles(std::vector<int4> &tiles, int nb, int sr) {
-  static const bool on = [] { const char *e = getenv("MXA_XPROD_XCD"); return e ? atoi(e) != 0 : true; }();
+  constexpr bool on = true;
   if (!on || tiles.size() < 8 * 64 || sr < 1) return false;
   int i_min = tiles[0].x;
   for (const int4 &t : tiles) i_min = std::min(i_min, t.x);
@@ -527,7 +530,7 @@ static bool xcd_order_tiles(std::vector<int4> &tiles, int nb, int sr) {
 // the Infinity Cache).  Gang boundaries stay aligned with multiples of 32 slots in every list; with the 8 x 8 super-tiles of xcd_order_tiles one
 // partial super-tile (36 tiles on the diagonal) shifts every later gang of that list across two super-tile halves.
 static bool gang_order_tiles(std::vector<int4> &tiles) {
-  static const bool on = [] { const char *e = getenv("MXA_XPROD_XCD"); return e ? atoi(e) != 0 : true; }();
+  constexpr bool on = true;
   constexpr size_t kGang = 32;
   if (!on || tiles.size() < 8 * 64) return false;
   std::sort(tiles.begin(), tiles.end(), [](const int4 &a, const int4 &b) {
@@ -599,8 +602,9 @@ static int launch_tiles(bool f4, size_t ntiles, hipStream_t s, const uint8_t *d_
     const int slots = (int)(ntiles / 8);
     const dim3 pgrid((unsigned)std::max(8, std::min<int>(cus, (int)ntiles)));
     MXA_HIP(hipMemsetAsync(d_gang, 0, sizeof(int) * kGangCtrs, s));
-    // second meeting point (experiment): one counter per gang and XCD list, behind the 17 control counters when the caller's buffer has room for them
-    // MXA_XPROD_GANG_MID = number of parts a tile's K range is cut into (meetings = parts - 1): 0 / 1 none, 2 (default) one meeting half way through
+    // second meeting point: one counter per gang and XCD list, behind the 17 control counters when the caller's buffer has room for them
+    // MXA_XPROD_GANG_MID = number of parts a tile's K range is cut into (meetings = parts - 1): 0 / 1 none, 2 (default) one meeting half way through.
+    // The gang form is only taken for long tiles (stages >= 1024, i.e. K >= 131k: tiles of >= 0.7 ms), and the meeting's wait is bounded by 4 % of the tile.
     const char *e_mid = getenv("MXA_XPROD_GANG_MID");
     const int mid_parts = std::max(1, std::min(8, e_mid ? atoi(e_mid) : 2));
     int *d_mid = nullptr;
@@ -634,32 +638,8 @@ static int launch_tiles(bool f4, size_t ntiles, hipStream_t s, const uint8_t *d_
     return 0;
   }
   if (f4) {
-    static const int exp = [] { const char *e = getenv("MXA_XPROD_EXP"); return e ? atoi(e) : 0; }();
-    if (d_diag && exp == 1) {
-      static unsigned long long mx1 = 0;
-      if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true, 1>), kF4Lds, &mx1)) return 1;
-      hipLaunchKernelGGL((k_crossprod_f4<true, 1>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag, post);
-    } else if (d_diag && exp == 2) {
-      static unsigned long long mx2 = 0;
-      if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true, 2>), kF4Lds, &mx2)) return 1;
-      hipLaunchKernelGGL((k_crossprod_f4<true, 2>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag, post);
-    } else if (d_diag && exp == 3) {
-      static unsigned long long mx3 = 0;
-      if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true, 3>), kF4Lds, &mx3)) return 1;
-      hipLaunchKernelGGL((k_crossprod_f4<true, 3>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag, post);
-    } else if (d_diag && exp == 4) {
-      static unsigned long long mx4 = 0;
-      if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true, 4>), kF4Lds, &mx4)) return 1;
-      hipLaunchKernelGGL((k_crossprod_f4<true, 4>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag, post);
-    } else if (d_diag && exp == 5) {
-      static unsigned long long mx5 = 0;
-      if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true, 5>), kF4Lds, &mx5)) return 1;
-      hipLaunchKernelGGL((k_crossprod_f4<true, 5>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag, post);
-    } else if (d_diag && exp == 6) {
-      static unsigned long long mx6 = 0;
-      if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_crossprod_f4<true, 6>), kF4Lds, &mx6)) return 1;
-      hipLaunchKernelGGL((k_crossprod_f4<true, 6>), grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag, post);
-    } else if (d_diag) hipLaunchKernelGGL(k_crossprod_f4<true>, grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag, post);
+    // (the diagnostic EXP instantiations of round 2 -- no unpack, no DMA, barrier only ..., all with wrong results -- were removed in round 5; what they measured: profiles/r02_mfma_f4_probe.txt)
+    if (d_diag) hipLaunchKernelGGL(k_crossprod_f4<true>, grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag, post);
     else hipLaunchKernelGGL(k_crossprod_f4<false>, grid, block, kF4Lds, s, d_X, nslabs, stages, d_tiles, rows, d_ans, ld, c0, d_diag, post);
   } else {
     static unsigned long long i0 = 0, i1 = 0;
@@ -696,7 +676,7 @@ int crossprod_device(const uint8_t *d_X, long k, long rows, size_t pitch, double
       if (flags) tiles.push_back(make_int4(i, j, flags, 0));
     }
   if (tiles.empty()) return 0;
-  static const int gang_order = [] { const char *e = getenv("MXA_XPROD_GANG_ORDER"); return e ? atoi(e) : 1; }();   // 0: the 8 x 8 super-tiles (A/B)
+  constexpr int gang_order = 1;   // (0: the 8 x 8 super-tiles of round 2, the A/B baseline)
   const bool xcd_lists = gang_order ? gang_order_tiles(tiles) : xcd_order_tiles(tiles, nb, 8);
   XBuf d_tiles, d_diag, d_gang;
   const size_t mid_cap = 7 * (tiles.size() + 64);      // >= 8 lists x slots per list x up to 7 meetings per tile
@@ -741,7 +721,7 @@ static int crossprod_to_host(const uint8_t *d_X, long k, long rows, size_t pitch
   const long slab_bytes = (slab_env && atol(slab_env) > 0 ? atol(slab_env) : 1024L) << 20;
   const int rows_per_chunk = (int)std::max<long>(1, slab_bytes / (rows * 8 * kXT));         // ~1 GiB column slabs
   const int nchunks = (nb + rows_per_chunk - 1) / rows_per_chunk;
-  static const int gang_order = [] { const char *e = getenv("MXA_XPROD_GANG_ORDER"); return e ? atoi(e) : 1; }();
+  constexpr int gang_order = 1;
   // one tile list per chunk of tile rows, each in XCD-aware order (super-tiles = the chunk's rows x 8 tile columns)
   std::vector<int4> tiles;
   std::vector<size_t> first((size_t)nchunks + 1, 0);
@@ -845,7 +825,7 @@ static int crossprod_to_host_ring(const uint8_t *d_X, long k, long rows, size_t 
   const size_t slot_elems = (size_t)rows * (size_t)std::min<long>(rows, (long)tcols * kXT);
   XBuf ring[kRing], d_tiles, d_gang;
   for (auto &r : ring) if (r.alloc(slot_elems * sizeof(double))) return 1;
-  static const int gang_order = [] { const char *e = getenv("MXA_XPROD_GANG_ORDER"); return e ? atoi(e) : 1; }();
+  constexpr int gang_order = 1;
   // tile lists of all slabs, one after the other (uploaded once)
   std::vector<int4> tiles;
   std::vector<size_t> first((size_t)nchunks + 1, 0);
@@ -1155,11 +1135,22 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
       debug_info("crossproduct call: %-34s %.3f s (at %.3f s)", what, std::chrono::duration<double>(now - last).count(), std::chrono::duration<double>(now - t0).count());
       last = now;
     }
-  } clk(!in_dev || !out_dev);
+  } clk(true);   // (round 5: for device operands too -- the operand is re-tiled into a buffer allocated per call, and hipMalloc of 12.5 GB takes 0-1.3 s on this pool)
   XStream st;
   if (st.create(hipStreamDefault)) return 1;   // blocking: ordered against the caller's default-stream work
   hipStream_t s = st.s;
   XBuf d_X, bounce, d_out, d_flag, f_tmp;
+  // the n x n device buffer of a host result that does not take the slab ring: checked against the free memory first, so that what does not fit is reported
+  // like the reference's pre-flight (cuda_utils.cu:162-185) instead of as a raw hipMalloc failure
+  auto alloc_result = [&](XBuf &b, size_t bytes) -> int {
+    size_t fb = 0, tb = 0;
+    if (hipMemGetInfo(&fb, &tb) == hipSuccess && bytes > fb) {
+      set_error(12, "Not enough device memory available. Required %zu GB, free %zu GB, total on device %zu GB", bytes >> 30, fb >> 30, tb >> 30);
+      return 1;
+    }
+    (void)hipGetLastError();
+    return b.alloc(bytes);
+  };
   if (d_X.alloc(xbytes) || d_flag.alloc(sizeof(int))) return 1;
   clk.mark("operand buffer allocated");
   MXA_HIP(hipMemsetAsync(d_X.p, 0, xbytes, s));
@@ -1211,7 +1202,7 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
     }
   }
   if (!out_dev && !use_ring) {
-    if (d_out.alloc(abytes)) return 1;
+    if (alloc_result(d_out, abytes)) return 1;
     d_ans = (double *)d_out.p;
     if (upper_only) MXA_HIP(hipMemsetAsync(d_ans, 0, abytes, s));   // the untouched part travels back as zeros
     clk.mark("device result buffer allocated");
@@ -1266,7 +1257,7 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
     return rc;
   }
   if (use_ring) {   // unfused post-processing needs the whole matrix on the device after all
-    if (d_out.alloc(abytes)) return 1;
+    if (alloc_result(d_out, abytes)) return 1;
     d_ans = (double *)d_out.p;
     start_prefault();
   }
@@ -1279,8 +1270,10 @@ static int crossprod_any(const unsigned char *snp_matrix, long k, long rows, dou
   }
   if (crossprod_device((const uint8_t *)d_X.p, k, rows, pitch, d_ans, s, c_begin, c_end, upper_only, ld, f4, post_kind, &xp)) return 1;
   if (post && !post_kind && postprocess_device(d_ans, rows, k, post, do_scale, d_f, s)) return 1;
+  clk.mark("tile list built, product enqueued");
   if (!out_dev) MXA_HIP(hipMemcpyAsync(ans, d_ans, abytes, hipMemcpyDeviceToHost, s));
   MXA_HIP(hipStreamSynchronize(s));
+  clk.mark("product (and download) finished");
   return 0;
 }
 

@@ -280,7 +280,9 @@ constexpr int kMaxI8Splits = 64;
 struct SplitTab { int begin[kMaxI8Splits + 1]; };
 static SplitTab make_split_tab(int stages_total, int splits, int max_len) {
   SplitTab t{};
-  static const double taper = [] { const char *e = getenv("MXA_I8_TAPER"); return e ? atof(e) : 0.0; }();   // A/B (measured: no gain for k_gemm_i8_tn, a loss for k_gemm_i8, whose XCD-dealt groups want equal work): uniform lengths
+  // uniform lengths.  A taper (lengths from 1.4x to 0.6x of the mean, longest dispatched first) was measured: no gain for the transposed-operand kernel, a LOSS for
+  // k_gemm_i8, whose XCD-dealt groups want equal work (profiles/r05_i8_taper_ab.txt: config-5 shard 'N' 0.964 -> 0.999 ms).  The table form is kept.
+  constexpr double taper = 0.0;
   const double mean = (double)stages_total / splits;
   double acc = 0.0;
   t.begin[0] = 0;
