@@ -137,10 +137,9 @@ void mxa_plink2compressed_shard(char *plink, char *plink_transposed, int snps_to
 
 /* dgemm_compressed with 64-bit leading dimensions on an explicit HIP stream (NULL = the object's own stream),
  * device pointers only, asynchronous when sync == 0.  Returns 0 / 1.
- * (Asynchronous with one exception, here and in mxa_dgemm_compressed_multi: under the default engine a product with 3 <= n <= 6, or with
- * n = 4q + 3 > 6 peeled columns, and every product of engine `i8-exact`, chooses its digit count from three integers read back from the device:
- * the calling thread -- in a multi-device object each shard's worker -- then waits for the work enqueued before it.  n <= 2 and the fp64 MFMA
- * products n = 4q, 4q + 1, 4q + 2 >= 7 never wait.)
+ * Asynchronous for EVERY n under the default engine (round 5): the verdict of the exact int8 route of narrow products and peeled columns is formed on
+ * the device; nothing is read back.  (The first call of a new shape on an object may grow its workspace, which waits for the stream once; the opt-in
+ * engine `i8-exact` reads three integers per call, as documented with it.)
  * ONE CALL IN FLIGHT PER OBJECT: every multiply on an object uses that object's workspace (fragment-ordered B, split-K
  * partials, column sums).  Calls on the same object must therefore be serialised on ONE stream (or the caller must wait
  * for the previous call before issuing the next on another stream); this includes mxa_gram_matvec and dgemm_compressed.
@@ -157,8 +156,7 @@ int mxa_gram_matvec(void *compressed, int n, const double *V, long ldv, double *
  * enqueued on the object's stream -- a blocking stream, so work the caller enqueues afterwards on the device's default stream (PyTorch, hipBLAS
  * on stream 0) is ordered behind it and a CG / GBLUP loop on device-resident vectors never waits on the host: the ~40 us between two
  * synchronous calls (return, caller, next launch) disappear from every iteration.  Single-device objects only.  Returns 0 / 1.
- * (n <= 2 -- the CG / GBLUP case -- never waits on the host.  For n >= 3 a product that takes the exact int8 route with per-call digits (engine 0:
- * 3 <= n <= 6 and peeled columns; engine 4: every n) reads three integers back first, i.e. the call blocks for the work enqueued before it.) */
+ * (No n waits on the host under the default engine: see mxa_dgemm_compressed_device.) */
 int mxa_gram_matvec_device(void *compressed, int n, const double *dV, long ldv, double *dOut, long ldo, int sync);
 
 /* on-device .bed staging helpers (reference counterparts live in the bindings:
@@ -302,10 +300,12 @@ int mxa_ld(const unsigned char *plink, int snps, int indiv, double *R, int is_pl
  *    the only roundings are the <= 31 additions of the recombination, and |error| <= 3.02 * 31 * 2^-53 * sum_k |z_k b_k| per
  *    output -- tighter than the K * 2^-53 * sum_k |z_k b_k| of any fp64 FMA chain of length K >= 128.  If the check fails (or
  *    K < 128) the fp64 pair-table kernel runs instead; results then and with engine 3 are fp64 lookup-add sums.
- *    3 <= n <= 6 (the products that would run on the narrowest MFMA tile, which the genotype extraction holds at 0.80 of the fp64 MFMA
- *    rate): the same exact route with the digit count chosen per call as engine 4 does -- taken only when B is represented without
- *    error (same bound with S <= 24), else the fp64 MFMA path; 1.2-1.7 ms instead of 3.2-4.4 ms on 500k x 50k.  n >= 7: fp64 MFMA, the
- *    one or two odd columns of n = 4q + 1, 4q + 2 through the exact route when it is exact.  MXA_AUTO_EXACT_MAX_N=0 keeps n >= 3 on fp64.
+ *    3 <= n <= 6 (the products that would run on the narrowest MFMA tile, which the genotype extraction holds at 0.80 of the fp64 MFMA rate) take the
+ *    same exact route.  Digits per column = what fits the tiles of 32 expanded columns: n = 3: 10 (one tile) or 21 (two), 4: 16 or 24, 5: 12 or 19,
+ *    6: 10 or 16.  The verdict is a CLASS formed on the device (round 5): exact with the smaller count, exact with the larger one, or neither; the kernels of
+ *    both classes are enqueued and each tests one flag word, so no product waits for the host.  Class "neither" (span beyond the digits, inf / NaN, a
+ *    column near the underflow threshold): plain fp64 FMA chains, one thread per output row, inside the same launch sequence.  1.0-1.5 ms instead of
+ *    3.2-4.4 ms on 500k x 50k.  n >= 7: fp64 MFMA; the 1-3 odd columns of n = 4q + r through the same guarded route.
  * 1 (opt-in, also MXA_ENGINE=i8 in the environment): the int8 slicing for every n with 7 digits (32 / 16 for n = 1 / 2) and NO
  *    exactness check: B is represented to 2^-54 of each column's largest |entry| (fixed point per column, not per element);
  *    results agree with engine 0 to ~1e-14 of each result column's largest entry on the test problems, at ~4x the throughput.
@@ -318,7 +318,9 @@ int mxa_ld(const unsigned char *plink, int snps, int indiv, double *R, int is_pl
  *    entry lies below 2^(8S - 1023), or K < 128: engine 0's path.  Typical data (spans of 15-30 binades) need 9-11 digits; the product is
  *    then 2-3 times faster than the fp64 matrix cores allow.  n <= 2: as engine 0.  One host synchronisation per call.
  * mxa_set_engine returns the previous value (an invalid argument leaves the engine unchanged).  mxa_last_path: kernel family of
- * the most recent product: 0 = fp64 MFMA (k_gemm), 1 = fp64 pair tables (k_lut), 2 = int8 slicing (k_gemm_i8). */
+ * the most recent product: 0 = fp64 MFMA (k_gemm), 1 = fp64 pair tables (k_lut: engine f64-strict and K < 128, where the stored copy's rows are the
+ * output rows), 2 = exact int8 slicing (k_gemm_i8 / k_gemm_i8_tn), 3 = the fp64 chains behind a declined exactness guard (the verdict is read from the
+ * device when this is called). */
 int mxa_set_engine(int engine);
 int mxa_get_engine(void);
 int mxa_last_path(void);
@@ -342,16 +344,19 @@ void mxa_last_geometry(long *m, long *k, int *n, int *splits, int *a_tile, int *
 /* doubles of split-K partial sums the fp64 MFMA launch of an m x k x n product writes (no device needed: tests check that the plan of the
  * columns left after a peel, which can be LARGER than the plan of all n columns, never outgrows the workspace) */
 long mxa_plan_partial_doubles(long m, long k, int n);
-/* Single-orientation objects (round 4; a property of the object from plink2compressed / mxa_bed2compressed / mxa_plink2compressed_shard on).
- * MXA_SINGLE_ORIENTATION in the environment of that call: 1 = always, 0 = never, unset or "auto" = only when the two packed copies do NOT fit the
- * device's free memory while one does -- where the reference reports "Not enough device memory" (cuda_utils.cu:162-185) this build keeps one copy and
- * carries on (a line under PRINT_LEVEL > 0 says so); a multi-device object decides once for all its shards.  Only the SNP-major copy is stored -- half the HBM (config 5 at its
- * full 2M x 100k: 50 GB instead of 100) and half the staging upload; plink_transposed is not read.  Both products then read that one copy: 'T' in
- * the plain form, 'N' in the transposed-operand forms (fp64 MFMA: k_gemm<..., TR>, as fast as with two copies; the exact int8 route of n <= 6 and
- * of the peeled odd columns: k_gemm_i8_tn, one pass over the matrix per tile of 32 expanded columns -- n <= 3: one pass, ~10 % slower than the plain
- * int8 kernel (a CG step 2.08 ms against 1.98 on 250k x 100k); n = 4..6: two passes, 2.2 ms against 1.4 on 500k x 50k, still ahead of the fp64 tile).  Results are those of a two-copy object to
- * rounding (bit-identical on the fp64 MFMA path).  What is given up: the opt-in engines i8 / i8-exact at wide n apply to 'T' only; 'T' with
- * n >= 7 runs the plain fp64 MFMA form (0.925 instead of 0.957 of the peak).  mxa_single_orientation: 1 / 0 (multi-device object: of its shards), -1 for an invalid handle. */
+/* One packed copy per object (round 5 default; a property of the object from plink2compressed / mxa_bed2compressed / mxa_plink2compressed_shard /
+ * mxa_plink2compressed_begin on).  Only the SNP-major copy is stored -- half the HBM (config 5 at its full 2M x 100k: 50 GB instead of 100; config 4 at its
+ * full 5M x 200k: 250 GB, on one device) and half the staging upload; plink_transposed is not read.  Both products read that one copy: 'T' in the plain
+ * form of k_gemm (output rows = packed rows), 'N' in the transposed-operand form (output rows = packed columns); since round 5 the two forms share one
+ * permuted K order and run at the same rate (0.957-0.962 of the fp64 MFMA peak at BASELINE config 2; bit-identical results).  The exact int8 route of
+ * n <= 6 and of peeled columns: 'T' on k_gemm_i8, 'N' on k_gemm_i8_tn (one pass over the matrix per tile of 32 expanded columns -- n <= 3: one pass, a CG
+ * step within 2 % of a two-copy object's; n = 4..6: two passes, 2.0 ms against 1.3 on 500k x 50k, still ahead of the fp64 tile).
+ * MXA_SINGLE_ORIENTATION=0 in the environment of the creating call asks for BOTH copies (what rounds 1-4 stored): 'N' then runs the plain kernels
+ * everywhere, and the opt-in engines i8 / i8-exact apply to both products at wide n (on a one-copy object: to 'T' only).  If the two copies do not fit the
+ * device's free memory and one does, one is kept and a line on stderr says so (the reference reports "Not enough device memory" there,
+ * cuda_utils.cu:162-185); a multi-device object decides once for all its shards.  Results of one-copy and two-copy objects agree to rounding
+ * (bit-identical on the fp64 MFMA path and for integer-valued operands).  mxa_single_orientation: 1 / 0 (multi-device object: of its shards), -1 for an
+ * invalid handle. */
 int mxa_single_orientation(void *compressed);
 /* capacity (doubles) of the partial-sum workspace an object holds right now; -1 for an invalid / multi-device object */
 long mxa_partial_capacity(void *compressed);
