@@ -361,9 +361,28 @@ def config5_cg_step_leg(torch, mx, L, dev, snps=250_000, indiv=100_000, reps=20)
         err_t = sampled_rows_vs_oracle(torch, S, 1, v, T, [0], 1, nsample=32)
         err_n = sampled_rows_vs_oracle(torch, S, 0, T, N, [0], 1, nsample=32)
         same = bool(torch.equal(out, N))
-        bytes_step = 2.0 * snps * ((indiv + 3) // 4)      # both packed orientations, once each
+        bytes_step = 2.0 * snps * ((indiv + 3) // 4)      # the packed matrix is read twice per step (one copy twice, or each of two copies once)
         tbs = bytes_step / t_step * 1e-12
+        # the same step on an object that stores BOTH packed copies (MXA_SINGLE_ORIENTATION=0, the opt-in since round 5): 'N' on the plain int8 kernel
+        old_so = os.environ.get("MXA_SINGLE_ORIENTATION")
+        os.environ["MXA_SINGLE_ORIENTATION"] = "0"
+        try:
+            obj2 = dg.init_compressed(S["plink"], S["plink_t"], snps, indiv, S["f"], 1)
+        finally:
+            if old_so is None:
+                os.environ.pop("MXA_SINGLE_ORIENTATION", None)
+            else:
+                os.environ["MXA_SINGLE_ORIENTATION"] = old_so
+        try:
+            out2 = torch.zeros((1, indiv), dtype=torch.float64, device=dev).t()
+            dg.gram_matvec(obj2, v, snps, indiv, out=out2)
+            t_two = timed(lambda: dg.gram_matvec(obj2, v, snps, indiv, out=out2), sync, reps)
+            two_vs_one = float((out2 - out).abs().max() / out.abs().max())
+        finally:
+            dg.free_compressed(obj2)
         return {"workload": f"{snps} SNPs x {indiv} indiv (per-GPU shard of config 5), n=1, centred, one mxa_gram_matvec = 'T' + 'N'",
+                "object": "one packed copy (default): 'T' on k_gemm_i8, 'N' on k_gemm_i8_tn, both reading the SNP-major copy",
+                "ms_per_cg_step_two_copies": round(t_two * 1e3, 4), "two_copies_vs_one_copy_max_rel_err": two_vs_one,
                 "ms_per_cg_step": round(t_step * 1e3, 4), "ms_per_cg_step_back_to_back_no_host_wait": round(t_async * 1e3, 4), "kernel_path": path, "dominant_kernel_ms": {"T": round(ms_t / max(1, la_t), 4), "N": round(ms_n / max(1, la_n), 4)},
                 "algorithmic_TB_per_s": round(tbs, 3), "frac_of_8_TBs_spec": round(tbs / 8.0, 4), "frac_of_7.0_TBs_read_ceiling": round(tbs / 7.0, 4),   # 7.0: what one MI355X reads with non-temporal loads (tools/hbm_read_probe.hip; 6.3-6.5 with the default policy)
                 "check": {"T_32_sampled_rows_vs_dense_oracle_max_rel_err": err_t, "N_32_sampled_rows_vs_dense_oracle_max_rel_err": err_n,
@@ -1195,7 +1214,8 @@ def main():
                          "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "GB per launch, measured by this run (two rocprofv3 --pmc child passes of the same workload)", "traffic_detail": traffic_detail,
                          "algorithmic_bytes_per_launch_GB": round((W.snps_loc / W.n_shards * ((indiv + 3) // 4) + 8.0 * (W.snps_loc / W.n_shards + indiv) * n) / 1e9, 3),
-                         "kernel": "k_gemm<8,8,3,TR> (v_mfma_f64_4x4x4_4b_f64; transposed-operand form: each product reads the copy whose rows are its K index)", "launches": launches, "avg_launch_ms": round(avg_ms, 3)},
+                         "kernel": "k_gemm<8,8,3> on v_mfma_f64_4x4x4_4b_f64, two launches per step on the ONE stored (SNP-major) copy: 'N' = k_gemm<8, 8, 3, false, true> "
+                                   "(transposed-operand form), 'T' = k_gemm<8, 8, 3, false, false> (plain form); same tile, same permuted K order, same rate", "launches": launches, "avg_launch_ms": round(avg_ms, 3)},
         }
         if W.n_gpus > 1:
             slowest = max(per_rank["avg_k_gemm_launch_ms"]) if per_rank is not None else avg_ms
