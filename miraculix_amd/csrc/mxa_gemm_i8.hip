@@ -570,23 +570,26 @@ constexpr int kTnSlabStride = kTileBytes + 64;                // LDS bytes betwe
 constexpr int kTnSlabs = 2;
 constexpr int kTnMaxPieces = 64;              // partial-sum slots per strip at most
 struct TnPieces { int c_lo, n_lo, nitems; };  // strips [0, n_lo): c_lo pieces each, the others c_lo + 1 (plan_i8_tn)
-template <int BUFS>
+template <int BUFS, int TT>
 struct TnCfg {
   static constexpr int kWaves = 4;
   static constexpr int kBufBytes = kTnSlabs * kTnSlabStride;        // packed rows of one stage: 2 slabs x 8 KiB (+ the bank offset)
   static constexpr int kLds = BUFS * kBufBytes < 4 * 8192 ? 4 * 8192 : BUFS * kBufBytes;   // at least the 32 KiB of the final reduction
   static constexpr int kPackedPerWave = kTnSlabs * 8 / kWaves;      // 4 DMA units per wave and stage
-  static constexpr int kOpsPerWave = kPackedPerWave + 2;            // + the wave's two digit loads: what vmcnt counts per stage
+  static constexpr int kOpsPerWave = kPackedPerWave + 2 * TT;       // + the wave's digit loads (two K-steps x TT tiles): what vmcnt counts per stage
   static constexpr int kDepth = BUFS - 1;                           // stages in flight
 };
+// TT = digit tiles (32 expanded columns each) per pass over the matrix.  TT = 1: n <= 2, peeled columns, n = 3 with few digits -- 128 accumulator registers,
+// two workgroups per CU, 4 buffers.  TT = 2 (round 5): 3 <= n <= 6 -- the byte gather of a K-step feeds the MFMAs of BOTH tiles, 256 accumulator registers,
+// one workgroup per CU (one wave per SIMD), 6 buffers = 5 stages in flight to cover the latency alone: ONE pass where round 4 took two.
 
-template <int BUFS>
-__global__ void __launch_bounds__(256, 2)
+template <int BUFS, int TT>
+__global__ void __launch_bounds__(256, TT == 1 ? 2 : 1)
 k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__restrict__ Ad, int digit_tiles, int *__restrict__ P, long m_pad, int e_pad, int e_off,
              int strips, int stages_total, TnPieces pc, const int *__restrict__ skip_if_set) {
   // Ad: the digit fragments of THIS launch's tile of 32 expanded columns, K-steps digit_tiles KiB apart (k_slice_B interleaves the tiles of a K-step);
   // the sums go to rows e_off .. e_off + 31 of P[split][e_pad][m_pad].  A product with several tiles (3 <= n <= 6, the opt-in engines) is one launch per tile.
-  using Cfg = TnCfg<BUFS>;
+  using Cfg = TnCfg<BUFS, TT>;
   constexpr int D = Cfg::kDepth, NSET = D + 1;
   if (skip_if_set && *skip_if_set) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -605,9 +608,13 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
   const int rho = (lane - 32) >> 1;
   const uint32_t v_pack = lane < 32 ? (uint32_t)lane * 16 : (uint32_t)(2 * (16 + ((rho + 15) & 15)) + (lane & 1)) * 16;
   const uint32_t v_lin = (uint32_t)lane * 16;
-  v4i dig[NSET][2];                                           // digit fragments of this wave's two K-steps, one register set per stage in flight (+ the one in use)
+  v4i dig[NSET][2][TT];                                       // digit fragments of this wave's two K-steps (x TT tiles), one register set per stage in flight (+ the one in use)
 #pragma unroll
-  for (int i = 0; i < NSET; i++) { dig[i][0] = v4i{0, 0, 0, 0}; dig[i][1] = v4i{0, 0, 0, 0}; }
+  for (int i = 0; i < NSET; i++)
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+      for (int tt = 0; tt < TT; tt++) dig[i][kk][tt] = v4i{0, 0, 0, 0};
   // all global traffic of one stage: 4 packed DMA units, then the two digit loads (asm: the compiler does not see the DMA, so it must not count vmcnt either)
   auto issue_packed = [&](int stage, int buf) {               // stage relative to st0
     const uint32_t base = lds0 + buf * Cfg::kBufBytes;
@@ -620,17 +627,21 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
       idma16_stream(reinterpret_cast<const char *>(G) + (rb * (size_t)nslabs_all + (size_t)sl) * kTileBytes + (u & 7) * 1024, v_pack, base + (u >> 3) * kTnSlabStride + (u & 7) * 1024);
     }
   };
-  auto issue_digits = [&](int stage, v4i &d0, v4i &d1) {
+  auto issue_digits = [&](int stage, v4i (&d)[2][TT]) {       // the tiles of a K-step are 1 KiB apart, the K-steps digit_tiles KiB
     const char *src = reinterpret_cast<const char *>(Ad) + ((size_t)(st0 + stage) * 8 + (size_t)(2 * wave)) * ((size_t)digit_tiles * 1024);
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d0) : "v"(v_lin), "s"(src) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d1) : "v"(v_lin), "s"(src + (size_t)digit_tiles * 1024) : "memory");
-  };
-  v16i acc[8];
-  const int cg = lane & 15, khalf = lane >> 5;
-  // byte offset of W[r] inside a packed unit: slab region + row position (rotated for the upper half) * 32 + dword of the column group
-  int w_off[16];
 #pragma unroll
-  for (int r = 0; r < 16; r++) w_off[r] = (cg >> 3) * kTnSlabStride + (khalf ? 16 + ((r + 1) & 15) : r) * kSlabBytes + (cg & 7) * 4;
+    for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+      for (int tt = 0; tt < TT; tt++)
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d[kk][tt]) : "v"(v_lin), "s"(src + (size_t)kk * digit_tiles * 1024 + (size_t)tt * 1024) : "memory");
+  };
+  v16i acc[8][TT];
+  const int cg = lane & 15, khalf = lane >> 5;
+  // byte offset of W[r] inside a packed unit: slab region + row position (rotated for the upper half) * 32 + dword of the column group.  Row position of
+  // W[r]: r (lower K half) or 16 + ((r + 1) & 15) (upper half) = 17 + r for r < 15: ONE per-lane base + r * 32 as an immediate serves r = 0 .. 14 of both
+  // halves, W[15] (row 15 / row 16) has its own (two address registers instead of sixteen: the two-tile instantiation holds 256 accumulators)
+  const int w_base = (cg >> 3) * kTnSlabStride + (khalf ? 17 : 0) * kSlabBytes + (cg & 7) * 4;
+  const int w_15 = (cg >> 3) * kTnSlabStride + (khalf ? 16 : 15) * kSlabBytes + (cg & 7) * 4;
   const uint32_t sel1 = fh ? 0x07030602u : 0x05010400u;     // first gather stage: byte pairs (2 fh, 2 fh + 1) of the two rows
 
   for (int item = blockIdx.x; item < pc.nitems; item += gridDim.x) {
@@ -647,9 +658,11 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
 #pragma unroll
   for (int f = 0; f < 8; f++)
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[f][r] = 0;
+    for (int tt = 0; tt < TT; tt++)
 #pragma unroll
-  for (int i = 0; i < D; i++) if (i < stages) { issue_packed(i, i); issue_digits(i, dig[i][0], dig[i][1]); }
+      for (int r = 0; r < 16; r++) acc[f][tt][r] = 0;
+#pragma unroll
+  for (int i = 0; i < D; i++) if (i < stages) { issue_packed(i, i); issue_digits(i, dig[i]); }
   for (int s0 = 0; s0 < stages; s0 += NSET) {
 #pragma unroll
     for (int u = 0; u < NSET; u++) {
@@ -660,17 +673,19 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
         else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
         // (an empty volatile asm that "rewrites" the registers: volatile asms keep their order, so whatever reads the digits -- and any copy the register
         // allocator makes for this statement -- comes after the wait.  Tying the registers to the wait itself put such copies BEFORE it.)
-        asm volatile("" : "+v"(dig[u][0]), "+v"(dig[u][1]));
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+          for (int tt = 0; tt < TT; tt++) asm volatile("" : "+v"(dig[u][kk][tt]));
         __syncthreads();                                     // ... for every wave; and everybody is done with stage s - 1, whose buffer is refilled now
-        if (s + D < stages) { issue_packed(s + D, (s + D) % BUFS); issue_digits(s + D, dig[(u + D) % NSET][0], dig[(u + D) % NSET][1]); }
+        if (s + D < stages) { issue_packed(s + D, (s + D) % BUFS); issue_digits(s + D, dig[(u + D) % NSET]); }
         const char *bufp = smem + (s % BUFS) * Cfg::kBufBytes;
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
           const int T = 2 * wave + kk;                       // K-step of this wave inside the row block
-          const v4i af = dig[u][kk];
           uint32_t W[16];
 #pragma unroll
-          for (int r = 0; r < 16; r++) W[r] = *reinterpret_cast<const uint32_t *>(bufp + T * 1024 + w_off[r]);
+          for (int r = 0; r < 16; r++) W[r] = *reinterpret_cast<const uint32_t *>(bufp + T * 1024 + (r < 15 ? w_base + r * kSlabBytes : w_15));
           // byte gather, this lane's half: Pq[q][bb] byte i = byte (2 fh + bb) of W[4 i + q]
           uint32_t Pq[4][2];
 #pragma unroll
@@ -684,7 +699,8 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
             v4i bf;
 #pragma unroll
             for (int q = 0; q < 4; q++) bf[q] = (int)(g < 3 ? (Pq[q][bb] & (0x03030303u << (2 * g))) : ((Pq[q][bb] >> 2) & 0x30303030u));
-            acc[f] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[f], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < TT; tt++) acc[f][tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(dig[u][kk][tt], bf, acc[f][tt], 0, 0, 0);
           }
         }
       }
@@ -693,13 +709,15 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
   // ---- add the accumulators of the four waves that split the K-steps through LDS, two MFMA groups per pass, and store P[split][e][individual]
   __syncthreads();
   int *red = reinterpret_cast<int *>(smem);                  // [wave][group in pass (2)][reg (16)][lane (64)] ints = 8 KiB per wave
-  int *Pb = P + ((size_t)slot * e_pad + e_off) * m_pad;
+#pragma unroll
+  for (int tt = 0; tt < TT; tt++) {
+  int *Pb = P + ((size_t)slot * e_pad + e_off + 32 * tt) * m_pad;
 #pragma unroll
   for (int pass = 0; pass < 4; pass++) {
 #pragma unroll
     for (int gq = 0; gq < 2; gq++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) red[((wave * 2 + gq) * 16 + r) * 64 + lane] = acc[pass * 2 + gq][r];
+      for (int r = 0; r < 16; r++) red[((wave * 2 + gq) * 16 + r) * 64 + lane] = acc[pass * 2 + gq][tt][r];
     __syncthreads();
     {
       const int gq = wave & 1, r0 = 8 * (wave >> 1);         // this wave finishes group gq, registers r0 .. r0 + 7
@@ -718,6 +736,7 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
     }
     __syncthreads();
   }
+  }   // tiles of the pass
   }
   }   // items of this workgroup
 }
@@ -1051,14 +1070,15 @@ constexpr int kTnBufs = 4;   // 4 buffers x 2 workgroups per CU: 3 stages in fli
 // Items of the transposed-operand kernel: the first n_lo strips are cut into c_lo equal pieces of their K range, the other strips into c_lo + 1; the items of
 // the c_lo-piece strips (the longer ones) come first, piece-major.  Chosen so that the items fill whole rounds of the resident slots with (nearly) equal
 // lengths inside every round: cost = sum over the rounds of (longest item of the round + a few stages of start-up and flush), fewest pieces among equals.
-static void plan_i8_tn(long indiv_slabs, long snp_rows, int *strips_out, int *stages_out, TnPieces *pc) {
+static void plan_i8_tn(long indiv_slabs, long snp_rows, int wg_per_cu, int *strips_out, int *stages_out, TnPieces *pc) {
   const int n = (int)((indiv_slabs + kTnSlabs - 1) / kTnSlabs), K = (int)((snp_rows + kTileRows - 1) / kTileRows);
   *strips_out = n; *stages_out = K;
-  static const long slots = [] {
+  static const long cus = [] {
     int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) { (void)hipGetLastError(); return 512L; }
-    return 2L * prop.multiProcessorCount;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) { (void)hipGetLastError(); return 256L; }
+    return (long)prop.multiProcessorCount;
   }();
+  const long slots = cus * wg_per_cu;
   const int c_min = std::max(1, (K + 2046) / 2047);               // int32 accumulators: at most 2047 stages per piece
   const int c_max = std::max(c_min, std::min(kTnMaxPieces - 1, K / 24));   // pieces shorter than ~24 stages are mostly start-up
   double best = -1.0; int best_c = c_min, best_nlo = n;
@@ -1078,17 +1098,18 @@ static void plan_i8_tn(long indiv_slabs, long snp_rows, int *strips_out, int *st
   pc->c_lo = best_c; pc->n_lo = best_nlo; pc->nitems = best_nlo * best_c + (n - best_nlo) * (best_c + 1);
 }
 
-template <int BUFS>
+template <int BUFS, int TT>
 static int launch_i8_tn(const PackedMatrix &G_tn, const int8_t *d_Bs, int *d_P, const I8Plan &p, int strips, int stages, const TnPieces &pc, hipStream_t s, const int *skip) {
   static unsigned long long attr_tn = 0;
-  if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8_tn<BUFS>), TnCfg<BUFS>::kLds, &attr_tn)) return 1;
+  if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8_tn<BUFS, TT>), (TnCfg<BUFS, TT>::kLds), &attr_tn)) return 1;
   static int per_dev[64] = {};
   int dev = 0;
   MXA_HIP(hipGetDevice(&dev));
-  if (!per_dev[dev & 63]) { hipDeviceProp_t prop; MXA_HIP(hipGetDeviceProperties(&prop, dev)); per_dev[dev & 63] = 2 * std::max(1, prop.multiProcessorCount); }
-  const unsigned grid = (unsigned)std::min(pc.nitems, per_dev[dev & 63]);   // persistent: one workgroup per resident slot, fewer if there are fewer items
-  for (int nt = 0; nt < p.NT; nt++)
-    hipLaunchKernelGGL(k_gemm_i8_tn<BUFS>, dim3(grid), dim3(256), TnCfg<BUFS>::kLds, s, G_tn.d, G_tn.nslabs, d_Bs + (size_t)nt * 1024, p.NT, d_P, p.m_pad, p.e_pad,
+  if (!per_dev[dev & 63]) { hipDeviceProp_t prop; MXA_HIP(hipGetDeviceProperties(&prop, dev)); per_dev[dev & 63] = std::max(1, prop.multiProcessorCount); }
+  const unsigned grid = (unsigned)std::min(pc.nitems, (TT == 1 ? 2 : 1) * per_dev[dev & 63]);   // persistent: one workgroup per resident slot, fewer if there are fewer items
+  constexpr int lds = TnCfg<BUFS, TT>::kLds;
+  for (int nt = 0; nt < p.NT; nt += TT)
+    hipLaunchKernelGGL((k_gemm_i8_tn<BUFS, TT>), dim3(grid), dim3(256), lds, s, G_tn.d, G_tn.nslabs, d_Bs + (size_t)nt * 1024, p.NT, d_P, p.m_pad, p.e_pad,
                        nt * 32, strips, stages, pc, skip);
   MXA_HIP(hipGetLastError());
   return 0;
@@ -1104,14 +1125,16 @@ static int plan_i8_full(const PackedMatrix &G, int n, int S_override, const Pack
   // transposed-operand form (G_tn = the copy whose ROWS are the K index): same digits, same exactness guard, other main kernel and P layout
   // (several tiles of 32 expanded columns: one pass over the matrix per tile -- 3 <= n <= 6 and peeled columns of single-orientation objects; beyond what the
   // fp64 MFMA tile would take, or with several column chunks, the caller's fp64 path is the better choice: declined with 2 before anything is enqueued)
-  if (G_tn != nullptr && (p.nchunks != 1 || p.NT > (n <= 4 ? 2 : 5))) return 2;
+  // round 5: tiles are taken two per pass (k_gemm_i8_tn<.., 2>); more than three passes cost more than the fp64 path
+  if (G_tn != nullptr && (p.nchunks != 1 || (p.NT + 1) / 2 > 3)) return 2;
+  if (G_tn != nullptr && p.NT >= 2 && (p.NT & 1)) { p.NT += 1; p.e_pad = p.nchunks * p.NT * 32; }   // an even number of tiles: the last pass multiplies a tile of zero digits (the launch is bound by the packed stream)
   f.tn = G_tn != nullptr;
   // host-side operand check before anything is enqueued: a kernel must never be handed the dimensions-only descriptor of a copy that is not stored
   if ((f.tn ? G_tn->d : G.d) == nullptr) { set_error(4, "internal: the int8 route was given a packed matrix that is not stored (single-orientation object)"); return 1; }
   f.tn_strips = f.tn_stages = 0; f.tn_pc = TnPieces{1, 0, 0};
   if (f.tn) {
     if (G_tn->k != m || G_tn->rows != k) { set_error(4, "internal: transposed operand has the wrong shape"); return 1; }
-    plan_i8_tn(G_tn->nslabs, G_tn->rows, &f.tn_strips, &f.tn_stages, &f.tn_pc);
+    plan_i8_tn(G_tn->nslabs, G_tn->rows, p.NT >= 2 ? 1 : 2, &f.tn_strips, &f.tn_stages, &f.tn_pc);
     if ((long)f.tn_stages * kTileRows > G_tn->rows_pad) { set_error(4, "internal: packed matrix smaller than the transposed i8 plan"); return 1; }
     if ((f.tn_stages + f.tn_pc.c_lo - 1) / f.tn_pc.c_lo > 2047) return 2;   // K beyond 64 x 2047 row blocks (33.5 M SNPs in one object): the fp64 path
     // splits = partial-sum slots per strip
@@ -1215,7 +1238,8 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   const bool small_tile = p.nchunks == 1 && p.NT == 1 && p.nc * p.S <= 32 && (p.nc == 1 || p.nc == 2);   // n <= 2: one tile
   I8Direct dir{};
   if (tn) {
-    if (launch_i8_tn<kTnBufs>(*G_tn, d_Bs, d_P, p, tn_strips, tn_stages, pf.tn_pc, s, skip)) return 1;
+    if (p.NT >= 2 ? launch_i8_tn<6, 2>(*G_tn, d_Bs, d_P, p, tn_strips, tn_stages, pf.tn_pc, s, skip)
+                  : launch_i8_tn<kTnBufs, 1>(*G_tn, d_Bs, d_P, p, tn_strips, tn_stages, pf.tn_pc, s, skip)) return 1;
     if (ev1) MXA_HIP(hipEventRecord(ev1, s));
     static_assert(kFinTBlockRows == kTnSlabs * kSlabK, "a block of k_finish_i8_t = one strip of k_gemm_i8_tn: it adds that strip's slots");
     dim3 grid((unsigned)((fill_rows + kFinTBlockRows - 1) / kFinTBlockRows), (unsigned)n);
