@@ -968,8 +968,9 @@ def opt_in_engine_leg(W, L, args, step, sync, engine, flops_step, description):
     dN = float(((W.C_N - C_N64).abs().amax(dim=0) / C_N64.abs().amax(dim=0)).max())
     dT = float(((W.C_T - C_T64).abs().amax(dim=0) / C_T64.abs().amax(dim=0)).max())
     avg_ms = ms8 / max(1, la8)
-    if one_copy:   # the headline object keeps one packed copy (the default): at wide n the opt-in engines then apply to 'T' only
-        description += "; NOTE: one-copy object -- at this n the int8 engines multiply 'T' only, 'N' runs the fp64 engine (both copies: MXA_SINGLE_ORIENTATION=0)"
+    if one_copy:   # the headline object keeps one packed copy (the default): 'N' then runs the transposed-operand int8 kernel in column chunks
+        description += ("; one-copy object (default): 'T' on k_gemm_i8, 'N' on k_gemm_i8_tn in column chunks of <= 6 digit tiles, one pass over the packed matrix per two "
+                        "tiles (both copies, MXA_SINGLE_ORIENTATION=0: 'N' on the plain kernel in one launch)")
     out = {"engine": description, "kernel_family_of_last_product": {0: "k_gemm", 1: "k_lut", 2: "k_gemm_i8", 3: "k_small_n_fp64"}.get(path, str(path)),
            "value": round(flops_step * args.steps / dt8 * 1e-9, 1), "unit": "GFLOP/s (fp64-equivalent: same 2*snps*indiv*ncol count)",
            "ms_per_step": round(dt8 / args.steps * 1e3, 3), "avg_kernel_ms": round(avg_ms, 3), "digits_per_column": digits,

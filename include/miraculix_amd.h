@@ -352,7 +352,7 @@ long mxa_plan_partial_doubles(long m, long k, int n);
  * n <= 6 and of peeled columns: 'T' on k_gemm_i8, 'N' on k_gemm_i8_tn (n <= 3: one digit tile, a CG step within 2 % of a two-copy object's; n = 4..6: two
  * tiles in ONE pass over the matrix, 1.44-1.50 ms against 1.3 on 500k x 50k; the fp64 tile would take 3.2-4.4).
  * MXA_SINGLE_ORIENTATION=0 in the environment of the creating call asks for BOTH copies (what rounds 1-4 stored): 'N' then runs the plain kernels
- * everywhere (4 <= n <= 6: 10-15 % faster), and the opt-in engines i8 / i8-exact apply to both products at wide n (on a one-copy object: to 'T' only).  If the two copies do not fit the
+ * everywhere (4 <= n <= 6: 10-15 % faster), and the opt-in engines i8 / i8-exact multiply 'N' at wide n on the plain int8 kernel (on a one-copy object: on the transposed-operand kernel in column chunks of at most six digit tiles, one pass over the packed matrix per two tiles).  If the two copies do not fit the
  * device's free memory and one does, one is kept and a line on stderr says so (the reference reports "Not enough device memory" there,
  * cuda_utils.cu:162-185); a multi-device object decides once for all its shards.  Results of one-copy and two-copy objects agree to rounding
  * (bit-identical on the fp64 MFMA path and for integer-valued operands).  mxa_single_orientation: 1 / 0 (multi-device object: of its shards), -1 for an

@@ -647,24 +647,35 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     }
   }
   if (centered && launch_colsums(dB, ldb, k, n, trans ? nullptr : h->d_f, w.d_colpart, d_sumB, d_sumfB, s)) return 1;
+  // Engines 1 / 4 (opt-in): the int8 slicing of all n columns with S digits each (0: plan_i8's choice).  Plain form: one call.  Transposed-operand form ('N' of a
+  // one-copy object): k_gemm_i8_tn takes at most six tiles of 32 expanded columns per call (three passes of two tiles), so a wide product goes in balanced column
+  // chunks -- every pass streams the packed matrix once, and three columns' worth of fp64 MFMA time buys a pass (C2, n = 32, 10 digits: 6 passes of 2.9 ms against
+  // 43 ms on the fp64 tile).  stats_base: column maxima that are already there (k_colmax_partial's layout: the maxima of column j at [64 j, 64 j + 64)).
+  auto i8_engine_product = [&](int S, double *stats_base, hipEvent_t e0, hipEvent_t e1, int *splits_out) -> int {
+    const int rc = gemm_i8_device(G, trans, n, dB, ldb, dC, ldc, fill_rows, centered, d_sumB, d_sumfB, h->d_f, w, s, e0, e1, splits_out, 0, nullptr, nullptr, S, G_tn_single, stats_base);
+    if (rc != 2 || !G_tn_single) return rc;
+    const int cmax = (6 * 32) / (S > 0 ? S : 7);
+    if (cmax < 1) return 2;
+    const int chunks = (n + cmax - 1) / cmax, per = (n + chunks - 1) / chunks;
+    if (chunks < 2) return 2;                  // declined for another reason than the tile count (K beyond the accumulators' range)
+    for (int c0 = 0; c0 < n; c0 += per) {
+      const int nc = std::min(per, n - c0);
+      const int rcc = gemm_i8_device(G, trans, nc, dB + (size_t)c0 * ldb, ldb, dC + (size_t)c0 * ldc, ldc, fill_rows, centered, d_sumB + c0, d_sumfB + c0, h->d_f, w, s,
+                                     c0 == 0 ? e0 : nullptr, c0 + nc >= n ? e1 : nullptr, splits_out, 0, nullptr, nullptr, S, G_tn_single, stats_base ? stats_base + (size_t)c0 * 64 : nullptr);
+      if (rcc == 2 && c0 == 0) return 2;       // nothing is enqueued yet: the fp64 path takes the product
+      if (rcc) { if (rcc == 2) set_error(4, "internal: a later column chunk of the int8 engine declined"); return 1; }
+    }
+    return 0;
+  };
   // Engine 4 (i8-exact, opt-in): the same exact slicing for EVERY n with the digit count chosen PER CALL from the measured exponent span of B's columns --
   // S = max(7, ceil((span + 55) / 8)) <= 24 -- by the host: three integers are read back (ONE host synchronisation per call, documented with the engine).
-  auto exact_adaptive = [&](int c0, int nc, hipEvent_t e0, hipEvent_t e1, int *splits_out, int *digits_out) -> int {
-    int hs[3] = {0, 0, 1};
-    const double *dBc = dB + (size_t)c0 * ldb;
-    if (launch_colspan(dBc, ldb, k, nc, w.d_colpart, w.d_denflag + 4, s)) return 1;
+  if (engine == 4 && k >= 128 && n > 2) {
+    int splits8 = 1, hs[3] = {0, 0, 1};
+    if (launch_colspan(dB, ldb, k, n, w.d_colpart, w.d_denflag + 4, s)) return 1;
     MXA_HIP(hipMemcpyAsync(hs, w.d_denflag + 4, sizeof(hs), hipMemcpyDeviceToHost, s));
     MXA_HIP(hipStreamSynchronize(s));
     const int S = std::max(7, (hs[0] + 55 + 7) / 8);
-    if (hs[2] || S > kI8ExactMaxDigits || hs[1] < 8 * S - 1023) return 2;
-    if (digits_out) *digits_out = S;
-    const int rc = gemm_i8_device(G, trans, nc, dBc, ldb, dC + (size_t)c0 * ldc, ldc, fill_rows, centered, d_sumB + c0, d_sumfB + c0, h->d_f, w, s, e0, e1, splits_out, 0,
-                                  nullptr, nullptr, S, G_tn_single, w.d_colpart);
-    return rc == 2 ? 2 : rc ? 1 : 0;
-  };
-  if (engine == 4 && k >= 128) {
-    int splits8 = 1, S = 0;
-    const int rcx = n <= 2 ? 2 : exact_adaptive(0, n, pe0, pe1, &splits8, &S);
+    const int rcx = (hs[2] || S > kI8ExactMaxDigits || hs[1] < 8 * S - 1023) ? 2 : i8_engine_product(S, w.d_colpart, pe0, pe1, &splits8);
     if (rcx == 1) return 1;
     if (rcx == 0) {
       MXA_HIP(hipMemsetAsync(w.d_denflag, 0, sizeof(int), s));
@@ -677,7 +688,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   }
   if (engine == 1 || (engine == 2 && n <= 4)) {   // opt-in: the int8 slicing without the exactness check (7 digits; 32 / 16 for n = 1 / 2)
     int splits8 = 1;
-    const int rc8 = gemm_i8_device(G, trans, n, dB, ldb, dC, ldc, fill_rows, centered, d_sumB, d_sumfB, h->d_f, w, s, pe0, pe1, &splits8, 0, nullptr, nullptr, 0, G_tn_single);
+    const int rc8 = i8_engine_product(0, nullptr, pe0, pe1, &splits8);
     if (rc8 == 0) {
       std::lock_guard<std::mutex> lk(g_prof_mutex);
       Geometry &geo = last_geometry();
@@ -685,7 +696,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
       h->prof_pending[slot] = prof;
       return 0;
     }
-    if (rc8 != 2) return 1;   // 2: the transposed-operand form declined (single-orientation 'N' at wide n): fp64 path below
+    if (rc8 != 2) return 1;   // 2: the int8 route declined (K beyond the accumulators' range in the transposed-operand form): fp64 path below
   }
   // Column peel (engine 0, n = 4q + r > 6, r = 1, 2, 3): the MFMA tile works on groups of 4 columns, so 10 columns would cost 12 (the reference harness's
   // default n = 10).  The r odd columns go through the guarded route above -- one HBM-bound pass over the packed matrix -- and the multiple of 4 runs on the

@@ -41,6 +41,11 @@ def last_path():
     return {0: "k_gemm", 1: "k_lut", 2: "k_gemm_i8", 3: "k_small_n_fp64"}[_lib.check_library_handle().mxa_last_path()]
 
 
+def single_orientation(obj):
+    """1: the object keeps ONE packed copy (SNP-major, the default), 0: both copies (multi-device object: of its shards); -1: not an object"""
+    return int(_lib.check_library_handle().mxa_single_orientation(obj))
+
+
 def check_dimensions(plink, snps, indiv):
     """miraculix.jl check_dimensions: rows of ceil(indiv/4) bytes, one row per SNP (row-major here)."""
     nbytes = int(np.prod(plink.shape))

@@ -84,6 +84,41 @@ def test_obeys_the_stated_bound_elementwise(mx, n, decades, trans):
         dg.free_compressed(obj)
 
 
+@pytest.mark.parametrize("n,decades", [(8, 3), (10, 30), (17, 9), (32, 6), (33, 16), (70, 5)])
+def test_one_copy_objects_N_in_column_chunks_obeys_the_same_bound(mx, n, decades):
+    """default objects keep ONE packed copy: 'N' at wide n runs the transposed-operand int8 kernel in column chunks of at most six digit tiles -- same digit
+    count, same exact integer sums, same element-wise bound as the plain kernel"""
+    import os
+    os.environ["MXA_SINGLE_ORIENTATION"] = "1"
+    o = Oracle()
+    snps, indiv = 3001, 1037
+    prob = _adversarial_problem(snps, indiv, seed=11)
+    dg = mx.dgemm_compressed
+    dg.set_options(use_gpu=True, not_center=True, verbose=0)
+    obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], n)
+    try:
+        assert dg.single_orientation(obj) == 1
+        B = _wide_B(snps, n, decades, seed=3, big_every=7)
+        C = _run(mx, obj, prob, 0, B)
+        assert dg.last_path() == "k_gemm_i8"
+        S = _digits(mx)
+        span = max(np.frexp(np.abs(b).max())[1] - np.frexp(np.abs(b[b != 0]).min())[1] for b in B)
+        assert S == max(7, -(-(span + 55) // 8)) and S <= 24
+        ref = o.dgemm_dense(0, prob, B, 0)[:, :indiv]
+        abssum = o.dgemm_dense(0, prob, np.abs(B), 0)[:, :indiv]
+        err = np.abs(C - ref)
+        bound = 3.02 * (S - 1) * U * abssum
+        assert np.all(err <= bound + 1e-300), float((err / np.maximum(bound, 1e-300)).max())
+        dg.set_options(use_gpu=True, not_center=False, verbose=0)
+        Cc = _run(mx, obj, prob, 0, B)
+        assert dg.last_path() == "k_gemm_i8"
+        refc = o.dgemm_dense(0, prob, B, 1)[:, :indiv]
+        assert np.abs(Cc - refc).max() <= 1e-11 * np.abs(refc).max()
+        assert np.array_equal(Cc, _run(mx, obj, prob, 0, B))
+    finally:
+        dg.free_compressed(obj)
+
+
 @pytest.mark.parametrize("case", ["span", "inf", "nan", "tiny", "short_k"])
 @pytest.mark.parametrize("n", [3, 12])
 def test_declines_and_the_fp64_path_takes_over(mx, case, n):

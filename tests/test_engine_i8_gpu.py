@@ -53,6 +53,38 @@ def test_i8_engine_vs_oracle(dg, snps, indiv, n, centered):
         dg.free_compressed(obj)
 
 
+@pytest.mark.parametrize("snps,indiv,n", [(777, 1301, 10), (3001, 2050, 32), (1500, 700, 40), (20000, 300, 33), (2600, 900, 28), (2600, 900, 55)])
+def test_i8_engine_on_one_copy_objects_multiplies_N_from_the_snp_major_copy(dg, snps, indiv, n):
+    """default objects keep ONE packed copy: 'N' at wide n runs k_gemm_i8_tn in column chunks of at most six digit tiles (three passes of two tiles each);
+    same digits and exact integer sums as the plain kernel, so the same tolerance -- and integer-valued B must come out bit-exact"""
+    import os
+    os.environ["MXA_SINGLE_ORIENTATION"] = "1"
+    o = Oracle()
+    prob = make_problem(snps, indiv, n, seed=42 + snps, missing_frac=0.02)
+    for centered in (0, 1):
+        dg.set_options(use_gpu=True, not_center=not centered, verbose=0)
+        obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], n)
+        try:
+            assert dg.single_orientation(obj) == 1
+            B = make_B(snps, n, seed=43)
+            B[n // 2, :snps] *= 1e-9
+            B[0, :snps] *= 3e7
+            ref = o.dgemm_dense(0, prob, B, centered)[:, :indiv]
+            Bcm = np.asfortranarray(B[:, :snps].T)
+            C = dg.dgemm_compressed_main(False, obj, Bcm, snps, indiv)
+            assert dg.last_path() == "k_gemm_i8"
+            err = (np.abs(C.T - ref).max(axis=1) / np.abs(ref).max(axis=1)).max()
+            assert err <= RTOL, err
+            assert np.array_equal(C, dg.dgemm_compressed_main(False, obj, Bcm, snps, indiv))
+            if not centered:
+                Bi = np.random.default_rng(3).integers(-(2 ** 20), 2 ** 20, size=(n, snps)).astype(np.float64)
+                Ci = dg.dgemm_compressed_main(False, obj, np.asfortranarray(Bi.T), snps, indiv)
+                assert dg.last_path() == "k_gemm_i8"
+                assert np.array_equal(Ci, (prob["Z"].astype(np.int64) @ Bi.T.astype(np.int64)).astype(np.float64))
+        finally:
+            dg.free_compressed(obj)
+
+
 def test_i8_engine_zero_column_ld_padding_and_engine_switch(dg):
     o = Oracle()
     prob = make_problem(1203, 610, 5, seed=7)
