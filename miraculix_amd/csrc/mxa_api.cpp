@@ -335,7 +335,7 @@ int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink
   if (env_print_level() > 0 || o.print_level > 0) {
     hipDeviceProp_t prop;
     print_compile_info("dgemm_compressed");
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) printf("miraculix_amd - dgemm_compressed: using device %s (device no %d).\n", prop.name, dev);
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) printf("miraculix_amd - dgemm_compressed: using device %s [%s] (device no %d).\n", prop.name, prop.gcnArchName, dev);
   }
   // memory pre-flight like checkDevMemory (cuda_utils.cu:162-185).  Where the reference gives up -- two packed copies do not fit -- this build keeps
   // the SNP-major copy alone if THAT fits (MXA_SINGLE_ORIENTATION unset / auto; Handle::single): both products then read the one copy.

@@ -190,3 +190,24 @@ def test_planner_sweep_host_build():
     subprocess.check_call(["make", "-C", d, "plan_sweep"], stdout=subprocess.DEVNULL)
     r = subprocess.run([os.path.join(d, "plan_sweep")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and " 0 failures" in r.stdout, r.stdout[-2000:]
+
+
+def test_reference_fortran_programs_bind_only_symbols_this_library_exports(built):
+    """oracle/Makefile.ref_fortran links the reference's own (unmodified) Fortran tests and benchmark harness against libmiraculix_amd.so: every symbol their
+    binding modules leave undefined (bind(C) names of mod5codesapi.f90 / modmiraculix_gpu.f90) must be one this library exports -- the link itself proves
+    it; here the list is written out.  (No compute: the programs run in tests/test_reference_fortran_gpu.py.)  Skipped where they are not built."""
+    bindir = os.path.join(ROOT, "oracle", "_ref", "fortran")
+    progs = [os.path.join(bindir, p) for p in ("test_5codesapi.out", "test_5codesapi_t.out", "test_solve.out", "benchmark.out")]
+    if not all(os.path.exists(p) for p in progs):
+        pytest.skip("oracle/_ref/fortran not built (needs /root/reference and flang)")
+    exported = {ln.split()[-1].split("@")[0] for ln in subprocess.check_output(["nm", "-D", "--defined-only", LIB], text=True).splitlines() if ln.strip()}
+    api = {"setOptions_compressed", "plink2compressed", "dgemm_compressed", "free_compressed", "get_compressed_freq", "sparse_times_plink",
+           "sparse2gpu", "dcsrtrsv_solve_gpu", "potrs_solve_gpu", "free_sparse_gpu", "snp_multiply_gpu"}
+    bound = set()
+    for p in progs:
+        needed = subprocess.check_output(["readelf", "-d", p], text=True)
+        assert "libmiraculix_amd.so" in needed
+        undef = {ln.split()[-1].split("@")[0] for ln in subprocess.check_output(["nm", "-D", "--undefined-only", p], text=True).splitlines() if ln.strip()}
+        bound |= undef & api
+        assert (undef & api) <= exported
+    assert {"setOptions_compressed", "plink2compressed", "dgemm_compressed", "free_compressed", "sparse2gpu", "dcsrtrsv_solve_gpu", "free_sparse_gpu"} <= bound
