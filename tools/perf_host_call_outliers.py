@@ -27,3 +27,15 @@ for trans in (False, True):
     out = [(i, round(float(t), 2)) for i, t in enumerate(ts) if i > 0 and t > 2 * med]
     print(f"{'T' if trans else 'N'}: median {med:.3f} ms, calls above 2x median (index, ms): {out}", flush=True)
 dg.free_compressed(obj)
+# control: the bare pageable upload of the same B through torch (no library call): outliers here belong to the runtime's pageable-copy path
+B = np.asfortranarray(rng.standard_normal((snps, n)))
+dst = torch.empty((n, snps), dtype=torch.float64, device="cuda")
+src = torch.from_numpy(B.T)
+ts = []
+for i in range(reps):
+    t0 = time.perf_counter()
+    dst.copy_(src); torch.cuda.synchronize()
+    ts.append(time.perf_counter() - t0)
+ts = np.array(ts) * 1e3
+med = np.median(ts[1:])
+print(f"bare pageable upload of {B.nbytes / 1e6:.0f} MB: median {med:.3f} ms, copies above 2x median (index, ms): {[(i, round(float(t), 2)) for i, t in enumerate(ts) if i > 0 and t > 2 * med]}", flush=True)
