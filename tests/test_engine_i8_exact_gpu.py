@@ -172,12 +172,15 @@ def test_integer_B_is_exact_and_matches_default_engine_closely(mx):
         dg.free_compressed(obj)
 
 
-def test_sharded_object_and_fused_gram_step(mx):
+@pytest.mark.parametrize("copies,n", [(2, 12), (1, 12), (1, 40)])
+def test_sharded_object_and_fused_gram_step(mx, copies, n):
     """the engine behind a multi-shard object (every shard chooses its own digit count for its rows of B) and through the fused CG step
-    mxa_gram_matvec at n = 12: against the oracle, and the fused step bit-identical to its two products"""
+    mxa_gram_matvec: against the oracle, and the fused step bit-identical to its two products.  copies = 1: default objects ('N' in column chunks on the
+    transposed-operand kernel, per shard)"""
     import os
+    os.environ["MXA_SINGLE_ORIENTATION"] = "1" if copies == 1 else "0"
     o = Oracle()
-    snps, indiv, n = 4100, 901, 12
+    snps, indiv = 4100, 901
     prob = make_problem(snps, indiv, n, seed=21)
     dg = mx.dgemm_compressed
     dg.set_options(use_gpu=True, not_center=False, verbose=0)
