@@ -69,3 +69,16 @@ def test_reference_solver_test_reports_ok_for_every_case():
     assert rc == 0, out[-3000:]
     assert "wrong" not in out, out[-3000:]
     assert len(re.findall(r" OK\s*$", out, flags=re.M)) == 6, out[-3000:]   # U\B, U^T\B, U^T\U\B twice, L^T\L\B twice (without and with the permutation)
+
+
+def test_reference_benchmark_harness_runs_in_gpu_mode(tmp_path):
+    """utils/benchmark/benchmark.f90 (the timing protocol SURVEY.md 8d cites: 1 warm-up + 10 repetitions of 'n' and of 't', ncol = 10, centred, host B / C), mode GPU:
+    runs to the end against this library and reports both averages (numbers at a size where they mean something: profiles/r05_reference_fortran_tests.txt)"""
+    exe = _need("benchmark.out")
+    _write_dataset(str(tmp_path / "small"), 5003, 1201, seed=6)
+    rc, out = _run([exe, "GPU", "small.bed", "small.freq"], str(tmp_path))
+    assert rc == 0, out[-3000:]
+    assert out.count("Elapsed time - Z - GPU") == 10 and out.count("Elapsed time - Z^T - GPU") == 10, out[-3000:]
+    for label in ("Average time - Z - GPU: ", "Average time - Z^T - GPU: "):
+        m = re.search(re.escape(label) + r"(\S+)", out)
+        assert m and 0.0 < float(m.group(1)) < 1.0, out[-3000:]
