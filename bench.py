@@ -963,7 +963,7 @@ def opt_in_engine_leg(W, L, args, step, sync, engine, flops_step, description):
         path = L.mxa_last_path()
     finally:
         L.mxa_set_engine(0)
-    digits = ga.value if engine == 4 else 7          # of the last product of the step ('T'); engine 4 reports its per-call choice
+    digits = ga.value if engine == 4 else 10 if engine == 5 else 7          # of the last product of the step ('T'); engine 4 reports its per-call choice; engine 5: class 0 of a 6-column chunk
     one_copy = bool(L.mxa_single_orientation(W.eng.obj) == 1)
     dN = float(((W.C_N - C_N64).abs().amax(dim=0) / C_N64.abs().amax(dim=0)).max())
     dT = float(((W.C_T - C_T64).abs().amax(dim=0) / C_T64.abs().amax(dim=0)).max())
@@ -1145,13 +1145,16 @@ def main():
 
     # informational extra passes, outside the timed region: the same steps with the two opt-in int8 engines (include/miraculix_amd.h,
     # mxa_set_engine).  Reported beside the headline, never as `value`.
-    alt = alt_exact = None
+    alt = alt_exact = alt_guarded = None
     if not args.no_alt_engine and not W.inprocess:
         alt = opt_in_engine_leg(W, L, args, step, sync, 1, flops_step,
                                 "i8: B split into 7 radix-256 digits per column (to 2^-54 of the column maximum, no exactness check), v_mfma_i32_32x32x32_i8, exact int32 sums, fp64 recombination")
         alt_exact = opt_in_engine_leg(W, L, args, step, sync, 4, flops_step,
                                       "i8-exact: digit count chosen per call from the measured exponent span of B so that B is represented WITHOUT error "
                                       "(|error| <= 3.02 (S-1) 2^-53 sum|z b| per output, tighter than an fp64 FMA chain); fp64 MFMA path when that needs more than 24 digits")
+        alt_guarded = opt_in_engine_leg(W, L, args, step, sync, 5, flops_step,
+                                        "i8-guarded: the default engine's guarded exact int8 route for every n -- chunks of <= 6 columns, each with its verdict formed ON THE DEVICE "
+                                        "(10 or 16 digits per column at 6 columns; fp64 chains for a chunk that is not exactly representable): asynchronous, no host read")
 
     # ABI end-to-end (reference harness utils/benchmark/benchmark.f90:192-209): the same two products with HOST
     # B and C through the plain reference symbol dgemm_compressed -- what a Julia / Fortran caller sees, PCIe included.
@@ -1232,6 +1235,8 @@ def main():
             out["opt_in_engine"] = alt
         if alt_exact is not None:
             out["opt_in_engine_exact"] = alt_exact
+        if alt_guarded is not None:
+            out["opt_in_engine_guarded"] = alt_guarded
         if abi is not None:
             out["abi_end_to_end"] = abi
         if W.keep_raw:   # CPU baseline + parity against the checker: rank 0 at N = 1 only

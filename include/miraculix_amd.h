@@ -317,6 +317,9 @@ int mxa_ld(const unsigned char *plink, int snps, int indiv, double *R, int is_pl
  *    additions: |error| <= 3.02 * (S - 1) * 2^-53 * sum_k |z_k b_k|, S <= 24.  Wider spans (> 137 binades), inf / NaN, columns whose largest
  *    entry lies below 2^(8S - 1023), or K < 128: engine 0's path.  Typical data (spans of 15-30 binades) need 9-11 digits; the product is
  *    then 2-3 times faster than the fp64 matrix cores allow.  n <= 2: as engine 0.  One host synchronisation per call.
+ * 5 (opt-in, MXA_ENGINE=i8-guarded): engine 0's guarded exact route for EVERY n -- the columns go in balanced chunks of at most six, each chunk with its own
+ *    device-side verdict (exact with the digits of two tiles / of three tiles / not exact -> the fp64 chains of that chunk) and one pass over the packed
+ *    matrix: the ASYNCHRONOUS counterpart of engine 4 (nothing is read back; same error bound with S <= 24).  K < 128: engine 0's path.
  * mxa_set_engine returns the previous value (an invalid argument leaves the engine unchanged).  mxa_last_path: kernel family of
  * the most recent product: 0 = fp64 MFMA (k_gemm), 1 = fp64 pair tables (k_lut: engine f64-strict and K < 128, where the stored copy's rows are the
  * output rows), 2 = exact int8 slicing (k_gemm_i8 / k_gemm_i8_tn), 3 = the fp64 chains behind a declined exactness guard (the verdict is read from the

@@ -34,6 +34,7 @@ static std::atomic<int> g_engine{[] {
   if (e && std::string(e) == "small-n-i8") return 2;
   if (e && std::string(e) == "f64-strict") return 3;
   if (e && std::string(e) == "i8-exact") return 4;
+  if (e && std::string(e) == "i8-guarded") return 5;
   return 0;
 }()};
 
@@ -605,7 +606,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   // tile of 32 expanded columns; a class whose passes would cost more than the fp64 MFMA tile is not offered (gemm_i8_reserve returns 2).
   const bool no_plain = h->single && !trans;
   const PackedMatrix *G_tn_single = no_plain ? &gemm_operand(h, trans, true) : nullptr;
-  const bool small_ok = (engine == 0 || engine == 2 || (engine == 4 && n <= 2)) && k >= 128;
+  const bool small_ok = (engine == 0 || engine == 2 || engine == 5 || (engine == 4 && n <= 2)) && k >= 128;
   // columns [c0, c0 + nc), nc <= 6.  0: enqueued (int8 chains + fp64 kernel: the columns are done whatever the verdict), 2: not applicable, 1: error
   auto guarded_small = [&](int c0, int nc, const PackedMatrix *G_tn, hipEvent_t e0, hipEvent_t e1, int *splits_out, const int **flag_ptr) -> int {
     static const int S0_of[7] = {0, 32, 16, 10, 16, 12, 10}, S1_of[7] = {0, 0, 0, 21, 24, 19, 16};
@@ -639,6 +640,28 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     const int rcx = guarded_small(0, n, G_tn, pe0, pe1, &splits8, &d_flag);
     if (rcx == 1) return 1;
     if (rcx == 0) {   // (the range flag of the denormal-operand mode -- mxa_last_range_fallback -- is cleared by the chain's k_slice_B)
+      std::lock_guard<std::mutex> lk(g_prof_mutex);
+      Geometry &geo = last_geometry();
+      geo.m = m; geo.k = k; geo.n = n; geo.splits = splits8; geo.a = 0; geo.c = 0; geo.path = 4; geo.d_flag = d_flag; geo.flag_dev = h->device;
+      h->prof_pending[slot] = prof;
+      return 0;
+    }
+  }
+  // Engine 5 (i8-guarded, opt-in): the guarded route above for EVERY n, in balanced chunks of at most six columns -- each chunk carries its own device-side
+  // verdict (class 0 / 1: exact with the digits of two / three tiles; class 2: the fp64 chains in its k_slice_B launch), so the whole product is enqueued
+  // without a host read: the asynchronous counterpart of engine 4.  One pass over the packed matrix per chunk (2 x 32 digit columns at class 0).
+  if (engine == 5 && small_ok && n > kSmallNMaxColsHost) {
+    const int chunks = (n + kSmallNMaxColsHost - 1) / kSmallNMaxColsHost, per = (n + chunks - 1) / chunks;
+    int splits8 = 1, done = 0;
+    const int *d_flag = nullptr;
+    for (int c0 = 0; c0 < n; c0 += per) {
+      const int nc = std::min(per, n - c0);
+      const int rcx = guarded_small(c0, nc, G_tn_single, c0 == 0 ? pe0 : nullptr, c0 + nc >= n ? pe1 : nullptr, &splits8, &d_flag);
+      if (rcx == 2 && c0 == 0) break;          // the route does not apply to this object (nothing is enqueued): fp64 path below
+      if (rcx) { if (rcx == 2) set_error(4, "internal: a later column chunk of the guarded int8 engine declined"); return 1; }
+      done += nc;
+    }
+    if (done == n) {
       std::lock_guard<std::mutex> lk(g_prof_mutex);
       Geometry &geo = last_geometry();
       geo.m = m; geo.k = k; geo.n = n; geo.splits = splits8; geo.a = 0; geo.c = 0; geo.path = 4; geo.d_flag = d_flag; geo.flag_dev = h->device;
@@ -1279,7 +1302,7 @@ int mxa_device_count(void) {
 }
 
 int mxa_set_engine(int engine) {
-  if (engine < 0 || engine > 4) return g_engine.load();
+  if (engine < 0 || engine > 5) return g_engine.load();
   return g_engine.exchange(engine);
 }
 int mxa_get_engine(void) { return g_engine.load(); }

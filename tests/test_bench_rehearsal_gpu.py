@@ -29,6 +29,8 @@ def test_bench_two_ranks_one_gpu_gloo():
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert "cpu_baseline" not in out                                       # rank 0 at N = 1 only
     assert out["opt_in_engine"]["max_colwise_rel_diff_vs_f64_engine"] <= 1e-11
+    gd = out["opt_in_engine_guarded"]
+    assert gd["max_colwise_rel_diff_vs_f64_engine"] <= 1e-12 and gd["kernel_family_of_last_product"] == "k_gemm_i8"
     ex = out["opt_in_engine_exact"]
     assert ex["max_colwise_rel_diff_vs_f64_engine"] <= 1e-12 and ex["kernel_family_of_last_product"] == "k_gemm_i8" and 7 <= ex["digits_per_column"] <= 24
 
