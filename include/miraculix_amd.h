@@ -304,7 +304,8 @@ int mxa_ld(const unsigned char *plink, int snps, int indiv, double *R, int is_pl
  *    same exact route.  Digits per column = what fits the tiles of 32 expanded columns: n = 3: 10 (one tile) or 21 (two), 4: 16 or 24, 5: 12 or 19,
  *    6: 10 or 16.  The verdict is a CLASS formed on the device (round 5): exact with the smaller count, exact with the larger one, or neither; the kernels of
  *    both classes are enqueued and each tests one flag word, so no product waits for the host.  Class "neither" (span beyond the digits, inf / NaN, a
- *    column near the underflow threshold): plain fp64 FMA chains, one thread per output row, inside the same launch sequence.  1.0-1.5 ms instead of
+ *    column near the underflow threshold): fp64 -- gated launches of the fp64 kernels behind the int8 chains (2 <= n <= 6, peeled pairs / triples), plain FMA chains inside the same
+ *    launch sequence (n = 1).  1.0-1.5 ms instead of
  *    3.2-4.4 ms on 500k x 50k.  n >= 7: fp64 MFMA; the 1-3 odd columns of n = 4q + r through the same guarded route.
  * 1 (opt-in, also MXA_ENGINE=i8 in the environment): the int8 slicing for every n with 7 digits (32 / 16 for n = 1 / 2) and NO
  *    exactness check: B is represented to 2^-54 of each column's largest |entry| (fixed point per column, not per element);
@@ -318,11 +319,11 @@ int mxa_ld(const unsigned char *plink, int snps, int indiv, double *R, int is_pl
  *    entry lies below 2^(8S - 1023), or K < 128: engine 0's path.  Typical data (spans of 15-30 binades) need 9-11 digits; the product is
  *    then 2-3 times faster than the fp64 matrix cores allow.  n <= 2: as engine 0.  One host synchronisation per call.
  * 5 (opt-in, MXA_ENGINE=i8-guarded): engine 0's guarded exact route for EVERY n -- the columns go in balanced chunks of at most six, each chunk with its own
- *    device-side verdict (exact with the digits of two tiles / of three tiles / not exact -> the fp64 chains of that chunk) and one pass over the packed
+ *    device-side verdict (exact with the digits of two tiles / of three tiles / not exact -> the gated fp64 launches of that chunk) and one pass over the packed
  *    matrix: the ASYNCHRONOUS counterpart of engine 4 (nothing is read back; same error bound with S <= 24).  K < 128: engine 0's path.
  * mxa_set_engine returns the previous value (an invalid argument leaves the engine unchanged).  mxa_last_path: kernel family of
  * the most recent product: 0 = fp64 MFMA (k_gemm), 1 = fp64 pair tables (k_lut: engine f64-strict and K < 128, where the stored copy's rows are the
- * output rows), 2 = exact int8 slicing (k_gemm_i8 / k_gemm_i8_tn), 3 = the fp64 chains behind a declined exactness guard (the verdict is read from the
+ * output rows), 2 = exact int8 slicing (k_gemm_i8 / k_gemm_i8_tn), 3 = the fp64 path behind a declined exactness guard (the verdict is read from the
  * device when this is called). */
 int mxa_set_engine(int engine);
 int mxa_get_engine(void);

@@ -608,9 +608,23 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   const PackedMatrix *G_tn_single = no_plain ? &gemm_operand(h, trans, true) : nullptr;
   const bool small_ok = (engine == 0 || engine == 2 || engine == 5 || (engine == 4 && n <= 2)) && k >= 128;
   // columns [c0, c0 + nc), nc <= 6.  0: enqueued (int8 chains + fp64 kernel: the columns are done whatever the verdict), 2: not applicable, 1: error
+  // Verdict class 2 ("not exactly representable"; inf / NaN; a column near the underflow threshold): who does the product in fp64?
+  //   nc = 1: fp64 chains, one thread per output row, inside the first chain's k_slice_B launch (no launch of their own: the CG step counts its launches; with 32 digits =
+  //           201 binades the class needs inf / NaN or an entry 60 decades below its column's maximum).
+  //   nc >= 2: the plain-operand fp64 path behind the chains, every launch gated by the verdict word -- k_lut + k_finish (nc = 2, plain form) or k_pack_B + k_gemm<MODE 0>
+  //           + k_finish: three empty launches (~5 us each) on a >= 1 ms product when the int8 classes apply, against 45-280 ms of chains when they do not
+  //           (500k x 50k, n = 4 .. 6: measured late in round 5).  If its partial sums do not fit the budget (objects that fill the device): the chains.
   auto guarded_small = [&](int c0, int nc, const PackedMatrix *G_tn, hipEvent_t e0, hipEvent_t e1, int *splits_out, const int **flag_ptr) -> int {
     static const int S0_of[7] = {0, 32, 16, 10, 16, 12, 10}, S1_of[7] = {0, 0, 0, 21, 24, 19, 16};
     I8Chain ch; ch.S0 = S0_of[nc]; ch.S1 = S1_of[nc];
+    const bool fb_lut = nc <= 2 && !no_plain;
+    GemmPlan pf = fb_lut ? plan_lut(m, G.k_pad, nc) : plan_gemm(m, G.k_pad, nc);
+    bool fast_fb = nc >= 2;
+    if (fast_fb) {
+      const size_t one = (size_t)pf.n_pad * pf.m_pad, need = one * pf.splits;
+      fast_fb = partial_budget(w, need, one) >= need;
+    }
+    ch.fp64_rows = !fast_fb;
     const int r0 = gemm_i8_reserve(G, nc, ch.S0, G_tn, w, s);
     if (r0) return r0;
     if (ch.S1) {
@@ -627,7 +641,17 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
                                     cls == 0 ? splits_out : nullptr, 2, &d_flag, w.d_colpart, 0, G_tn, nullptr, &ch);
       if (rc != 3) return 1;
     }
-    // (class 2: plain fp64 chains, one thread per output row, inside the first chain's k_slice_B launch)
+    if (fast_fb) {   // class 2: the gated fp64 launches (d_flag = the word "class == 2")
+      if (ensure_partials(w, pf, s)) return 1;
+      if (fb_lut) { if (launch_lut(G, dBc, ldb, nc, w.d_P, pf, s, d_flag)) return 1; }
+      else {
+        const bool trf = gemm_use_tr(pf, h, trans);
+        if (launch_pack_B(dBc, ldb, k, nc, w.d_Bp, G.k_pad, pf.n_pad, pf.c, s, nullptr, 0, -1, d_flag)) return 1;
+        if (launch_gemm(gemm_operand(h, trans, trf), w.d_Bp, w.d_P, pf, 0, s, next_ctr(w), 0, -1, d_flag, trf)) return 1;
+      }
+      if (launch_finish(w.d_P, pf, m, nc, dCc, ldc, fill_rows, trans ? 1 : 0, centered, d_sumB + c0, d_sumfB + c0, h->d_f, s, nullptr, 0, 0, d_flag, nullptr)) return 1;
+    }
+    // (class 2 at nc = 1: plain fp64 chains, one thread per output row, inside the first chain's k_slice_B launch)
     if (flag_ptr) *flag_ptr = d_flag;
     return 0;
   };

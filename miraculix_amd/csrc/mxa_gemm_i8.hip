@@ -1224,7 +1224,7 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
     const long total = (long)p.T_total * 2 * ncols * 4;
     SmallNFallback fb{};
     long blocks = (total + 255) / 256;
-    if (fused && chain->first) {   // the fp64 rows of verdict class 2 ride in this launch: a thread per output row
+    if (fused && chain->first && chain->fp64_rows) {   // the fp64 rows of verdict class 2 ride in this launch: a thread per output row (n = 1; wider chains: gated fp64 launches of the caller)
       const PackedMatrix &GF = tn ? *G_tn : G;
       fb = SmallNFallback{GF.d, GF.nslabs, m, k, dC, ldc, fill_rows, tn ? 1 : 0, trans ? 1 : 0, centered ? 1 : 0, d_f};
       blocks = std::max(blocks, (fill_rows + 255) / 256);

@@ -246,7 +246,7 @@ int launch_sparse_times_plink(const uint8_t *dP, size_t pitch, long entries, int
 // digits per column (S1 = 0: no second class), class 2: neither.  One call enqueues the chain of ONE class (my_class; its kernels do nothing unless the
 // verdict is that class); `first`: this call also launches the statistics pass, publishes E, the column sums and the three flag words, and carries the fp64
 // chains of class 2 inside its k_slice_B launch.  The caller enqueues the chains of all classes back to back; nothing waits for the host.
-struct I8Chain { int S0 = 0, S1 = 0, my_class = 0; bool first = true; };
+struct I8Chain { int S0 = 0, S1 = 0, my_class = 0; bool first = true; bool fp64_rows = true; };   // fp64_rows: verdict class 2 is served by the fp64 chains inside the first chain's k_slice_B launch (false: by gated launches of the caller)
 int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, bool centered, double *d_sumB,
                    double *d_sumfB, const double *d_f, Workspace &w, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int *splits_out, int guard = 0,
                    const int **flag_out = nullptr, double *colsum_scratch = nullptr, int S_override = 0, const PackedMatrix *G_tn = nullptr,

@@ -38,7 +38,7 @@ def set_engine(name):
 
 def last_path():
     """kernel family of the most recent product: 'k_gemm' (fp64 MFMA), 'k_lut' (fp64 pair tables: engine f64-strict, K < 128), 'k_gemm_i8' (exact int8
-    slicing) or 'k_small_n_fp64' (the fp64 chains behind the exactness guard of the int8 route: the device-side verdict declined it)"""
+    slicing) or 'k_small_n_fp64' (the fp64 path behind the exactness guard of the int8 route -- gated fp64 kernels, plain chains at n = 1 --: the device-side verdict declined it)"""
     return {0: "k_gemm", 1: "k_lut", 2: "k_gemm_i8", 3: "k_small_n_fp64"}[_lib.check_library_handle().mxa_last_path()]
 
 
