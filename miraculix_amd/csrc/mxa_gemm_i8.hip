@@ -145,7 +145,8 @@ constexpr int kSmallNMaxCols = 6;             // columns of a guarded small-n ch
 // triples that stood here -- k_lut + k_finish; k_pack_B + k_gemm<MODE 0> + k_finish -- cost ~5 us each on a 1 ms product whether or not they ran).
 // Plain form (tn = 0): thread <-> packed row, 32 bytes per slab of 128 genotypes; the entries of B are wave-uniform.
 // Transposed-operand form (tn = 1): thread <-> individual (a packed column), one byte per packed row; K runs over the rows.
-// n <= kSmallNMaxCols columns.  Not fast (a few ms on the config-5 shard) and not meant to be.
+// n <= kSmallNMaxCols columns.  SLOW (measured late in round 5 on 500k x 50k: 44 ms ('T') / 198 ms ('N') at n = 4): since then only chains of ONE column use it (n = 1 and a peeled
+// single column, where verdict class 2 needs inf / NaN or a span beyond 201 binades); wider chains are followed by gated launches of the fp64 kernels (mxa_api.cpp: guarded_small).
 struct SmallNFallback {
   const uint8_t *G;                 // nullptr: no fallback in this launch
   long nslabs, m, k;
