@@ -1,19 +1,20 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: effective GFLOP/s of dgemm_compressed (2-bit SNP x fp64) on N MI355X.
 
-Structure: setup_process / stage_headline / make_step_and_sync / run_timed (the timed region and `value`), then legs that never feed
-`value`: per_rank (launcher) or per_shard + p2p_reduction / rccl_reduction (the one that was not timed as `value`: RCCL is, wherever every shard has its own device) + hub_operands_on_first_device (in-process N > 1), opt_in_engine,
-abi_end_to_end, cpu_baseline + check, and at N = 1 the other BASELINE configs under their own checkers: config5_cg_step,
-config4_shard, config3_crossprod (reference harness shape: utils/benchmark/benchmark.f90:182-254).
+python bench.py --gpus N --steps K --warmup W   (N > 1: launched by torch.distributed.run, one rank per GPU; without a launcher: SNP shards behind the C ABI)
 
-Workload (BASELINE.json configs[1]): 1M SNPs x 50k individuals, n=32, dgemm_compressed 'N' and 'T', uncentred,
-synthetic PLINK data generated on the device.  One step = one 'N' multiply (+ the fp64 all-reduce of the indiv x n
-result when N > 1) and one 'T' multiply; flops per step = 2 * (2 * snps * indiv * n).  Inputs (packed genotypes, B, C)
-are resident in HBM when the timed region starts.  N > 1: the SNP dimension is sharded over the ranks (strong scaling,
-total work fixed), one process per GPU, RCCL all-reduce.
+Workload (BASELINE.json configs[1]): 1M SNPs x 50k individuals, n = 32, dgemm_compressed 'N' and 'T', uncentred, synthetic PLINK data generated on
+the device.  One step = one 'N' multiply (+ the fp64 reduction of the indiv x n result when N > 1) and one 'T' multiply; flops per step =
+2 * (2 * snps * indiv * n).  Inputs (packed genotypes, B, C) are resident in HBM when the timed region starts.  N > 1: the SNP dimension is sharded
+(strong scaling, total work fixed).
 
-python bench.py --gpus N --steps K --warmup W   (N > 1: launched by torch.distributed.run, one rank per GPU)
-"""
+Order of a run: setup_process / stage_headline -> ONE untimed step checked against the oracle (oracle_check: every N, every form; a violation ends the run
+without a number) -> warm-up -> the timed region (run_timed: `value`) -> legs that never feed `value`: per_rank (launcher) or per_shard + the other
+reduction + hub operands (in-process N > 1), opt-in engines, abi_end_to_end, cpu_baseline (+ the check against the CPU library), and at N = 1 the other
+BASELINE configs under their own checkers (config5_cg_step, config4_shard, config3_crossprod, the full-extent legs).
+
+Output: ONE compact JSON line on stdout (compact_line: <= 4 KB -- the contract's keys, roofline, cpu_baseline + cpu_baseline_port, check, who reduced,
+one number per leg: c3_* crossproduct, c4_* config 4, c5_* CG step) and everything measured in bench_detail.json beside this file."""
 import argparse
 import ctypes
 import json
@@ -154,7 +155,7 @@ def cpu_baseline_and_check(torch, mx, plink_dev, freq_dev, snps, indiv, n, B_T, 
             "kind": "port (about 2x faster than the reference build it restates: 735 against 373 GFLOP/s on 16 cores, BENCH_r04; not tuned further)",
             "engine": "oracle/oracle.c oracle5_dgemm: 5-codes tables + lookup-add, OpenMP over the cores above (tracked source, built by __graft_entry__.build())",
             "sample": what + f" (N {times[0]:.3f}s, T {times[1]:.3f}s)"}
-    base, extra = port, None
+    base, extra = port, port          # both keys are always in the line: `cpu_baseline` = the reference's own library where it travelled, else the port; `cpu_baseline_port` = the port
     if have_reference():
         rt = {}
         _, rt[0] = run_reference(prob, 0, Bn, centered=False, variant=256, cores=cores, reps=2)
@@ -164,7 +165,6 @@ def cpu_baseline_and_check(torch, mx, plink_dev, freq_dev, snps, indiv, n, B_T, 
                           "oracle/Makefile.ref; git-ignored build output that travelled with this push -- a clean checkout reports the port instead",
                 "sample": what + f" (N {rt[0]:.3f}s, T {rt[1]:.3f}s)",
                 "port_T_output_bitwise_equal_to_reference_build": bool(np.array_equal(Ct_ref[:, :sample], Ct_cpu[:, :sample]))}
-        extra = port
     # parity: GPU 'T' rows of the sample against the CPU engine
     got = C_T[:sample].t().cpu().numpy()
     err_t = float(np.abs(got - Ct_cpu[:, :sample]).max() / np.abs(Ct_cpu[:, :sample]).max())
@@ -254,14 +254,17 @@ def measure_traffic(args):
 
 
 # ====================================================================================================== helpers shared by the legs
-def extract_sample(torch, S, nsample=64, seed=1):
+def extract_sample(torch, S, nsample=64, seed=1, seed_rows=None):
     """the packed rows a sampled check needs, copied to the host: nsample individuals (rows of the individual-major matrix) for 'N' and
     nsample SNPs (rows of the SNP-major matrix) for 'T'.  After this the raw device matrices may be released (the full-extent legs need
-    the memory for the staged objects)."""
+    the memory for the staged objects).  seed_rows: the SNP rows from a generator of their own (the launcher's ranks sample the same individuals
+    and different SNP rows)."""
     import numpy as np
     dev, snps, indiv = S["dev"], S["snps"], S["indiv"]
     rng = np.random.default_rng(seed)
     ii = np.sort(rng.choice(indiv, min(nsample, indiv), replace=False))
+    if seed_rows is not None:
+        rng = np.random.default_rng(seed_rows)
     ss = np.sort(rng.choice(snps, min(nsample, snps), replace=False))
     f = S["f"].cpu().numpy()
     return dict(snps=snps, indiv=indiv, dev=dev, f=f, ii=ii, ss=ss,
@@ -825,6 +828,9 @@ def stage_headline(W, args, mx, L):
     W.eng = HipLocalEngine(plink, plink_t, W.snps_loc, indiv, freq, n, centered=bool(args.centered))
     os.environ.pop("MIRACULIX_NUM_GPUS", None)
     W.n_shards = mx.dgemm_compressed.num_shards(W.eng.obj)
+    # the packed rows the in-run oracle check needs (oracle_check): 64 individuals -- the SAME on every rank -- and 64 SNP rows of this process's block
+    # (one process: of the whole matrix), copied to the host before the raw matrices are released
+    W.sample = extract_sample(torch, dict(dev=device, snps=W.snps_loc, indiv=indiv, plink=plink, plink_t=plink_t, f=freq), nsample=64, seed=1, seed_rows=101 + W.rank)
     W.keep_raw = W.world == 1 and not W.inprocess and not args.no_cpu_baseline       # the CPU-baseline / parity leg samples the raw matrices
     W.plink, W.plink_t, W.freq = (plink, plink_t, freq) if W.keep_raw else (None, None, None)
     del plink, plink_t
@@ -832,7 +838,11 @@ def stage_headline(W, args, mx, L):
     W.op = ShardedGenotypeOperator(W.eng, snps, indiv)
     W.op.force_collective = W.force_dist
     g = torch.Generator(device=device); g.manual_seed(43)
-    W.B_N = torch.randn((n, snps), dtype=torch.float64, device=device, generator=g)[:, b:e].contiguous().t()   # snps_loc x n, column-major
+    # MXA_BENCH_TEST_MISCUT=1 (tests only): ranks / shards > 0 take their rows of B four SNPs too early -- an error BOTH products share, which the adjoint
+    # identity cannot see and the oracle check must (tests/test_bench_rehearsal_gpu.py)
+    W.miscut = 4 if os.environ.get("MXA_BENCH_TEST_MISCUT") == "1" else 0
+    bb, ee = (b - W.miscut, e - W.miscut) if (W.rank > 0 and W.miscut) else (b, e)
+    W.B_N = torch.randn((n, snps), dtype=torch.float64, device=device, generator=g)[:, bb:ee].contiguous().t()   # snps_loc x n, column-major
     W.B_T = torch.randn((n, indiv), dtype=torch.float64, device=device, generator=g).t()                       # indiv x n
     W.C_N = torch.zeros((n, indiv), dtype=torch.float64, device=device).t()
     W.C_T = torch.zeros((n, W.snps_loc), dtype=torch.float64, device=device).t()
@@ -848,7 +858,8 @@ def stage_headline(W, args, mx, L):
         W.BN_s, W.CT_s, W.BT_s = [], [], []
         for (b1, e1), d in zip(W.bounds, W.devs):
             buf = torch.zeros((n, ld), dtype=torch.float64, device=d)
-            buf[:, : e1 - b1] = W.B_N[b1:e1].t().to(d)
+            mc = W.miscut if b1 > 0 else 0
+            buf[:, : e1 - b1] = W.B_N[b1 - mc:e1 - mc].t().to(d)
             W.BN_s.append(buf.t()[: e1 - b1])
             W.CT_s.append(torch.zeros((n, ld), dtype=torch.float64, device=d).t()[: e1 - b1])
             W.BT_s.append(W.B_T if d == device else W.B_T.t().to(d).t())
@@ -916,6 +927,75 @@ def adjoint_check(W):
     return err
 
 
+def oracle_check(W, args):
+    """Parity against the checker on EVERY run and for every N, before timing counts: sampled rows of both products of one untimed step against
+    the long-double dense oracle (oracle/oracle.c) on the extracted packed rows; tolerance 1e-11 of the largest reference entry; a violation ends the run
+    WITHOUT a number, on every rank.  Independent of the partition logic it checks: the global matrix is the concatenation of the ranks' blocks in rank
+    order, the global B of 'N' is regenerated whole from its seed.
+      'T' (no exchange): 64 SNP rows of every rank's / of the whole matrix's result -- in-process: read from the shard that owns the row.
+      'N' (the reduced result): 64 individuals; under the launcher their packed bytes (64 x snps_loc / 4 per rank; the blocks are cut at multiples of 4) and
+           the ranks' allele frequencies are gathered on rank 0, which checks the all-reduced C_N.
+    Returns the `check` keys of the line."""
+    import numpy as np
+    torch, dist = W.torch, W.dist
+    snps, indiv, n = args.snps, args.indiv, args.ncol
+    cols = [0, n - 1] if n > 1 else [0]
+    cen = int(bool(args.centered))
+    sm = W.sample
+    out = {"tol": 1e-11, "rows_N": int(len(sm["ii"])), "cols": cols}
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        err_n = check_sample(torch, sm, 0, W.B_N, W.C_N, cols, cen)
+        if W.inprocess:
+            err_t, rows_t = 0.0, 0
+            for g, (b1, e1) in enumerate(W.bounds):
+                sel = (sm["ss"] >= b1) & (sm["ss"] < e1)
+                if not sel.any():
+                    continue
+                sub = dict(sm, ss=sm["ss"][sel], rows_s=np.ascontiguousarray(sm["rows_s"][sel]))
+                err_t = max(err_t, check_sample(torch, sub, 1, W.BT_s[g], W.CT_s[g], cols, cen, row_offset=b1))
+                rows_t += int(sel.sum())
+        else:
+            err_t, rows_t = check_sample(torch, sm, 1, W.B_T, W.C_T, cols, cen), int(len(sm["ss"]))
+    else:
+        world, rank = dist.get_world_size(), dist.get_rank()
+        on_host = dist.get_backend() != "nccl"                       # the gloo rehearsal gathers host tensors
+        cdev = torch.device("cpu") if on_host else W.device
+        err_t = check_sample(torch, sm, 1, W.B_T, W.C_T, cols, cen)
+        rows_t = int(len(sm["ss"])) * world
+        sizes = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([W.snps_loc], dtype=torch.int64, device=cdev))
+        sizes = [int(x.item()) for x in sizes]
+        maxs = max(sizes)
+        rb = (W.snps_loc + 3) // 4
+        buf = torch.zeros((len(sm["ii"]), (maxs + 3) // 4), dtype=torch.uint8, device=cdev)
+        buf[:, :rb] = torch.from_numpy(sm["rows_t"]).to(cdev)
+        fb = torch.zeros(maxs, dtype=torch.float64, device=cdev)
+        fb[: W.snps_loc] = torch.from_numpy(sm["f"]).to(cdev)
+        gb = [torch.zeros_like(buf) for _ in range(world)]
+        gf = [torch.zeros_like(fb) for _ in range(world)]
+        dist.all_gather(gb, buf)
+        dist.all_gather(gf, fb)
+        err_n = 0.0
+        if rank == 0:
+            if sum(sizes) != snps or any(x % 4 for x in sizes[:-1]):
+                raise SystemExit(f"bench.py: the ranks' SNP blocks {sizes} do not tile {snps} SNPs at multiples of 4: no number reported")
+            rows = np.ascontiguousarray(np.concatenate([g[:, : (x + 3) // 4].cpu().numpy() for g, x in zip(gb, sizes)], axis=1))
+            f_all = np.concatenate([g[:x].cpu().numpy() for g, x in zip(gf, sizes)])
+            gen = torch.Generator(device=W.device); gen.manual_seed(43)
+            B_all = torch.randn((n, snps), dtype=torch.float64, device=W.device, generator=gen)          # the call of stage_headline, whole
+            glob = dict(snps=snps, indiv=indiv, dev=W.device, f=f_all, ii=sm["ii"], rows_t=rows)
+            err_n = check_sample(torch, glob, 0, B_all.t(), W.C_N, cols, cen)
+            del B_all
+        e = torch.tensor([err_t, err_n], dtype=torch.float64, device=cdev)
+        e = torch.where(torch.isnan(e), torch.full_like(e, 1e300), e)
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        err_t, err_n = float(e[0].item()), float(e[1].item())
+    out.update({"oracle_T_max_rel_err": err_t, "oracle_N_max_rel_err": err_n, "rows_T": rows_t})
+    if not (err_t <= 1e-11 and err_n <= 1e-11):
+        raise SystemExit(f"bench.py: GPU results differ from the oracle ({out}): no number reported")
+    return out
+
+
 def per_shard_report(W, mx, args, flops_shard):
     """in-process N > 1: what every shard did in the timed region (HIP events on the streams the work ran on)"""
     info = mx.dgemm_compressed.multi_info(W.eng.obj)
@@ -963,7 +1043,7 @@ def opt_in_engine_leg(W, L, args, step, sync, engine, flops_step, description):
         path = L.mxa_last_path()
     finally:
         L.mxa_set_engine(0)
-    digits = ga.value if engine == 4 else 10 if engine == 5 else 7          # of the last product of the step ('T'); engine 4 reports its per-call choice; engine 5: class 0 of a 6-column chunk
+    digits = ga.value if engine == 4 else 7          # of the last product of the step ('T'); engine 4 reports its per-call choice
     one_copy = bool(L.mxa_single_orientation(W.eng.obj) == 1)
     dN = float(((W.C_N - C_N64).abs().amax(dim=0) / C_N64.abs().amax(dim=0)).max())
     dT = float(((W.C_T - C_T64).abs().amax(dim=0) / C_T64.abs().amax(dim=0)).max())
@@ -1030,10 +1110,17 @@ def main():
     # ---- the timed region: W untimed steps, then exactly K steps between barrier + synchronize on both sides
     step, sync = make_step_and_sync(W, mx)
     reduction = "none (one GPU)"
-    reduction_info = {}
+    reduction_info = {"world_size": 1, "rccl_ranks": 0}
     if dist.is_initialized():
         reduction = "rccl all-reduce (torch.distributed, one process per GPU)" if os.environ.get("MXA_BENCH_BACKEND", "nccl") == "nccl" else "gloo all-reduce (rehearsal)"
         reduction_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0}
+        # can this rank's device reach rank 0's memory directly (xGMI peer access)?  -1: same device (one-GPU rehearsal)
+        me, root = torch.cuda.current_device(), 0
+        pa = -1 if (os.environ.get("MXA_BENCH_SINGLE_DEVICE") == "1" or me == root) else int(torch.cuda.can_device_access_peer(me, root))
+        cdev = torch.device("cpu") if dist.get_backend() != "nccl" else W.device
+        allpa = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(dist.get_world_size())]
+        dist.all_gather(allpa, torch.tensor([pa], dtype=torch.int64, device=cdev))
+        reduction_info["peer_access_to_rank0"] = [int(x.item()) for x in allpa]
     elif W.inprocess:
         reduction = "p2p"
         if args.reduce in ("auto", "rccl"):   # the timed reduction is RCCL's wherever RCCL applies; any failure falls back to p2p and is said in the line
@@ -1048,6 +1135,10 @@ def main():
                     dg.multi_set_reduction(W.eng.obj, "p2p")
                 except RuntimeError:
                     pass
+    # ---- parity first ("parity check on every run ... before timing counts"): one untimed step, both results against the oracle, for every N
+    step()
+    sync()
+    chk = oracle_check(W, args)
     for _ in range(args.warmup):
         step()
     sync()
@@ -1070,8 +1161,9 @@ def main():
         dt = run_timed(W, step, sync, 0, args.steps)
     if W.inprocess:
         info0 = dg.multi_info(W.eng.obj)
-        reduction_info = {"rccl_ranks": info0["shards"] if reduction == "rccl" else 0, "rccl_checked": bool(info0["rccl_checked"]),
-                          "rccl_vs_p2p_max_rel_diff": info0["rccl_vs_p2p_max_rel_diff"], "devices": info0["devices"]}
+        reduction_info = {"world_size": 1, "shards": info0["shards"], "rccl_ranks": info0["shards"] if reduction == "rccl" else 0, "rccl_checked": bool(info0["rccl_checked"]),
+                          "rccl_vs_p2p_max_rel_diff": info0["rccl_vs_p2p_max_rel_diff"], "devices": info0["devices"],
+                          "peer_access_to_root": [s["peer_to_root"] for s in info0["per_shard"]]}
     launches, total_ms = kernel_profile(L)
     adj_err = adjoint_check(W)
     flops_step = 2 * 2.0 * snps * indiv * n
@@ -1145,16 +1237,13 @@ def main():
 
     # informational extra passes, outside the timed region: the same steps with the two opt-in int8 engines (include/miraculix_amd.h,
     # mxa_set_engine).  Reported beside the headline, never as `value`.
-    alt = alt_exact = alt_guarded = None
+    alt = alt_exact = None
     if not args.no_alt_engine and not W.inprocess:
         alt = opt_in_engine_leg(W, L, args, step, sync, 1, flops_step,
                                 "i8: B split into 7 radix-256 digits per column (to 2^-54 of the column maximum, no exactness check), v_mfma_i32_32x32x32_i8, exact int32 sums, fp64 recombination")
         alt_exact = opt_in_engine_leg(W, L, args, step, sync, 4, flops_step,
                                       "i8-exact: digit count chosen per call from the measured exponent span of B so that B is represented WITHOUT error "
                                       "(|error| <= 3.02 (S-1) 2^-53 sum|z b| per output, tighter than an fp64 FMA chain); fp64 MFMA path when that needs more than 24 digits")
-        alt_guarded = opt_in_engine_leg(W, L, args, step, sync, 5, flops_step,
-                                        "i8-guarded: the default engine's guarded exact int8 route for every n -- chunks of <= 6 columns, each with its verdict formed ON THE DEVICE "
-                                        "(10 or 16 digits per column at 6 columns; fp64 chains for a chunk that is not exactly representable): asynchronous, no host read")
 
     # ABI end-to-end (reference harness utils/benchmark/benchmark.f90:192-209): the same two products with HOST
     # B and C through the plain reference symbol dgemm_compressed -- what a Julia / Fortran caller sees, PCIe included.
@@ -1215,7 +1304,7 @@ def main():
                                    + (" inside one process behind the C ABI (MIRACULIX_NUM_GPUS), operands per shard on the shards' devices" if W.inprocess else ""),
                        "snps": snps, "indiv": indiv, "ncol": n, "parallelism": f"snp-shard{W.n_gpus}",
                        "genotypes": "p_s ~ U(0.1, 0.6), g ~ Binomial(2, p_s), no missings; B ~ N(0, 1)"},
-            "check": {"adjoint_identity_max_rel_err": adj_err, "adjoint_tolerance": 1e-10},
+            "check": {"adjoint_identity_max_rel_err": adj_err, "adjoint_tolerance": 1e-10, **chk},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "GB per launch, measured by this run (two rocprofv3 --pmc child passes of the same workload)", "traffic_detail": traffic_detail,
@@ -1235,8 +1324,6 @@ def main():
             out["opt_in_engine"] = alt
         if alt_exact is not None:
             out["opt_in_engine_exact"] = alt_exact
-        if alt_guarded is not None:
-            out["opt_in_engine_guarded"] = alt_guarded
         if abi is not None:
             out["abi_end_to_end"] = abi
         if W.keep_raw:   # CPU baseline + parity against the checker: rank 0 at N = 1 only
@@ -1279,10 +1366,93 @@ def main():
         if bad:
             raise SystemExit(f"bench.py: parity check failed in {bad}: {json.dumps({k: out[k] for k in bad})}")
     if W.rank == 0:
+        # everything measured goes to bench_detail.json (next to this file, and to gpurun_out/ when that exists); the ONE line on stdout is its compact
+        # summary (<= 4 KB, so that the driver's record keeps every leg)
+        for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+            if os.path.isdir(d):
+                try:
+                    with open(os.path.join(d, "bench_detail.json"), "w") as fh:
+                        json.dump(out, fh, indent=1)
+                except OSError:
+                    pass
+        line = json.dumps(compact_line(out), separators=(",", ":"))
+        assert len(line) <= 4096, len(line)
         sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        os.write(real_stdout, (line + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def compact_line(d):
+    """the contract's JSON line: the headline, its roofline and CPU baseline, the in-run checks, who ran the reduction, and ONE number per
+    leg of the other BASELINE configs (c3_* crossproduct, c4_* config 4, c5_* CG step); prose and per-shard tables stay in bench_detail.json"""
+    g = lambda x, *ks: (g(x.get(ks[0]), *ks[1:]) if len(ks) > 1 else x.get(ks[0])) if isinstance(x, dict) and ks else x
+    rf = d["roofline"]
+    line = {k: d[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    c = d["config"]
+    line["config"] = {"workload": f"{c['snps']}x{c['indiv']} (SNPs x indiv), ncol={c['ncol']}, dgemm_compressed N+T per step, {'centred' if 'uncentred' not in c['workload'] else 'uncentred'}",
+                      "snps": c["snps"], "indiv": c["indiv"], "ncol": c["ncol"], "parallelism": c["parallelism"], "form": "in-process (MIRACULIX_NUM_GPUS)" if "inside one process" in c["workload"] else "one process per GPU"}
+    line["roofline"] = {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")} | {"kernel": "k_gemm<8,8,3>", "avg_launch_ms": rf["avg_launch_ms"], "launches": rf["launches"],
+                                                                                                       "algorithmic_GB": rf["algorithmic_bytes_per_launch_GB"]}
+    for k in ("cpu_baseline", "cpu_baseline_port"):
+        if k in d:
+            b = d[k]
+            line[k] = {"value": b["value"], "unit": b["unit"], "cores": b["cores"], "kind": b["kind"].split(" (")[0], "sample": b["sample"].split(", one 'N'")[0]}
+    ck = d["check"]
+    line["check"] = {k: ck[k] for k in ("oracle_T_max_rel_err", "oracle_N_max_rel_err", "rows_T", "rows_N", "tol", "adjoint_identity_max_rel_err",
+                                        "gpu_T_rows_vs_cpu_library_max_rel_err", "gpu_N_64_sampled_rows_vs_dense_oracle_max_rel_err") if k in ck}
+    line["reduction"] = d["reduction"][:90]
+    for k in ("world_size", "backend", "shards", "rccl_ranks", "rccl_checked", "devices", "peer_access_to_rank0", "peer_access_to_root"):
+        if k in d:
+            line[k] = d[k]
+    if "predicted_ms_per_step_from_per_shard" in d:
+        line["predicted_ms_per_step"] = d["predicted_ms_per_step_from_per_shard"]["from_this_run"]
+    if "per_rank" in d:
+        line["k_gemm_ms_per_rank"] = d["per_rank"]["avg_k_gemm_launch_ms"]
+        line["allreduce_alone_ms"] = d["per_rank"]["allreduce_alone_ms"]
+    if "per_shard" in d:
+        line["k_gemm_ms_per_shard"] = [x["avg_k_gemm_ms"] for x in d["per_shard"]["shards"]]
+        line["reduce_kernel_ms"] = d["per_shard"]["avg_reduce_kernel_ms"]
+    for k in ("p2p_reduction", "rccl_reduction", "hub_operands_on_first_device"):
+        if k in d:
+            line[k.split("_")[0] + "_GFLOPs"] = g(d[k], "value") if "value" in d[k] else next(iter(d[k].values()))[:60]
+    if "abi_end_to_end" in d:
+        line["abi_GFLOPs"] = d["abi_end_to_end"]["mean_GFLOPs"]
+        line["abi_bitwise_equal"] = d["abi_end_to_end"]["bitwise_equal_to_device_resident_results"]
+    for k, short in (("opt_in_engine", "i8"), ("opt_in_engine_exact", "i8_exact")):
+        if k in d:
+            line["engine_" + short + "_GFLOPs"] = d[k]["value"]
+    failed = [k for k in d if isinstance(d[k], dict) and "failed" in d[k]]
+    c3 = d.get("config3_crossprod")
+    if c3 and "failed" not in c3:
+        for key, e in (("k_crossprod_i8 (int8 MFMA)", "i8"), ("k_crossprod_f4 (FP4 MFMA, default)", "f4")):
+            line[f"c3_ms_{e}"] = c3[key]["kernel_ms"]
+            line[f"c3_frac_{e}"] = c3[key]["frac_of_peak_executed"]
+        line["c3_exact"] = all(c3[key]["check"]["four_256x256_tiles_and_mirrors_bit_exact_vs_int32_oracle"] for key in c3 if key.startswith("k_crossprod"))
+        line["c3_workload"] = c3["workload"].split(",")[1].strip() + ", int8->int32 MFMA path (c3_*_i8) = the engine BASELINE config 3 names; FP4 MFMA = default while exact"
+    c5 = d.get("config5_cg_step")
+    if c5 and "failed" not in c5:
+        line.update({"c5_step_ms": c5["ms_per_cg_step"], "c5_step_ms_two_copies": c5["ms_per_cg_step_two_copies"], "c5_TBps": c5["algorithmic_TB_per_s"], "c5_frac_hbm": c5["frac_of_8_TBs_spec"],
+                     "c5_bitwise_T_then_N": c5["check"]["gram_matvec_bitwise_equals_T_then_N"]})
+    c4 = d.get("config4_shard")
+    if c4 and "failed" not in c4:
+        line["c4_shard_frac"] = [c4["N"]["frac_of_fp64_mfma_peak_kernel"], c4["T"]["frac_of_fp64_mfma_peak_kernel"]]
+    c4f = d.get("config4_full_one_copy")
+    if c4f and "failed" not in c4f:
+        line["c4_full_TFLOPs"] = [c4f["N"]["TFLOPs_call"], c4f["T"]["TFLOPs_call"]]
+        line["c4_full_snps"] = c4f["snps_run"]
+    c5f = d.get("config5_full_8_virtual_shards")
+    if c5f and "failed" not in c5f:
+        line["c5_full_ms"] = {k: c5f[k]["ms_per_gram_matvec"] for k in c5f if isinstance(c5f[k], dict) and "ms_per_gram_matvec" in c5f[k]}
+    c4e = d.get("config4_full_extent_8_virtual_shards")
+    if c4e and "failed" not in c4e:
+        line["c4_extent_TFLOPs_8_shards"] = [g(c4e, next(k for k in c4e if k.endswith("virtual_shards")), t, "TFLOPs_call") for t in ("N", "T")]
+    if any(k.startswith("config") for k in d):
+        line["legs_parity_ok"] = True          # (a violated leg check ends the run before this line is printed)
+    if failed:
+        line["legs_failed"] = failed
+    line["detail"] = "bench_detail.json"
+    return line
 
 
 def leg_checks_ok(leg):

@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--indiv", type=int, default=20_000)
     ap.add_argument("--lam", type=float, default=None, help="ridge term; default = snps (well-conditioned toy system)")
     ap.add_argument("--max-iter", type=int, default=200)
-    ap.add_argument("--engine", choices=["f64", "i8", "small-n-i8", "f64-strict"], default="f64",
+    ap.add_argument("--engine", choices=["f64", "i8", "f64-strict", "i8-exact"], default="f64",
                     help="f64 (default): at n = 1 the exact radix-256 splitting of the vector on the int8 matrix cores whenever a per-call check proves it exact "
                          "(HBM-bound), else fp64 pair tables; f64-strict: fp64 arithmetic only; i8: the splitting without the check")
     args = ap.parse_args()

@@ -291,40 +291,22 @@ int mxa_grm(const unsigned char *plink_transposed, int snps, int indiv, double *
             const double *allele_freq);
 int mxa_ld(const unsigned char *plink, int snps, int indiv, double *R, int is_plink_format, const double *allele_freq);
 
-/* multiply engine of dgemm_compressed (process-wide).
- * 0 (default): fp64 on v_mfma_f64_4x4x4_4b_f64, the arithmetic of the reference (fp64 FMAs), for n >= 3.  For n <= 2 -- the CG /
- *    GBLUP iteration, which is HBM-bound -- each column of B is split into balanced radix-256 digits (32 digits for n = 1, 16 for
- *    n = 2), the 0/1/2 genotypes are multiplied with the digit planes on the int8 matrix cores with exact int32/int64 sums and the
- *    planes are recombined in fp64, PROVIDED a per-call check on the device finds the split EXACT: every entry finite, and the
- *    binary-exponent span of the non-zero entries of each column at most 201 (n = 1) / 73 (n = 2).  Then no bit of B is dropped,
- *    the only roundings are the <= 31 additions of the recombination, and |error| <= 3.02 * 31 * 2^-53 * sum_k |z_k b_k| per
- *    output -- tighter than the K * 2^-53 * sum_k |z_k b_k| of any fp64 FMA chain of length K >= 128.  If the check fails (or
- *    K < 128) the fp64 pair-table kernel runs instead; results then and with engine 3 are fp64 lookup-add sums.
- *    3 <= n <= 6 (the products that would run on the narrowest MFMA tile, which the genotype extraction holds at 0.80 of the fp64 MFMA rate) take the
- *    same exact route.  Digits per column = what fits the tiles of 32 expanded columns: n = 3: 10 (one tile) or 21 (two), 4: 16 or 24, 5: 12 or 19,
- *    6: 10 or 16.  The verdict is a CLASS formed on the device (round 5): exact with the smaller count, exact with the larger one, or neither; the kernels of
- *    both classes are enqueued and each tests one flag word, so no product waits for the host.  Class "neither" (span beyond the digits, inf / NaN, a
- *    column near the underflow threshold): fp64 -- gated launches of the fp64 kernels behind the int8 chains (2 <= n <= 6, peeled pairs / triples), plain FMA chains inside the same
- *    launch sequence (n = 1).  1.0-1.5 ms instead of
- *    3.2-4.4 ms on 500k x 50k.  n >= 7: fp64 MFMA; the 1-3 odd columns of n = 4q + r through the same guarded route.
- * 1 (opt-in, also MXA_ENGINE=i8 in the environment): the int8 slicing for every n with 7 digits (32 / 16 for n = 1 / 2) and NO
- *    exactness check: B is represented to 2^-54 of each column's largest |entry| (fixed point per column, not per element);
- *    results agree with engine 0 to ~1e-14 of each result column's largest entry on the test problems, at ~4x the throughput.
- * 2 (MXA_ENGINE=small-n-i8): engine 1 for n <= 4 only, engine 0's fp64 path otherwise.
- * 3 (MXA_ENGINE=f64-strict): fp64 arithmetic for every n (n <= 2: the pair-table kernel, never the int8 route).
- * 4 (opt-in, MXA_ENGINE=i8-exact): the int8 slicing for EVERY n, but only when it is exact, with the digit count chosen per call: one
- *    pass over B measures the binary-exponent span of the non-zero entries of every column; S = max(7, ceil((span + 55) / 8)) digits
- *    represent every entry of B without error (the condition of engine 0's n <= 2 check), so the error bound above holds with S - 1
- *    additions: |error| <= 3.02 * (S - 1) * 2^-53 * sum_k |z_k b_k|, S <= 24.  Wider spans (> 137 binades), inf / NaN, columns whose largest
- *    entry lies below 2^(8S - 1023), or K < 128: engine 0's path.  Typical data (spans of 15-30 binades) need 9-11 digits; the product is
- *    then 2-3 times faster than the fp64 matrix cores allow.  n <= 2: as engine 0.  One host synchronisation per call.
- * 5 (opt-in, MXA_ENGINE=i8-guarded): engine 0's guarded exact route for EVERY n -- the columns go in balanced chunks of at most six, each chunk with its own
- *    device-side verdict (exact with the digits of two tiles / of three tiles / not exact -> the gated fp64 launches of that chunk) and one pass over the packed
- *    matrix: the ASYNCHRONOUS counterpart of engine 4 (nothing is read back; same error bound with S <= 24).  K < 128: engine 0's path.
- * mxa_set_engine returns the previous value (an invalid argument leaves the engine unchanged).  mxa_last_path: kernel family of
- * the most recent product: 0 = fp64 MFMA (k_gemm), 1 = fp64 pair tables (k_lut: engine f64-strict and K < 128, where the stored copy's rows are the
- * output rows), 2 = exact int8 slicing (k_gemm_i8 / k_gemm_i8_tn), 3 = the fp64 path behind a declined exactness guard (the verdict is read from the
- * device when this is called). */
+/* multiply engine of dgemm_compressed (process-wide; MXA_ENGINE in the environment sets the initial one).  Details and error bounds: DESIGN.md 3.2 / 3.3.
+ *
+ *   id  MXA_ENGINE   arithmetic                                                                     host waits
+ *   0   (default)    n >= 7: fp64 MFMA, the reference's FMA chains; n <= 6 and the 1-3 odd columns   never
+ *                    of n = 4q + r: exact int8 slicing of B when a device-side check proves it
+ *                    exact (|err| <= 3.02 (S-1) 2^-53 sum|z b|), else fp64
+ *   1   i8           int8 slicing for every n, 7 digits per column, no exactness check               never
+ *   3   f64-strict   fp64 for every n (n <= 2: pair tables)                                          never
+ *   4   i8-exact     int8 slicing for every n with the digit count chosen per call so that B is      once per call
+ *                    represented without error (S <= 24; otherwise engine 0's path)
+ *
+ * Only engine 0 is ever the benchmark's `value`.  Ids 2 and 5 (small-n-i8, i8-guarded; rounds 3-5) are retired.
+ * mxa_set_engine returns the previous id; an invalid id leaves the engine unchanged.
+ * mxa_last_path: kernel family of the MAIN part of the most recent product (the 4q columns of a peeled n = 4q + r; the peeled columns carry their own
+ * device-side verdict, which is not reported): 0 = k_gemm, 1 = k_lut (fp64 pair tables), 2 = k_gemm_i8 / k_gemm_i8_tn, 3 = fp64 behind a declined
+ * exactness check (read from the device when this is called). */
 int mxa_set_engine(int engine);
 int mxa_get_engine(void);
 int mxa_last_path(void);

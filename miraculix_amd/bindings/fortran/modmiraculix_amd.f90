@@ -83,7 +83,7 @@ module modmiraculix_amd
    integer(c_int) :: rc
   end function
 
-  function mxa_set_engine(engine) bind(C, name='mxa_set_engine') result(previous)   ! 0 default, 1 i8, 2 small-n-i8, 3 f64-strict, 4 i8-exact, 5 i8-guarded
+  function mxa_set_engine(engine) bind(C, name='mxa_set_engine') result(previous)   ! 0 default, 1 i8, 3 f64-strict, 4 i8-exact
    import c_int
    integer(c_int), value, intent(in) :: engine
    integer(c_int) :: previous

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -27,14 +28,12 @@ Options &options() { static Options o; return o; }
 Profile &profile() { static Profile p; return p; }
 Geometry &last_geometry() { static Geometry g; return g; }
 static bool g_profile_on = true;
-// multiply engine: 0 = fp64 MFMA (default), 1 = exact int8 slicing on the int8 MFMA (opt-in; MXA_ENGINE=i8 or mxa_set_engine)
+// multiply engine (include/miraculix_amd.h, mxa_set_engine): 0 = fp64 MFMA (default), 1 = int8 slicing, 3 = fp64 only, 4 = exact int8 slicing; ids 2 and 5 (rounds 3-5) are retired
 static std::atomic<int> g_engine{[] {
   const char *e = getenv("MXA_ENGINE");
   if (e && std::string(e) == "i8") return 1;
-  if (e && std::string(e) == "small-n-i8") return 2;
   if (e && std::string(e) == "f64-strict") return 3;
   if (e && std::string(e) == "i8-exact") return 4;
-  if (e && std::string(e) == "i8-guarded") return 5;
   return 0;
 }()};
 
@@ -87,6 +86,20 @@ void debug_info(const char *fmt, ...) {
   vprintf(fmt, ap);
   printf("\n");
   va_end(ap);
+}
+
+thread_local CallClock *tl_call_clock = nullptr;
+double CallClock::now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+void CallClock::mark(const char *what) {
+  if (!on) return;
+  const double t = now();
+  if (len < (int)sizeof(line) - 48) len += snprintf(line + len, sizeof(line) - len, " %s %.3f", what, (t - last) * 1e3);
+  last = t;
+}
+void CallClock::report(const char *head) {
+  if (!on) return;
+  printf("\t %s: total %.3f ms |%s (ms)\n", head, (now() - t0) * 1e3, line);
+  on = false;
 }
 
 static Handle *as_handle(void *p, const char *who) {
@@ -263,16 +276,20 @@ static int ensure_partials(Workspace &w, const GemmPlan &p, hipStream_t s) {
 // most 16 GiB (a group costs one more read + write of C: 18 groups of config 4's 'T' 1.3 % of the call, 6 groups 0.4 %) and at most what the device has
 // free right now (the old buffer counted as free: it is released before the new one is allocated) less 2 GiB; never less than ONE split's partials.
 // MXA_P_BUDGET_MB overrides (tests force the grouped path on small products).
-static size_t partial_budget(const Workspace &w, size_t need, size_t one_split) {
-  const char *e_mb = getenv("MXA_P_BUDGET_MB");   // read per call: the tests switch it
+// The memory-dependent part is decided ONCE per object (Workspace::big_budget, at the first product that needs it): later products reuse it, so a solver
+// loop never re-grows the buffer because more memory happens to be free (hipFree + device sync + a multi-GiB hipMalloc in the middle of the loop).
+static size_t partial_budget(Workspace &w, size_t need, size_t one_split) {
+  const char *e_mb = getenv("MXA_P_BUDGET_MB");   // test knob, read per product: tests/test_grouped_and_incremental_gpu.py switches it on one object
   const long env_mb = e_mb ? atol(e_mb) : -1L;
   if (env_mb >= 0) return std::max(one_split, std::min(need, (size_t)env_mb * (1u << 20) / sizeof(double)));
   if (need * sizeof(double) <= ((size_t)4 << 30) || need <= w.cap_P) return need;
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return need; }
-  const size_t avail = free_b + w.cap_P * sizeof(double), margin = (size_t)2 << 30, soft = (size_t)16 << 30;
-  const size_t cap = std::min(soft, avail > margin ? avail - margin : 0) / sizeof(double);
-  return std::max(one_split, std::min(need, std::max(cap, (size_t)w.cap_P)));
+  if (!w.big_budget) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return need; }
+    const size_t avail = free_b + w.cap_P * sizeof(double), margin = (size_t)2 << 30, soft = (size_t)16 << 30;
+    w.big_budget = std::max<size_t>(1, std::min(soft, avail > margin ? avail - margin : 0) / sizeof(double));
+  }
+  return std::max(one_split, std::min(need, std::max(w.big_budget, (size_t)w.cap_P)));
 }
 
 static int ensure_workspace(Handle *h, int n) {
@@ -293,6 +310,24 @@ static int ensure_workspace(Handle *h, int n) {
     MXA_HIP(hipMalloc(reinterpret_cast<void **>(&w.d_denflag), (16 + 16 * 16) * sizeof(int)));
     MXA_HIP(hipMemset(w.d_denflag, 0, (16 + 16 * 16) * sizeof(int)));
     w.d_ctr = w.d_denflag + 16;
+  }
+  return 0;
+}
+
+// digits per column of the guarded exact int8 route by column count (gemm_device: guarded_small): class 0 / class 1
+static const int kSmallS0[7] = {0, 32, 16, 10, 16, 12, 10}, kSmallS1[7] = {0, 0, 0, 21, 24, 19, 16};
+
+// The int8 workspace the guarded route of an n-column product will ask for (n <= 6: the whole product; n = 4q + r: the r peeled columns), reserved when
+// the object is made instead of inside the first product (1.1-1.4 ms of hipMalloc in the first dgemm_compressed call of the reference's harness).
+static int reserve_small_routes(Handle *h, int n) {
+  const int nc = n <= 6 ? n : (n & 3);
+  if (nc <= 0 || g_engine.load() != 0) return 0;
+  for (int trans = 0; trans < 2; trans++) {
+    const PackedMatrix &G = trans ? h->snp_major : h->ind_major;
+    if (G.k < 128) continue;
+    const PackedMatrix *G_tn = (h->single && !trans) ? &h->snp_major : nullptr;
+    if (gemm_i8_reserve(G, nc, kSmallS0[nc], G_tn, h->ws, h->stream) == 1) return 1;
+    if (kSmallS1[nc] && gemm_i8_reserve(G, nc, kSmallS1[nc], G_tn, h->ws, h->stream) == 1) return 1;
   }
   return 0;
 }
@@ -374,16 +409,20 @@ int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink
                      stage_matrix(h->ind_major, plink_t, plink_t_pitch, indiv, snps, h->stream))) { destroy_handle(h); return 1; }
   if (!check_hip(hipMalloc(reinterpret_cast<void **>(&h->d_f), sizeof(double) * snps), __func__, __LINE__)) { destroy_handle(h); return 1; }
   h->h_f = (double *)calloc((size_t)snps, sizeof(double));
+  if (!h->h_f) { set_error(12, "plink2compressed: out of host memory for %ld allele frequencies", snps); destroy_handle(h); return 1; }
   if (f) {
     hipError_t e = hipMemcpy(h->d_f, f, sizeof(double) * snps, hipMemcpyDefault);
-    if (!check_hip(e, __func__, __LINE__)) { destroy_handle(h); return 1; }
-    e = hipMemcpy(h->h_f, h->d_f, sizeof(double) * snps, hipMemcpyDeviceToHost);
     if (!check_hip(e, __func__, __LINE__)) { destroy_handle(h); return 1; }
     h->has_f = true;
   } else {
     (void)hipMemset(h->d_f, 0, sizeof(double) * snps);
   }
-  if (ensure_workspace(h, h->max_n)) { destroy_handle(h); return 1; }
+  // The host copy of the frequencies travels on the OBJECT'S stream: the first device-to-host copy a stream issues pays the runtime's lazy set-up of that
+  // path -- 7-9 ms, which the reference's harness otherwise meets inside its first dgemm_compressed call (the download of a 4 MB C took 7.2-9.3 ms on the
+  // device's own clock there, a 20 MB one later 0.4: profiles/r06_harness_phase_clock.txt).  Here it is part of plink2compressed.
+  if (!check_hip(hipMemcpyAsync(h->h_f, h->d_f, sizeof(double) * snps, hipMemcpyDeviceToHost, h->stream), __func__, __LINE__) ||
+      !check_hip(hipStreamSynchronize(h->stream), __func__, __LINE__)) { destroy_handle(h); return 1; }
+  if (ensure_workspace(h, h->max_n) || reserve_small_routes(h, h->max_n)) { destroy_handle(h); return 1; }
   *out = h;
   return 0;
 }
@@ -424,6 +463,7 @@ int begin_handle(long snps, long indiv, int max_n, void **out, int device) {
   if (!check_hip(hipMalloc(reinterpret_cast<void **>(&h->d_f), sizeof(double) * snps), __func__, __LINE__) ||
       !check_hip(hipMemsetAsync(h->d_f, 0, sizeof(double) * snps, h->stream), __func__, __LINE__)) { destroy_handle(h); return 1; }
   h->h_f = (double *)calloc((size_t)snps, sizeof(double));
+  if (!h->h_f) { set_error(12, "mxa_plink2compressed_begin: out of host memory for %ld allele frequencies", snps); destroy_handle(h); return 1; }
   h->has_f = true;
   if (ensure_workspace(h, h->max_n)) { destroy_handle(h); return 1; }
   *out = h;
@@ -434,6 +474,13 @@ int append_rows(Handle *h, const uint8_t *rows, long snp_begin, long nrows, cons
   if (!h->staging) { set_error(19, "mxa_plink2compressed_rows: the object is sealed (or was not made by mxa_plink2compressed_begin)"); return 1; }
   if (!rows || snp_begin < 0 || nrows <= 0 || snp_begin + nrows > h->snps) {
     set_error(1, "mxa_plink2compressed_rows: need rows != NULL and 0 <= snp_begin, snp_begin + nrows <= snps (got [%ld, %ld) of %ld)", snp_begin, snp_begin + nrows, h->snps);
+    return 1;
+  }
+  // coverage is an interval set, not a count: a block appended twice (a retried block) or overlapping another one is refused, so that an object can only
+  // be sealed with every SNP row written exactly once
+  auto at = std::lower_bound(h->staged_iv.begin(), h->staged_iv.end(), std::make_pair(snp_begin, snp_begin));
+  if ((at != h->staged_iv.end() && at->first < snp_begin + nrows) || (at != h->staged_iv.begin() && std::prev(at)->second > snp_begin)) {
+    set_error(1, "mxa_plink2compressed_rows: rows [%ld, %ld) overlap rows that were already appended", snp_begin, snp_begin + nrows);
     return 1;
   }
   MXA_HIP(hipSetDevice(h->device));
@@ -467,20 +514,24 @@ int append_rows(Handle *h, const uint8_t *rows, long snp_begin, long nrows, cons
     if (rc) return 1;
   }
   h->staged_rows += nrows;
+  h->staged_iv.insert(at, {snp_begin, snp_begin + nrows});
   return 0;
 }
 
 int end_handle(Handle *h) {
   if (!h->staging) { set_error(19, "mxa_plink2compressed_end: the object is already sealed"); return 1; }
-  if (h->staged_rows != h->snps) {
-    set_error(1, "mxa_plink2compressed_end: %ld SNP rows were appended, the object has %ld", h->staged_rows, h->snps);
+  long covered = 0, next = 0;          // the intervals are disjoint and sorted: full coverage = they chain from 0 to snps
+  for (const auto &iv : h->staged_iv) { if (iv.first != next) break; next = iv.second; covered = next; }
+  if (covered != h->snps) {
+    set_error(1, "mxa_plink2compressed_end: %ld SNP rows were appended, the object has %ld (first row not yet appended: %ld)", h->staged_rows, h->snps, covered);
     return 1;
   }
+  h->staged_iv.clear(); h->staged_iv.shrink_to_fit();
   MXA_HIP(hipSetDevice(h->device));
+  MXA_HIP(hipMemcpyAsync(h->h_f, h->d_f, sizeof(double) * h->snps, hipMemcpyDeviceToHost, h->stream));   // (on the object's stream: see create_handle)
   MXA_HIP(hipStreamSynchronize(h->stream));
-  MXA_HIP(hipMemcpy(h->h_f, h->d_f, sizeof(double) * h->snps, hipMemcpyDeviceToHost));
   h->staging = false;
-  return 0;
+  return reserve_small_routes(h, h->max_n);
 }
 
 
@@ -517,11 +568,12 @@ static void harvest_slot(Handle *h, int slot) {
   std::lock_guard<std::mutex> lk(g_prof_mutex);
   profile().launches += 1; profile().total_ms += ms;
   h->prof.launches += 1; h->prof.kernel_ms += ms;
+  h->prof_last_kernel_ms = ms;
 }
 static void harvest_copies(Handle *h) {
   float ms = 0.f;
-  if (h->in_pending) { h->in_pending = false; if (elapsed_ms(h->ev_in[0], h->ev_in[1], &ms)) { h->prof.in_copies += 1; h->prof.in_ms += ms; } }
-  if (h->out_pending) { h->out_pending = false; if (elapsed_ms(h->ev_out[0], h->ev_out[1], &ms)) { h->prof.out_copies += 1; h->prof.out_ms += ms; } }
+  if (h->in_pending) { h->in_pending = false; if (elapsed_ms(h->ev_in[0], h->ev_in[1], &ms)) { h->prof.in_copies += 1; h->prof.in_ms += ms; h->prof_last_in_ms = ms; } }
+  if (h->out_pending) { h->out_pending = false; if (elapsed_ms(h->ev_out[0], h->ev_out[1], &ms)) { h->prof.out_copies += 1; h->prof.out_ms += ms; h->prof_last_out_ms = ms; } }
 }
 void harvest_profile(Handle *h) {
   if (!h) return;
@@ -583,6 +635,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   if (n > 65535) { set_error(7, "dgemm_compressed: n = %d exceeds the supported 65535 columns per call", n); return 1; }
   if (n > h->max_n) { h->max_n = n; }
   if (ensure_workspace(h, n)) return 1;
+  clock_mark("workspace");
   Workspace &w = h->ws;
   double *d_sumB = w.d_colpart + (size_t)n * 128, *d_sumfB = d_sumB + n;
   const int engine = g_engine.load();
@@ -592,6 +645,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     if (!h->ev0[slot]) { MXA_HIP(hipEventCreate(&h->ev0[slot])); MXA_HIP(hipEventCreate(&h->ev1[slot])); }
     harvest_slot(h, slot);   // the pair of the product before last is read before it is recorded again
     h->prof_slot = slot ^ 1;
+    clock_mark("prof-events");
   }
   hipEvent_t pe0 = prof ? h->ev0[slot] : nullptr, pe1 = prof ? h->ev1[slot] : nullptr;
   // ---- the guarded exact int8 route of narrow products and of peeled columns (HBM-bound).
@@ -606,7 +660,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   // tile of 32 expanded columns; a class whose passes would cost more than the fp64 MFMA tile is not offered (gemm_i8_reserve returns 2).
   const bool no_plain = h->single && !trans;
   const PackedMatrix *G_tn_single = no_plain ? &gemm_operand(h, trans, true) : nullptr;
-  const bool small_ok = (engine == 0 || engine == 2 || engine == 5 || (engine == 4 && n <= 2)) && k >= 128;
+  const bool small_ok = (engine == 0 || (engine == 4 && n <= 2)) && k >= 128;
   // columns [c0, c0 + nc), nc <= 6.  0: enqueued (int8 chains + fp64 kernel: the columns are done whatever the verdict), 2: not applicable, 1: error
   // Verdict class 2 ("not exactly representable"; inf / NaN; a column near the underflow threshold): who does the product in fp64?
   //   nc = 1: fp64 chains, one thread per output row, inside the first chain's k_slice_B launch (no launch of their own: the CG step counts its launches; with 32 digits =
@@ -615,8 +669,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
   //           + k_finish: three empty launches (~5 us each) on a >= 1 ms product when the int8 classes apply, against 45-280 ms of chains when they do not
   //           (500k x 50k, n = 4 .. 6: measured late in round 5).  If its partial sums do not fit the budget (objects that fill the device): the chains.
   auto guarded_small = [&](int c0, int nc, const PackedMatrix *G_tn, hipEvent_t e0, hipEvent_t e1, int *splits_out, const int **flag_ptr) -> int {
-    static const int S0_of[7] = {0, 32, 16, 10, 16, 12, 10}, S1_of[7] = {0, 0, 0, 21, 24, 19, 16};
-    I8Chain ch; ch.S0 = S0_of[nc]; ch.S1 = S1_of[nc];
+    I8Chain ch; ch.S0 = kSmallS0[nc]; ch.S1 = kSmallS1[nc];
     const bool fb_lut = nc <= 2 && !no_plain;
     GemmPlan pf = fb_lut ? plan_lut(m, G.k_pad, nc) : plan_gemm(m, G.k_pad, nc);
     bool fast_fb = nc >= 2;
@@ -655,7 +708,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     if (flag_ptr) *flag_ptr = d_flag;
     return 0;
   };
-  if (small_ok && n <= kSmallNMaxColsHost && !(engine == 2 && n <= 4)) {   // (engine 2: the unguarded slicing for n <= 4 below)
+  if (small_ok && n <= kSmallNMaxColsHost) {
     const char *e_tn = getenv("MXA_I8_TN");   // A/B (read per call): n <= 2 from the copy whose rows are the K index
     const bool tn_ab = e_tn && atoi(e_tn) != 0;
     const PackedMatrix *G_tn = no_plain ? G_tn_single : (tn_ab && n <= 2 && !h->single) ? &gemm_operand(h, trans, true) : nullptr;   // (the A/B needs both stored copies)
@@ -664,28 +717,6 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     const int rcx = guarded_small(0, n, G_tn, pe0, pe1, &splits8, &d_flag);
     if (rcx == 1) return 1;
     if (rcx == 0) {   // (the range flag of the denormal-operand mode -- mxa_last_range_fallback -- is cleared by the chain's k_slice_B)
-      std::lock_guard<std::mutex> lk(g_prof_mutex);
-      Geometry &geo = last_geometry();
-      geo.m = m; geo.k = k; geo.n = n; geo.splits = splits8; geo.a = 0; geo.c = 0; geo.path = 4; geo.d_flag = d_flag; geo.flag_dev = h->device;
-      h->prof_pending[slot] = prof;
-      return 0;
-    }
-  }
-  // Engine 5 (i8-guarded, opt-in): the guarded route above for EVERY n, in balanced chunks of at most six columns -- each chunk carries its own device-side
-  // verdict (class 0 / 1: exact with the digits of two / three tiles; class 2: the fp64 chains in its k_slice_B launch), so the whole product is enqueued
-  // without a host read: the asynchronous counterpart of engine 4.  One pass over the packed matrix per chunk (2 x 32 digit columns at class 0).
-  if (engine == 5 && small_ok && n > kSmallNMaxColsHost) {
-    const int chunks = (n + kSmallNMaxColsHost - 1) / kSmallNMaxColsHost, per = (n + chunks - 1) / chunks;
-    int splits8 = 1, done = 0;
-    const int *d_flag = nullptr;
-    for (int c0 = 0; c0 < n; c0 += per) {
-      const int nc = std::min(per, n - c0);
-      const int rcx = guarded_small(c0, nc, G_tn_single, c0 == 0 ? pe0 : nullptr, c0 + nc >= n ? pe1 : nullptr, &splits8, &d_flag);
-      if (rcx == 2 && c0 == 0) break;          // the route does not apply to this object (nothing is enqueued): fp64 path below
-      if (rcx) { if (rcx == 2) set_error(4, "internal: a later column chunk of the guarded int8 engine declined"); return 1; }
-      done += nc;
-    }
-    if (done == n) {
       std::lock_guard<std::mutex> lk(g_prof_mutex);
       Geometry &geo = last_geometry();
       geo.m = m; geo.k = k; geo.n = n; geo.splits = splits8; geo.a = 0; geo.c = 0; geo.path = 4; geo.d_flag = d_flag; geo.flag_dev = h->device;
@@ -733,7 +764,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
       return 0;
     }
   }
-  if (engine == 1 || (engine == 2 && n <= 4)) {   // opt-in: the int8 slicing without the exactness check (7 digits; 32 / 16 for n = 1 / 2)
+  if (engine == 1) {   // opt-in: the int8 slicing without the exactness check (7 digits; 32 / 16 for n = 1 / 2)
     int splits8 = 1;
     const int rc8 = i8_engine_product(0, nullptr, pe0, pe1, &splits8);
     if (rc8 == 0) {
@@ -753,6 +784,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     const int rcp = guarded_small(n - n_odd, n_odd, G_tn_single, nullptr, nullptr, nullptr, nullptr);
     if (rcp == 1) return 1;
     if (rcp == 0) n -= n_odd;            // the rest of this function multiplies the first 4q columns
+    clock_mark("peel-enqueued");
   }
   const bool use_lut = n <= 2 && !no_plain;   // fp64 pair tables: engine f64-strict, and K < 128
   GemmPlan p = use_lut ? plan_lut(m, G.k_pad, n) : plan_gemm(m, G.k_pad, n);
@@ -768,6 +800,7 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
     }
   }
   if (splits_per_group == p.splits && ensure_partials(w, p, s)) return 1;   // the plan of the columns left after a peel may need more than the plan ensure_workspace sized for
+  clock_mark("partials");
   {
     std::lock_guard<std::mutex> lk(g_prof_mutex);
     Geometry &geo = last_geometry();
@@ -804,8 +837,9 @@ static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb,
       if (pass && launch_pack_B(dB, ldb, k, n, w.d_Bp, G.k_pad, p.n_pad, p.c, s, nullptr, 0, -1, gate)) return 1;
       for (int sb = 0; sb < p.splits; sb += splits_per_group) {
         const int se = std::min(p.splits, sb + splits_per_group);
-        // the kernel addresses P by the absolute split index: shift the base so that split sb lands at the start of the buffer
-        if (launch_gemm(GL, w.d_Bp, w.d_P - (size_t)sb * stride, p, pass ? 0 : mode, s, next_ctr(w), sb, se, gate, tr)) return 1;
+        // split sb lands at the start of the buffer (p_split0 = sb)
+        if ((size_t)(se - sb) * stride > w.cap_P) { set_error(4, "internal: a group of %d K splits exceeds the partial-sum workspace", se - sb); return 1; }
+        if (launch_gemm(GL, w.d_Bp, w.d_P, p, pass ? 0 : mode, s, next_ctr(w), sb, se, gate, tr, sb)) return 1;
         const int group = (sb > 0 ? 1 : 0) | (se < p.splits ? 2 : 0);
         if (launch_finish(w.d_P, p, m, n, dC, ldc, fill_rows, trans ? 1 : 0, centered, d_sumB, d_sumfB, h->d_f, s, pass ? nullptr : d_E, 0, 0, gate, nullptr, se - sb, group)) return 1;
       }
@@ -1004,13 +1038,22 @@ int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, double *C,
   if (!B || !C) { set_error(1, "dgemm_compressed: B and C must not be NULL"); return 1; }
   if (ldb < k || ldc < m) { set_error(7, "dgemm_compressed: leading dimension too small (ldb %ld < %ld or ldc %ld < %ld)", ldb, k, ldc, m); return 1; }
   hipStream_t s = h->stream;
+  // phase clock of the call (PRINT_LEVEL > 0 / print_details): one line per call, see CallClock
+  CallClock clk;
+  clk.start(sync && env_print_level() > 0);   // (the environment only: the reference harness passes print_details = 1, and its timed loop should not print)
+  struct ClockScope {
+    CallClock *prev; CallClock &c; bool trans; int n;
+    ClockScope(CallClock &c_, bool t, int n_) : prev(tl_call_clock), c(c_), trans(t), n(n_) { tl_call_clock = &c; }
+    ~ClockScope() { char head[64]; snprintf(head, sizeof(head), "dgemm_compressed '%c' n=%d", trans ? 'T' : 'N', n); c.report(head); tl_call_clock = prev; }
+  } clock_scope(clk, trans, n);
   int b_devno = -1, c_devno = -1;
   const bool b_local = ptr_location(B, &b_devno) == 1 && b_devno == h->device;
   const bool c_local = ptr_location(C, &c_devno) == 1 && c_devno == h->device;
+  clk.mark("locate");
   if (b_devno >= 0 && !b_local && sync_foreign_producer(b_devno)) return 1;   // B may still be being produced on the other device's default stream
   if (sync && (!b_local || !c_local)) {   // an operand in host memory or on another GPU, synchronous call: transfers hidden behind the product when they are large
     const int rcp = gemm_host_pipelined(h, trans, n, B, ldb, !b_local, b_local, C, ldc, !c_local, c_local, fill_rows);
-    if (rcp != 2) return rcp;
+    if (rcp != 2) { clk.mark("pipelined"); return rcp; }
   }
   const double *dB = B; long dldb = ldb;
   double *dC = C; long dldc = ldc;
@@ -1018,29 +1061,44 @@ int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, double *C,
   if (!b_local || !c_local) {
     harvest_copies(h);
     for (hipEvent_t *e : {&h->ev_in[0], &h->ev_in[1], &h->ev_out[0], &h->ev_out[1]}) if (!*e) MXA_HIP(hipEventCreate(e));
+    clk.mark("copy-events");
   }
   if (!b_local) {   // host memory, or memory of another device (peer copy over xGMI): dense k x n copy into this device's staging buffer
     if (grow(&w.d_Bstage, &w.cap_Bstage, (size_t)k * n)) return 1;
+    clk.mark("grow-Bstage");
     MXA_HIP(hipEventRecord(h->ev_in[0], s));
     if (ldb == k) MXA_HIP(hipMemcpyAsync(w.d_Bstage, B, sizeof(double) * (size_t)k * n, hipMemcpyDefault, s));
     else MXA_HIP(copy_columns(w.d_Bstage, sizeof(double) * k, B, sizeof(double) * ldb, sizeof(double) * k, n, s));
     MXA_HIP(hipEventRecord(h->ev_in[1], s));
     h->in_pending = true;
     dB = w.d_Bstage; dldb = k;
+    clk.mark("upload-B");
   }
   if (!c_local) {
     if (grow(&w.d_Cstage, &w.cap_Cstage, (size_t)fill_rows * n)) return 1;
     dC = w.d_Cstage; dldc = fill_rows;
+    clk.mark("grow-Cstage");
   }
   if (gemm_device(h, trans, n, dB, dldb, dC, dldc, fill_rows, s, timing)) return 1;
+  clk.mark("enqueued");
   if (!c_local) {
     MXA_HIP(hipEventRecord(h->ev_out[0], s));
     if (ldc == fill_rows) MXA_HIP(hipMemcpyAsync(C, dC, sizeof(double) * (size_t)fill_rows * n, hipMemcpyDefault, s));
     else MXA_HIP(copy_columns(C, sizeof(double) * ldc, dC, sizeof(double) * fill_rows, sizeof(double) * fill_rows, n, s));
     MXA_HIP(hipEventRecord(h->ev_out[1], s));
     h->out_pending = true;
+    clk.mark("download-C");
   }
-  if (sync) { MXA_HIP(hipStreamSynchronize(s)); harvest_profile(h); }
+  if (sync) {
+    MXA_HIP(hipStreamSynchronize(s));
+    clk.mark("stream-wait");
+    harvest_profile(h);
+    if (clk.on) {   // device-side durations of the same call, from the events that are there anyway
+      char tmp[96];
+      snprintf(tmp, sizeof(tmp), " | device: kernel %.3f in %.3f out %.3f", h->prof.launches ? h->prof_last_kernel_ms : 0.0, h->prof_last_in_ms, h->prof_last_out_ms);
+      if (clk.len < (int)sizeof(clk.line) - 100) clk.len += snprintf(clk.line + clk.len, sizeof(clk.line) - clk.len, "%s", tmp);
+    }
+  }
   return 0;
 }
 
@@ -1313,6 +1371,7 @@ void get_compressed_freq(void *compressed, double *f) {
   if (is_multi(compressed)) { if (f) multi_freq(compressed, f); return; }
   Handle *h = as_handle(compressed, "get_compressed_freq");
   if (!h || !f) return;
+  if (refuse_while_staging(h, "get_compressed_freq")) return;   // the host copy of the frequencies is filled when the object is sealed
   memcpy(f, h->h_f, sizeof(double) * (size_t)h->snps);
 }
 
@@ -1326,7 +1385,7 @@ int mxa_device_count(void) {
 }
 
 int mxa_set_engine(int engine) {
-  if (engine < 0 || engine > 5) return g_engine.load();
+  if (engine != 0 && engine != 1 && engine != 3 && engine != 4) return g_engine.load();
   return g_engine.exchange(engine);
 }
 int mxa_get_engine(void) { return g_engine.load(); }

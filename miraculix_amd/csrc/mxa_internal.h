@@ -4,6 +4,8 @@
 #include <cstddef>
 #include <cstdint>
 #include <functional>
+#include <utility>
+#include <vector>
 #include "mxa_plan.h"
 
 namespace mxa {
@@ -47,6 +49,7 @@ struct Workspace {
   double *d_Cstage = nullptr; size_t cap_Cstage = 0;   // result staged here when C is a host pointer
   double *d_Bp = nullptr;     size_t cap_Bp = 0;       // B in MFMA fragment order
   double *d_P = nullptr;      size_t cap_P = 0;        // split-K partial slabs
+  size_t big_budget = 0;                               // doubles of partial sums a product beyond 4 GiB may hold; decided once per object (partial_budget)
   double *d_colpart = nullptr; size_t cap_colpart = 0; // column-sum partials + sums
   double *d_tmp = nullptr;    size_t cap_tmp = 0;      // snps x n intermediate of mxa_gram_matvec
   int *d_exp = nullptr;       size_t cap_exp = 0;      // per-column exponents of B (denormal-operand mode)
@@ -80,6 +83,7 @@ struct Handle {
   // products are refused until _end
   bool staging = false;
   long staged_rows = 0;
+  std::vector<std::pair<long, long>> staged_iv;   // disjoint [begin, end) blocks appended so far, sorted
   double *d_f = nullptr;     // snps
   double *h_f = nullptr;
   bool has_f = false;
@@ -94,6 +98,7 @@ struct Handle {
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};   // around the staging copies of a non-local B / C
   bool in_pending = false, out_pending = false;
   ObjectProfile prof;                        // per object, next to the process-wide profile()
+  double prof_last_kernel_ms = 0.0, prof_last_in_ms = 0.0, prof_last_out_ms = 0.0;   // the most recent harvested durations (phase clock line)
   // host-operand pipeline (mxa_api.cpp: gemm_host_pipelined): two compute streams for alternating chunks, events per chunk
   hipStream_t pipe[2] = {nullptr, nullptr};
   hipEvent_t pev[18] = {};                   // [0] start, [1] operands ready, [2..9] upload of chunk c, [10..17] chunk c computed
@@ -173,6 +178,20 @@ void clear_error();   // every fallible API entry starts with it: mxa_last_error
 bool check_hip(hipError_t e, const char *func, int line);
 #define MXA_HIP(x) do { if (!::mxa::check_hip((x), __func__, __LINE__)) return 1; } while (0)
 void debug_info(const char *fmt, ...);
+// Wall-clock phases of ONE ABI call (host side), printed as one line under PRINT_LEVEL > 0 / print_details: where the time of a call through the plain
+// symbols goes -- operand classification, workspace growth, the staged upload of a pageable B (the host thread blocks in it), the enqueueing of the
+// kernels, the final stream wait.  Off: one branch per mark.  gemm_any arms tl_call_clock, gemm_device marks through it.
+struct CallClock {
+  bool on = false;
+  double t0 = 0.0, last = 0.0;
+  char line[512]; int len = 0;
+  static double now();
+  void start(bool enabled) { on = enabled; len = 0; line[0] = 0; if (on) t0 = last = now(); }
+  void mark(const char *what);
+  void report(const char *head);
+};
+extern thread_local CallClock *tl_call_clock;
+inline void clock_mark(const char *what) { if (tl_call_clock && tl_call_clock->on) tl_call_clock->mark(what); }
 
 // ---- kernel launchers (mxa_kernels.hip)
 // recode raw PLINK rows (src pitch arbitrary) into the padded z-coded device layout
@@ -208,8 +227,10 @@ int gemm_default_mode(int c);
 // d_ctr: 9 ints of device memory for the work queues of this launch (zeroed here, on s); must not be shared with a launch that may run at the same time
 // tr: transposed operand (k_gemm<..., TR>): the output rows are G's COLUMNS (p planned for m = G.k) and K runs over G's rows -- the 'N' product from the
 // SNP-major copy; modes 0 and 2 only
+// p_split0: the K split whose partial sums land at dP (grouped K splits keep one GROUP of splits in the buffer: p_split0 = the group's first split;
+// the host-operand pipeline addresses the whole buffer: 0)
 int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, int mode, hipStream_t s, int *d_ctr, int split_begin = 0, int split_end = -1,
-                const int *run_if_set = nullptr, bool tr = false);
+                const int *run_if_set = nullptr, bool tr = false, int p_split0 = 0);
 GemmPlan plan_lut(long m, long k_pad, int n);
 // run_if_set (nullable, device int): the kernel does nothing unless *run_if_set != 0 (fallback of the guarded small-n route)
 int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double *dP, const GemmPlan &p, hipStream_t s, const int *run_if_set = nullptr);

@@ -372,7 +372,7 @@ template <int A, int C, int MODE, bool DIAG = false, bool TR = false>
 __global__ void __launch_bounds__(256, 2)
 k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ Bp, int H, double *__restrict__ P,
        long m_pad, int n_pad, int rowblocks, int nchunks, int slabs_total, KSplit ks, int xcd_order,
-       unsigned long long *__restrict__ diag, int split0, const int *__restrict__ run_if_set, int nunits, int *__restrict__ ctr, int g8) {
+       unsigned long long *__restrict__ diag, int split0, const int *__restrict__ run_if_set, int nunits, int *__restrict__ ctr, int g8, int p_split0) {
   using Cfg = GemmCfg<A, C>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_next;
@@ -593,7 +593,7 @@ k_gemm(const uint8_t *__restrict__ G, size_t pitch, const double *__restrict__ B
     static_assert(GP >= 1, "epilogue scratch");
     double *scr = reinterpret_cast<double *>(smem + Cfg::kBufBytes) + wave * kPerWave;
     // P[split][row block][n_pad][rows of the block]: the workgroup's results form one contiguous chunk
-    double *Pbase = P + ((size_t)u.sp * rowblocks + u.rb) * ((size_t)n_pad * Cfg::kRowsWG);
+    double *Pbase = P + ((size_t)(u.sp - p_split0) * rowblocks + u.rb) * ((size_t)n_pad * Cfg::kRowsWG);   // p_split0: the K split whose partial sums start the buffer (grouped K splits)
 #pragma unroll
     for (int g0 = 0; g0 < A; g0 += GP) {
 #pragma unroll
@@ -653,7 +653,7 @@ GemmPlan plan_gemm(long m, long k_pad, int n, const GemmPlan *ksplits_like) { re
 
 template <int A, int C, int MODE, bool TR = false>
 static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, hipStream_t s, int split_begin, int split_end, const int *run_if_set,
-                         int *d_ctr) {
+                         int *d_ctr, int p_split0) {
   using Cfg = GemmCfg<A, C>;
   static unsigned long long attr_mask = 0;   // function attributes are per device
   if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm<A, C, MODE, false, TR>), Cfg::kLds, &attr_mask)) return 1;
@@ -686,7 +686,7 @@ static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, c
     MXA_HIP(hipMalloc(reinterpret_cast<void **>(&d_diag), sizeof(unsigned long long) * 5 * nunits));
     MXA_HIP(hipMemsetAsync(d_diag, 0, sizeof(unsigned long long) * 5 * nunits, s));
     hipLaunchKernelGGL((k_gemm<A, C, MODE, true>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBp, p.n_pad / 4, dP,
-                       p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, ks, xcd_order, d_diag, split_begin, (const int *)nullptr, (int)nunits, d_ctr, g8);
+                       p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, ks, xcd_order, d_diag, split_begin, (const int *)nullptr, (int)nunits, d_ctr, g8, p_split0);
     MXA_HIP(hipStreamSynchronize(s));
     std::vector<unsigned long long> h(5 * nunits);
     MXA_HIP(hipMemcpy(h.data(), d_diag, sizeof(unsigned long long) * 5 * nunits, hipMemcpyDeviceToHost));
@@ -735,14 +735,15 @@ static int launch_gemm_t(const PackedMatrix &G, const double *dBp, double *dP, c
     return 0;
   }
   hipLaunchKernelGGL((k_gemm<A, C, MODE, false, TR>), dim3((unsigned)grid), dim3(256), Cfg::kLds, s, G.d, G.pitch, dBp, p.n_pad / 4, dP,
-                     p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, ks, xcd_order, (unsigned long long *)nullptr, split_begin, run_if_set, (int)nunits, d_ctr, g8);
+                     p.m_pad, p.n_pad, p.rowblocks, p.nchunks, p.slabs_total, ks, xcd_order, (unsigned long long *)nullptr, split_begin, run_if_set, (int)nunits, d_ctr, g8, p_split0);
   MXA_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const GemmPlan &p, int mode, hipStream_t s, int *d_ctr, int split_begin, int split_end,
-                const int *run_if_set, bool tr) {
+                const int *run_if_set, bool tr, int p_split0) {
   if (split_end < 0) split_end = p.splits;
+  if (p_split0 < 0 || p_split0 > split_begin) { set_error(4, "internal: k_gemm partial-sum base split %d outside [0, %d]", p_split0, split_begin); return 1; }
   if (!G.d) { set_error(4, "internal: k_gemm was given a packed matrix that is not stored (single-orientation object)"); return 1; }
   if (tr) {   // transposed operand: output rows = columns of G (its k individuals), K = rows of G in slabs of 128
     if ((long)p.slabs_total * kSlabK > G.rows_pad || G.nslabs < 1 || (mode != 0 && mode != 3)) {
@@ -751,8 +752,8 @@ int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const Gemm
     }
 #define MXA_DISPATCH_TR(AA, CC)                                                                                          \
     if (p.a == AA && p.c == CC) {                                                                                        \
-      if (mode == 3) return launch_gemm_t<AA, CC, 3, true>(G, dBp, dP, p, s, split_begin, split_end, nullptr, d_ctr);     \
-      return launch_gemm_t<AA, CC, 0, true>(G, dBp, dP, p, s, split_begin, split_end, run_if_set, d_ctr);                 \
+      if (mode == 3) return launch_gemm_t<AA, CC, 3, true>(G, dBp, dP, p, s, split_begin, split_end, nullptr, d_ctr, p_split0);     \
+      return launch_gemm_t<AA, CC, 0, true>(G, dBp, dP, p, s, split_begin, split_end, run_if_set, d_ctr, p_split0);                 \
     }
     MXA_DISPATCH_TR(16, 1) MXA_DISPATCH_TR(16, 2) MXA_DISPATCH_TR(16, 3) MXA_DISPATCH_TR(16, 4)
     MXA_DISPATCH_TR(8, 5) MXA_DISPATCH_TR(8, 6) MXA_DISPATCH_TR(8, 7) MXA_DISPATCH_TR(8, 8)
@@ -768,8 +769,8 @@ int launch_gemm(const PackedMatrix &G, const double *dBp, double *dP, const Gemm
   }
 #define MXA_DISPATCH(AA, CC)                                              \
   if (p.a == AA && p.c == CC) {                                           \
-    if (mode == 3) return launch_gemm_t<AA, CC, 3>(G, dBp, dP, p, s, split_begin, split_end, nullptr, d_ctr);     \
-    return launch_gemm_t<AA, CC, 0>(G, dBp, dP, p, s, split_begin, split_end, run_if_set, d_ctr);                 \
+    if (mode == 3) return launch_gemm_t<AA, CC, 3>(G, dBp, dP, p, s, split_begin, split_end, nullptr, d_ctr, p_split0);     \
+    return launch_gemm_t<AA, CC, 0>(G, dBp, dP, p, s, split_begin, split_end, run_if_set, d_ctr, p_split0);                 \
   }
   MXA_DISPATCH(16, 1)
   MXA_DISPATCH(16, 2)

@@ -20,15 +20,14 @@ def set_options(use_gpu=True, cores=0, not_center=False, variant=0, verbose=1):
         raise RuntimeError("setOptions_compressed failed: " + _lib.last_error()[1])
 
 
-_ENGINES = {"f64": 0, "i8": 1, "small-n-i8": 2, "f64-strict": 3, "i8-exact": 4, "i8-guarded": 5}
+_ENGINES = {"f64": 0, "i8": 1, "f64-strict": 3, "i8-exact": 4}
 
 
 def set_engine(name):
     """Additive (no reference counterpart): 'f64' = default (fp64 matrix cores; for n <= 6 and for odd columns the exact int8 slicing when a
-    per-call check proves it exact, else fp64 pair tables / fp64 matrix cores), 'i8' = int8 slicing of B for every n, 'small-n-i8' = 'i8' for n <= 4,
-    'f64-strict' = fp64 arithmetic for every n, 'i8-exact' = the int8 slicing for every n with the digit count chosen per call so that B is
-    represented without error (else the fp64 path; the host reads three integers per call), 'i8-guarded' = the default engine's guarded exact route for EVERY n, in
-    chunks of at most six columns with the verdict formed on the device per chunk (no host read) (include/miraculix_amd.h, mxa_set_engine).  Returns the previous engine's name."""
+    device-side check proves it exact, else fp64), 'i8' = int8 slicing of B for every n (7 digits, no exactness check), 'f64-strict' = fp64 arithmetic
+    for every n, 'i8-exact' = the int8 slicing for every n with the digit count chosen per call so that B is represented without error (else the fp64
+    path; the host reads three integers per call).  Table: include/miraculix_amd.h, mxa_set_engine.  Returns the previous engine's name."""
     L = _lib.check_library_handle()
     if name not in _ENGINES:
         raise ValueError("engine must be one of " + ", ".join(_ENGINES))

@@ -179,26 +179,13 @@ def test_i8_engine_negative_entries_far_below_the_column_maximum(dg):
 
 
 def test_engine_switch_values(dg):
-    """mxa_set_engine: 0 / 1 / 2 accepted, anything else leaves the engine unchanged; 'small-n-i8' takes the int8 path only for
-    n <= 4 (the n = 5 result must be bit-identical to the fp64 engine's)."""
+    """mxa_set_engine: 0 / 1 / 3 / 4 accepted; anything else -- the retired ids 2 (small-n-i8) and 5 (i8-guarded) included -- leaves the engine unchanged"""
     import miraculix_amd as m
     L = m.lib.check_library_handle()
     assert L.mxa_get_engine() == 1
-    assert L.mxa_set_engine(7) == 1 and L.mxa_get_engine() == 1
-    prob = make_problem(2000, 300, 5, seed=2)
-    dg.set_options(use_gpu=True, not_center=True, verbose=0)
-    obj = dg.init_compressed(prob["plink"], prob["plink_t"], 2000, 300, prob["f"], 5)
-    try:
-        B5 = np.asfortranarray(make_B(2000, 5, seed=1).T)
-        B1 = np.asfortranarray(B5[:, :1])
-        assert dg.set_engine("f64") == "i8"
-        C5_f64 = dg.dgemm_compressed_main(False, obj, B5, 2000, 300)
-        C1_f64 = dg.dgemm_compressed_main(False, obj, B1, 2000, 300)
-        assert dg.set_engine("small-n-i8") == "f64"
-        C5 = dg.dgemm_compressed_main(False, obj, B5, 2000, 300)
-        C1 = dg.dgemm_compressed_main(False, obj, B1, 2000, 300)
-        assert np.array_equal(C5, C5_f64)
-        assert np.abs(C1 - C1_f64).max() <= 1e-13 * np.abs(C1_f64).max()
-        assert dg.set_engine("i8") == "small-n-i8"
-    finally:
-        dg.free_compressed(obj)
+    for bad in (7, -1, 2, 5):
+        assert L.mxa_set_engine(bad) == 1 and L.mxa_get_engine() == 1
+    assert dg.set_engine("f64") == "i8" and dg.set_engine("f64-strict") == "f64" and dg.set_engine("i8-exact") == "f64-strict"
+    assert dg.set_engine("i8") == "i8-exact"
+    with pytest.raises(ValueError):
+        dg.set_engine("i8-guarded")

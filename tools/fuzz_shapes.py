@@ -19,7 +19,7 @@ for c in range(cases):
     snps = int(rng.choice([rng.integers(1, 130), rng.integers(130, 700), rng.integers(700, 6000)]))
     indiv = int(rng.choice([rng.integers(1, 40), rng.integers(40, 600), rng.integers(600, 3000)]))
     n = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 15, 16, 31, 32, 33, 40]))
-    eng = str(rng.choice(["f64", "f64", "i8-exact", "f64-strict", "i8-guarded"]))
+    eng = str(rng.choice(["f64", "f64", "i8-exact", "f64-strict"]))
     centered = int(rng.integers(0, 2))
     prob = make_problem(snps, indiv, n, seed=int(rng.integers(1 << 30)), missing_frac=float(rng.choice([0.0, 0.02])))
     dg.set_engine(eng)

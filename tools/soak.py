@@ -23,7 +23,7 @@ obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"],
 for it in range(iters):
     n = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 13, 15, 17, 32, 33, 34, 64, 130]))
     trans = bool(rng.integers(0, 2))
-    eng = str(rng.choice(["f64", "f64", "f64", "i8", "small-n-i8", "f64-strict", "i8-exact", "i8-exact", "i8-guarded", "i8-guarded"]))
+    eng = str(rng.choice(["f64", "f64", "f64", "i8", "f64-strict", "i8-exact", "i8-exact"]))
     dg.set_engine(eng)
     centered = bool(rng.integers(0, 2))
     dg.set_options(use_gpu=True, not_center=not centered, verbose=0)
