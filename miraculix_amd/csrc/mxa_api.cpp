@@ -1368,6 +1368,7 @@ void sparse_times_plink(char *transsparse, char *transcompressed, char *plink, c
 }
 
 void get_compressed_freq(void *compressed, double *f) {
+  clear_error();
   if (is_multi(compressed)) { if (f) multi_freq(compressed, f); return; }
   Handle *h = as_handle(compressed, "get_compressed_freq");
   if (!h || !f) return;

@@ -16,6 +16,7 @@
 // ("virtual shards": several SNP blocks on one GPU) -- that is how the path is tested on a one-GPU box.
 #include "../../include/miraculix_amd.h"
 #include "mxa_internal.h"
+#include "mxa_rccl.h"
 
 #include <dlfcn.h>
 
@@ -97,39 +98,6 @@ class WorkerPool {
 };
 WorkerPool &worker_pool() { static WorkerPool *p = new WorkerPool(); return *p; }   // never destroyed: no thread joins at process exit
 
-// ---- RCCL, bound at run time (the library does not link it; the default reduction does not need it)
-struct Rccl {
-  void *lib = nullptr;
-  int (*CommInitAll)(void **, int, const int *) = nullptr;
-  int (*CommDestroy)(void *) = nullptr;
-  int (*Reduce)(const void *, void *, size_t, int, int, int, void *, hipStream_t) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
-  const char *(*GetErrorString)(int) = nullptr;
-  bool ok = false;
-};
-constexpr int kNcclFloat64 = 8, kNcclSum = 0;   // rccl.h: ncclDataType_t::ncclFloat64, ncclRedOp_t::ncclSum
-
-Rccl &rccl() {
-  static Rccl r = [] {
-    Rccl q;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      q.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (q.lib) break;
-    }
-    if (!q.lib) return q;
-    q.CommInitAll = reinterpret_cast<decltype(q.CommInitAll)>(dlsym(q.lib, "ncclCommInitAll"));
-    q.CommDestroy = reinterpret_cast<decltype(q.CommDestroy)>(dlsym(q.lib, "ncclCommDestroy"));
-    q.Reduce = reinterpret_cast<decltype(q.Reduce)>(dlsym(q.lib, "ncclReduce"));
-    q.GroupStart = reinterpret_cast<decltype(q.GroupStart)>(dlsym(q.lib, "ncclGroupStart"));
-    q.GroupEnd = reinterpret_cast<decltype(q.GroupEnd)>(dlsym(q.lib, "ncclGroupEnd"));
-    q.GetErrorString = reinterpret_cast<decltype(q.GetErrorString)>(dlsym(q.lib, "ncclGetErrorString"));
-    q.ok = q.CommInitAll && q.CommDestroy && q.Reduce && q.GroupStart && q.GroupEnd;
-    return q;
-  }();
-  return r;
-}
-
 // the calling thread's current device is put back when a multi-device entry returns (the entries switch devices while they work;
 // a caller such as PyTorch keeps its own notion of the current device)
 struct DeviceRestore {
@@ -177,7 +145,7 @@ struct Multi {
   int reductions = 0; double reduce_ms = 0.0;
   bool use_rccl = false, rccl_checked = false;
   double rccl_diff = -1.0;
-  std::vector<void *> comm;                  // ncclComm_t per shard (created on first use of the RCCL reduction)
+  std::vector<ncclComm_t> comm;              // per shard (created on first use of the RCCL reduction)
   bool distinct_devices = false;
   int ndevices = 0;
 };
@@ -222,8 +190,8 @@ int init_rccl(Multi *m) {
   std::vector<int> devs(G);
   for (int g = 0; g < G; g++) devs[g] = m->sh[g].h->device;
   m->comm.assign(G, nullptr);
-  const int rc = rccl().CommInitAll(m->comm.data(), G, devs.data());
-  if (rc != 0) { set_error(17, "ncclCommInitAll failed: %s", rccl().GetErrorString ? rccl().GetErrorString(rc) : "?"); m->comm.clear(); return 1; }
+  const ncclResult_t rc = rccl().CommInitAll(m->comm.data(), G, devs.data());
+  if (rc != ncclSuccess) { set_error(17, "ncclCommInitAll failed: %s", rccl().GetErrorString ? rccl().GetErrorString(rc) : "?"); m->comm.clear(); return 1; }
   return 0;
 }
 
@@ -307,7 +275,7 @@ void multi_destroy(void *obj) {
   // everything in flight ends first (asynchronous products, pushes, the reduction)
   for (Shard &S : m->sh) if (S.h) { (void)hipSetDevice(S.h->device); (void)hipStreamSynchronize(S.h->stream); if (S.cs) (void)hipStreamSynchronize(S.cs); }
   if (m->root_stream) { (void)hipSetDevice(m->root); (void)hipStreamSynchronize(m->root_stream); }
-  for (void *c : m->comm) if (c) (void)rccl().CommDestroy(c);
+  for (ncclComm_t c : m->comm) if (c) (void)rccl().CommDestroy(c);
   // every shard is released by the thread that worked on it
   for (Shard &S : m->sh) {
     if (!S.h || !S.worker) continue;
@@ -515,17 +483,17 @@ static int reduce_rccl(Multi *m, long rows, int n, double *dC, long ldc, long fi
   if (he == hipSuccess) he = hipSetDevice(S0.h->device);
   if (he == hipSuccess) he = hipEventRecord(S0.ev_push0, S0.cs);
   MXA_HIP(he);
-  int rc = r.GroupStart();
-  if (!rc) {
-    for (int g = 0; g < G && !rc && he == hipSuccess; g++) {
+  ncclResult_t rc = r.GroupStart();
+  if (rc == ncclSuccess) {
+    for (int g = 0; g < G && rc == ncclSuccess && he == hipSuccess; g++) {
       he = hipSetDevice(m->sh[g].h->device);
       // the receive buffer is read on the root rank only; the other ranks pass a valid pointer all the same (their own partial)
-      if (he == hipSuccess) rc = r.Reduce(m->sh[g].d_part, g == 0 ? S0.d_land : m->sh[g].d_part, (size_t)rows * n, kNcclFloat64, kNcclSum, 0, m->comm[g], m->sh[g].cs);
+      if (he == hipSuccess) rc = r.Reduce(m->sh[g].d_part, g == 0 ? S0.d_land : m->sh[g].d_part, (size_t)rows * n, ncclFloat64, ncclSum, 0, m->comm[g], m->sh[g].cs);
     }
-    const int rc_end = r.GroupEnd();   // always
-    if (!rc) rc = rc_end;
+    const ncclResult_t rc_end = r.GroupEnd();   // always
+    if (rc == ncclSuccess) rc = rc_end;
   }
-  if (rc) { set_error(17, "ncclReduce failed: %s", r.GetErrorString ? r.GetErrorString(rc) : "?"); return 1; }
+  if (rc != ncclSuccess) { set_error(17, "ncclReduce failed: %s", r.GetErrorString ? r.GetErrorString(rc) : "?"); return 1; }
   MXA_HIP(he);
   // every rank's ncclReduce reads its own partial on its own copy stream: the shard's next 'N' product waits for THAT (the root's completion
   // alone does not order the other ranks' kernels)

@@ -70,6 +70,23 @@ def make_B(k, n, seed=43, ldb=None):
     return B
 
 
+def elementwise_bound(o, trans, prob, B, centered, factor=4.0):
+    """The hard element-wise error bound of SURVEY.md 8(d) for an fp64 chain of length K: factor * K * 2^-53 * sum_k |z_ik| |b_kj|, per output (n x m, like
+    Oracle.dgemm_dense).  Centred: the product computes sum z b and the rank-1 term 2 sum f b separately, so the magnitudes add: 'N' + 2 sum_k f_k |b_kj| (per
+    column), 'T' + 2 f_s sum_i |b_ij|.  The norm-wise tolerance (1e-11 of the largest entry) leaves output rows far below max|C| unprotected; this one does not."""
+    snps, indiv = prob["snps"], prob["indiv"]
+    k, m = (indiv, snps) if trans else (snps, indiv)
+    Ba = np.ascontiguousarray(np.abs(B))
+    mag = o.dgemm_dense(trans, prob, Ba, 0)[:, :m]                                   # sum |z| |b|  (z >= 0)
+    if centered:
+        f = np.asarray(prob["f"], dtype=np.float64)
+        if trans:
+            mag = mag + 2.0 * Ba[:, :k].sum(axis=1)[:, None] * f[None, :m]
+        else:
+            mag = mag + 2.0 * (Ba[:, :k] * f[None, :k]).sum(axis=1)[:, None]
+    return factor * k * 2.0 ** -53 * mag
+
+
 class Oracle:
     def __init__(self):
         if not os.path.exists(ORACLE_SO):

@@ -211,3 +211,27 @@ def test_reference_fortran_programs_bind_only_symbols_this_library_exports(built
         bound |= undef & api
         assert (undef & api) <= exported
     assert {"setOptions_compressed", "plink2compressed", "dgemm_compressed", "free_compressed", "sparse2gpu", "dcsrtrsv_solve_gpu", "free_sparse_gpu"} <= bound
+
+
+def test_rccl_bindings_are_typed_by_the_image_header_and_checked_at_compile_time(tmp_path):
+    """mxa_multi.cpp binds RCCL with dlopen / dlsym (no link dependency).  Its pointers are typed by <rccl/rccl.h> (csrc/mxa_rccl.h: decltype(&ncclReduce), ...) and
+    static_asserts pin the enumerators that cross the boundary (ncclFloat64 = 8, ncclSum = 0): the header of THIS image compiles, a differing expectation does not --
+    i.e. a ROCm whose rccl.h changes a prototype or an enumerator stops the build instead of corrupting a reduction."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc) or not os.path.exists("/opt/rocm/include/rccl/rccl.h"):
+        pytest.skip("hipcc / rccl.h not in this image")
+    src = tmp_path / "rccl_check.cpp"
+    src.write_text('#include "mxa_rccl.h"\nint main() { return mxa::rccl().ok ? 0 : 1; }\n')
+    base = [hipcc, "-x", "hip", "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(ROOT, "miraculix_amd", "csrc"), str(src)]
+    ok = subprocess.run(base, capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0 and "error" not in ok.stderr, ok.stderr[-2000:]
+    for wrong in ("-DMXA_RCCL_EXPECT_FLOAT64=7", "-DMXA_RCCL_EXPECT_SUM=1"):
+        bad = subprocess.run(base + [wrong], capture_output=True, text=True, timeout=300)
+        assert "enumerator values differ" in bad.stderr, bad.stderr[-2000:]
+    # and the product library does not link RCCL (bound at run time only)
+    so = os.path.join(ROOT, "miraculix_amd", "lib", "libmiraculix_amd.so")
+    needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+    assert "librccl" not in needed and "libamdhip64" in needed
+    multi = open(os.path.join(ROOT, "miraculix_amd", "csrc", "mxa_multi.cpp")).read()
+    assert "ncclFloat64, ncclSum" in multi and "kNcclFloat64" not in multi          # the call site uses the header's enumerators, no magic numbers

@@ -24,6 +24,7 @@ def test_config4_full_5M_x_200k_x_128_one_product_one_copy():
     assert bench.leg_checks_ok(leg), leg
     ck = leg["check"]
     assert ck["N_16_sampled_rows_vs_dense_oracle_max_rel_err"] <= RTOL and ck["T_16_sampled_rows_vs_dense_oracle_max_rel_err"] <= RTOL
+    assert ck["N_max_err_over_elementwise_bound"] <= 1.0 and ck["T_max_err_over_elementwise_bound"] <= 1.0     # per element: 4 K 2^-53 (sum |z||b| + centring magnitude)
     assert ck["centred_adjoint_identity_max_rel_err"] <= RTOL and ck["N_bitwise_repeatable"]
     assert leg["staging"]["single_orientation"] == 1
     # the stated size ran (a device with less free memory runs the largest SNP count that fits and says so: then this fails loudly, with the budget)

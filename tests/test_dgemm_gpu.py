@@ -4,7 +4,7 @@ dense (G - 2f) B oracle, max-abs comparison) with a much tighter, stated toleran
 import numpy as np
 import pytest
 
-from _util import Oracle, make_B, make_problem
+from _util import Oracle, elementwise_bound, make_B, make_problem, pack_plink
 
 pytestmark = pytest.mark.gpu
 
@@ -47,6 +47,8 @@ def test_dgemm_vs_oracle(mx, snps, indiv, n, trans, centered):
     assert C.shape == (m, n)
     err = np.abs(C.T - ref).max() / np.abs(ref).max()
     assert err <= RTOL, err
+    # ... and the hard bound per ELEMENT: |C_ij - ref_ij| <= 4 K 2^-53 sum_k |z_ik| |b_kj| (centred: + the rank-1 term's magnitude)
+    assert np.all(np.abs(C.T - ref) <= elementwise_bound(o, trans, prob, B, centered))
 
 
 @pytest.mark.parametrize("snps,indiv,n", [(1000, 500, 1), (2047, 771, 3), (5000, 1203, 4), (1003, 501, 5), (2600, 900, 6), (777, 1301, 10)])
@@ -71,6 +73,7 @@ def test_dgemm_vs_oracle_fp64_arithmetic_only(mx, snps, indiv, n, trans, centere
         dg.set_engine(prev)
     err = np.abs(C.T - ref).max() / np.abs(ref).max()
     assert err <= RTOL, err
+    assert np.all(np.abs(C.T - ref) <= elementwise_bound(o, trans, prob, B, centered))
 
 
 def test_missing_codes_are_zero_then_centred(mx):
@@ -97,6 +100,7 @@ def test_dgemm_vs_reference_golden(mx, fixture, idx):
     snps, indiv, n, ldb_pad, ldc_pad = [int(x) for x in g[f"{name}/dims"]]
     L = mx.check_library_handle()
     dg = mx.dgemm_compressed
+    o = Oracle()
     plink, plink_t, f = (np.ascontiguousarray(g[f"{name}/{k}"]) for k in ("plink", "plink_t", "f"))
     for centered in (0, 1):
         dg.set_options(use_gpu=True, not_center=not centered, verbose=0)
@@ -111,7 +115,53 @@ def test_dgemm_vs_reference_golden(mx, fixture, idx):
             assert L.mxa_last_error() == 0
             assert np.abs(C - ref).max() <= RTOL * np.abs(ref).max(), (name, trans, centered)
             assert np.all(C[:, m:] == 0.0)
+            # element-wise: against the long-double oracle on the fixture's inputs with the bound of ONE chain (4 K u sum|z||b|), and against the reference
+            # library's own outputs with room for both chains' roundings (5 K u sum|z||b|)
+            prob = dict(snps=snps, indiv=indiv, plink=plink, plink_t=plink_t, f=f)
+            Bd = np.ascontiguousarray(B[:, :k])
+            dense = o.dgemm_dense(trans, prob, Bd, centered)[:, :m]
+            bound = elementwise_bound(o, trans, prob, Bd, centered)
+            assert np.all(np.abs(C[:, :m] - dense) <= bound), (name, trans, centered)
+            assert np.all(np.abs(C[:, :m] - ref[:, :m]) <= 1.25 * bound), (name, trans, centered)
         fq = np.zeros(snps)
         L.get_compressed_freq(obj, fq.ctypes.data_as(ctypes.c_void_p))
         assert np.array_equal(fq, f)
         dg.free_compressed(obj)
+
+
+@pytest.mark.parametrize("trans", [0, 1])
+@pytest.mark.parametrize("centered", [0, 1])
+@pytest.mark.parametrize("n", [8, 32])
+def test_fp64_mfma_path_keeps_small_rows_of_a_700_binade_column(mx, trans, centered, n):
+    """Adversarial input for the denormal-operand form of k_gemm (columns of B scaled to just below 2^900, genotype operand z * 2^-1074; range guard at 800
+    binades): every column of B holds a few entries near 2^+350 and all the others near 2^-350 -- a span of 700 binades, inside the guard -- and the genotypes
+    are arranged so that some output rows never meet a large entry: their whole result is carried by the small entries, 700 binades below max|C|.  The
+    norm-wise tolerance cannot see those rows (anything is within 1e-11 of max|C|); the element-wise bound must hold for them, uncentred EXACTLY relative to
+    their own magnitude.  Path asserted: k_gemm without the range fallback."""
+    o = Oracle()
+    dg = mx.dgemm_compressed
+    L = mx.check_library_handle()
+    snps, indiv = 3000, 1100
+    rng = np.random.default_rng(17 + n)
+    prob = make_problem(snps, indiv, n, seed=91)
+    Z = prob["Z"].copy()                                            # indiv x snps
+    k, m = (indiv, snps) if trans else (snps, indiv)
+    hot = np.sort(rng.choice(k, 12, replace=False))                 # K positions that carry the large entries
+    quiet = np.sort(rng.choice(m, 40, replace=False))               # output rows that never meet them: genotype 0 at every hot position
+    if trans:
+        Z[np.ix_(hot, quiet)] = 0                                   # 'T': output rows = SNPs, K = individuals
+    else:
+        Z[np.ix_(quiet, hot)] = 0                                   # 'N': output rows = individuals, K = SNPs
+    prob = dict(prob, Z=Z, plink=np.ascontiguousarray(pack_plink(Z.T.copy())), plink_t=np.ascontiguousarray(pack_plink(Z)), f=Z.astype(np.float64).mean(axis=0) / 2.0)
+    B = make_B(k, n, seed=5) * 2.0 ** -350
+    B[:, hot] *= 2.0 ** 700
+    ref = o.dgemm_dense(trans, prob, B, centered)[:, :m]
+    C = _run(mx, prob, trans, B, centered)
+    assert dg.last_path() == "k_gemm"
+    bound = elementwise_bound(o, trans, prob, B, centered)
+    assert np.all(np.isfinite(C)) and np.all(np.abs(C.T - ref) <= bound)
+    if not centered:                                                # the quiet rows live 700 binades below the others and are still right to their own scale
+        q = np.abs(ref[:, quiet])
+        assert q.max() < 2.0 ** -300 and np.abs(ref).max() > 2.0 ** 340
+        assert np.all(np.abs(C.T[:, quiet] - ref[:, quiet]) <= 4.0 * k * 2.0 ** -53 * q.max())
+        assert np.all(np.abs(C.T[:, quiet] - ref[:, quiet]) <= bound[:, quiet])

@@ -7,7 +7,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from _util import Oracle
+from _util import Oracle, elementwise_bound
 
 pytestmark = pytest.mark.gpu
 
@@ -79,18 +79,54 @@ def test_sampled_rows_vs_dense_oracle(big):
     rows = big["plink_t"][torch.from_numpy(ii).to(big["dev"])].cpu().numpy()                 # 64 x ceil(snps/4)
     sub_plink = o.transpose_2bit(np.ascontiguousarray(rows), 64, SNPS)                        # snps x 16 bytes
     prob = dict(snps=SNPS, indiv=64, plink=sub_plink, plink_t=rows, f=np.zeros(SNPS))
-    ref = o.dgemm_dense(0, prob, np.ascontiguousarray(Y.t().cpu().numpy()), 0)               # 4 x 64
+    Yh = np.ascontiguousarray(Y.t().cpu().numpy())
+    ref = o.dgemm_dense(0, prob, Yh, 0)                                                       # 4 x 64
     got = ZY[torch.from_numpy(ii).to(big["dev"])].t().cpu().numpy()
     assert np.abs(got - ref).max() <= 1e-11 * np.abs(ref).max()
+    assert np.all(np.abs(got - ref) <= elementwise_bound(o, 0, prob, Yh, 0))                  # per element: 4 K 2^-53 sum |z||b|
     # 'T': rows = SNPs
     ss = np.sort(rng.choice(SNPS, 64, replace=False))
     X = torch.randn((4, INDIV), dtype=torch.float64, device=big["dev"], generator=g).t()
     ZtX = dg.dgemm_compressed_main(True, big["obj"], X, SNPS, INDIV)
     srows = big["plink"][torch.from_numpy(ss).to(big["dev"])].cpu().numpy()                   # 64 x ceil(indiv/4)
     prob = dict(snps=64, indiv=INDIV, plink=np.ascontiguousarray(srows), plink_t=None, f=np.zeros(64))
-    ref = o.dgemm_dense(1, prob, np.ascontiguousarray(X.t().cpu().numpy()), 0)
+    Xh = np.ascontiguousarray(X.t().cpu().numpy())
+    ref = o.dgemm_dense(1, prob, Xh, 0)
     got = ZtX[torch.from_numpy(ss).to(big["dev"])].t().cpu().numpy()
     assert np.abs(got - ref).max() <= 1e-11 * np.abs(ref).max()
+    assert np.all(np.abs(got - ref) <= elementwise_bound(o, 1, prob, Xh, 0))
+
+
+def test_sampled_rows_fp64_mfma_path_elementwise(big):
+    """the headline products themselves (n = 32: k_gemm on the fp64 MFMA, both forms) -- 48 sampled rows, four of the 32 columns, against the long-double oracle
+    under the hard ELEMENT-WISE bound |C_ij - ref_ij| <= 4 K 2^-53 sum_k |z_ik| |b_kj|"""
+    torch, dg = big["torch"], big["dg"]
+    o = Oracle()
+    g = torch.Generator(device=big["dev"]); g.manual_seed(21)
+    rng = np.random.default_rng(4)
+    cols = [0, 13, 30, 31]
+    ii = np.sort(rng.choice(INDIV, 48, replace=False))
+    Y = torch.randn((N, SNPS), dtype=torch.float64, device=big["dev"], generator=g).t()
+    ZY = dg.dgemm_compressed_main(False, big["obj"], Y, SNPS, INDIV)
+    assert dg.last_path() == "k_gemm"
+    rows = big["plink_t"][torch.from_numpy(ii).to(big["dev"])].cpu().numpy()
+    sub_plink = o.transpose_2bit(np.ascontiguousarray(rows), 48, SNPS)
+    prob = dict(snps=SNPS, indiv=48, plink=sub_plink, plink_t=rows, f=np.zeros(SNPS))
+    Yh = np.ascontiguousarray(Y[:, cols].t().cpu().numpy())
+    ref = o.dgemm_dense(0, prob, Yh, 0)
+    got = ZY[torch.from_numpy(ii).to(big["dev"])][:, cols].t().cpu().numpy()
+    assert np.all(np.abs(got - ref) <= elementwise_bound(o, 0, prob, Yh, 0))
+    del Y, ZY
+    ss = np.sort(rng.choice(SNPS, 48, replace=False))
+    X = torch.randn((N, INDIV), dtype=torch.float64, device=big["dev"], generator=g).t()
+    ZtX = dg.dgemm_compressed_main(True, big["obj"], X, SNPS, INDIV)
+    assert dg.last_path() == "k_gemm"
+    srows = big["plink"][torch.from_numpy(ss).to(big["dev"])].cpu().numpy()
+    prob = dict(snps=48, indiv=INDIV, plink=np.ascontiguousarray(srows), plink_t=None, f=np.zeros(48))
+    Xh = np.ascontiguousarray(X[:, cols].t().cpu().numpy())
+    ref = o.dgemm_dense(1, prob, Xh, 0)
+    got = ZtX[torch.from_numpy(ss).to(big["dev"])][:, cols].t().cpu().numpy()
+    assert np.all(np.abs(got - ref) <= elementwise_bound(o, 1, prob, Xh, 0))
 
 
 def test_exact_int8_engine_at_full_size(big):

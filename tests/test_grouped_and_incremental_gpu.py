@@ -160,6 +160,23 @@ def test_incremental_staging_equals_one_pointer_object(mx, tmp_path):
         with pytest.raises(RuntimeError, match="100 SNP rows were appended"):
             dg.init_compressed_end(part, snps)
         dg.free_compressed(part)
+        # coverage is tracked by interval, not by count: a block appended twice or overlapping another one is refused with error 1, so a
+        # retried block cannot stand in for rows that were never written; and the frequencies of an unsealed object are not handed out
+        part = dg.init_compressed_begin(snps, indiv, n)
+        dg.append_rows(part, np.ascontiguousarray(prob["plink"][:100]), 0)
+        for b0, nr in ((0, 100), (50, 100), (99, 1), (0, snps)):
+            with pytest.raises(RuntimeError, match="overlap"):
+                dg.append_rows(part, np.ascontiguousarray(prob["plink"][b0:b0 + nr]), b0)
+        assert mx.lib.last_error()[0] == 1
+        dg.append_rows(part, np.ascontiguousarray(prob["plink"][200:snps]), 200)          # rows [100, 200) are still missing: snps - 100 rows appended
+        with pytest.raises(RuntimeError, match=r"first row not yet appended: 100"):
+            dg.init_compressed_end(part, snps)
+        fz = np.full(snps, -1.0)
+        L.get_compressed_freq(part, mx.lib.ptr(fz))
+        assert mx.lib.last_error()[0] == 19 and np.all(fz == -1.0)
+        dg.append_rows(part, np.ascontiguousarray(prob["plink"][100:200]), 100)
+        assert np.array_equal(dg.init_compressed_end(part, snps), f_dev)
+        dg.free_compressed(part)
         # the .bed reader streams into a single-orientation object: same results, same frequencies
         bed = tmp_path / "x.bed"
         with open(bed, "wb") as fh:
