@@ -955,9 +955,7 @@ def oracle_check(W, args):
     out = {"tol": 1e-11, "rows_N": int(len(sm["ii"])), "cols": cols}
     if not dist.is_initialized() or dist.get_world_size() == 1:
         err_n, br_n = check_sample(torch, sm, 0, W.B_N, W.C_N, cols, cen, want_bound=True)
-        out["N_max_err_over_elementwise_bound"] = br_n
-        if br_n > 1.0:
-            raise SystemExit(f"bench.py: 'N' result violates the element-wise bound 4 K 2^-53 sum|z||b| by x{br_n:.3g}: no number reported")
+        out["N_max_err_over_elementwise_bound"] = br_n          # <= 1: every sampled element within 4 K 2^-53 sum |z||b| of the oracle
         if W.inprocess:
             err_t, rows_t = 0.0, 0
             for g, (b1, e1) in enumerate(W.bounds):
@@ -1004,7 +1002,7 @@ def oracle_check(W, args):
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
         err_t, err_n = float(e[0].item()), float(e[1].item())
     out.update({"oracle_T_max_rel_err": err_t, "oracle_N_max_rel_err": err_n, "rows_T": rows_t})
-    if not (err_t <= 1e-11 and err_n <= 1e-11):
+    if not (err_t <= 1e-11 and err_n <= 1e-11 and out.get("N_max_err_over_elementwise_bound", 0.0) <= 1.0):
         raise SystemExit(f"bench.py: GPU results differ from the oracle ({out}): no number reported")
     return out
 

@@ -20,7 +20,8 @@ export TMPDIR=/tmp
 T=$1; shift
 case "$T" in
 tests)
-  timeout -k 10 1100 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 | tee "$O/gputests.txt" &&
+  timeout -k 10 1100 python -m pytest tests -x -q -m gpu "$@" > "$O/gputests_full.txt" 2>&1; rc=$?
+  tail -c 6000 "$O/gputests_full.txt"; tail -6 "$O/gputests_full.txt" > "$O/gputests.txt"; [ $rc = 0 ] &&
   timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee -a "$O/gputests.txt" ;;
 bench)
   timeout -k 10 1100 python bench.py "$@" > "$O/bench_n1.json" 2> "$O/bench_n1.stderr" ; rc=$?
