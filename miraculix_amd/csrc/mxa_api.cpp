@@ -1546,7 +1546,7 @@ int bed_range_to_handle(const char *base_c, long snps_total, long indiv, long sn
       }
       if (!rc) bad(hipStreamSynchronize(h->stream), __LINE__);
     }
-    if (!rc) { h->staged_rows = rows; rc = end_handle(h); }
+    if (!rc) { h->staged_rows = rows; h->staged_iv.assign(1, {0L, (long)rows}); rc = end_handle(h); }   // (the loop above wrote every row of the range exactly once)
     if (!rc && f_out_local) memcpy(f_out_local, h->h_f, sizeof(double) * rows);
     for (int i = 0; i < 2; i++) if (dchunk[i]) (void)hipFree(dchunk[i]);
     goto out;

@@ -120,7 +120,7 @@ __device__ __forceinline__ double ld_scale_map(double v, double is_i, double is_
 // so its lanes run along gi as well.  AccT = v16i: exact int32 sums; v16f: sums of z z' / 4 (FP4 engine), exact, times 4.
 typedef float v16f __attribute__((ext_vector_type(16)));
 // the result is written once and never read by this kernel: non-temporal stores keep the 8 n^2 bytes from displacing the packed operand tiles, which ~n/256
-// tiles re-read, in the L2s and the Infinity Cache (MXA_XPROD_NT_STORE=0 at compile time: plain stores, for the A/B of tools/gpu_r3_xstore_ab.sh)
+// tiles re-read, in the L2s and the Infinity Cache (MXA_XPROD_NT_STORE=0 at compile time: plain stores, for an A/B; round 3: docs/HISTORY.md)
 #ifndef MXA_XPROD_NT_STORE
 #define MXA_XPROD_NT_STORE 1
 #endif

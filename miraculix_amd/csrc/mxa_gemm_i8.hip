@@ -1024,7 +1024,7 @@ static I8Plan plan_i8(long m, long k_pad, int n, int S_override) {
       if (actual != cand) continue;
       // Whole rounds of the resident slots.  Exception (round 4): ONE split of a product with at least two full rounds of row tiles -- its thinly
       // filled last round costs max(its workgroups, 0.6 slots), not a whole round: 500k x 50k, n = 4 .. 6, 'T' (1954 tiles on 768 slots) runs 2-10 % faster
-      // uncut than in the three splits the whole-round rule chose (tools/gpu_r4_i8_splits_n46.sh).  Products with few row tiles ('N') keep the
+      // uncut than in the three splits the whole-round rule chose (round 4, docs/HISTORY.md).  Products with few row tiles ('N') keep the
       // whole-round rule: there the sweeps want MORE workgroups than the soft rule would ask for (config-5 shard 'N' 2 / 5 splits 1.04 / 0.96 ms).
       const long wgs = units * actual, rounds = (wgs + resident - 1) / resident, full = wgs / resident, last = wgs - full * resident;
       double quant = (double)(rounds * resident) / (double)wgs;

@@ -303,7 +303,7 @@ __device__ __forceinline__ void dma16_s(const void *sbase, uint32_t voff, uint32
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
 }
 // non-temporal variant for the packed genotype stream (read once per pass, far larger than every cache): see mxa_gemm_i8.hip, idma16_stream.
-// Measured on the config-5 shard (tools/gpu_r3_nt_ab.sh): k_gemm_i8 at n = 1 0.96-0.97 ms with the hint against 1.01-1.02 without; the lookup kernel
+// Measured on the config-5 shard (profiles/r03_nt_stream_ab.txt): k_gemm_i8 at n = 1 0.96-0.97 ms with the hint against 1.01-1.02 without; the lookup kernel
 // k_lut 1.66 against 1.63 (LDS-bound: no gain, MXA_NT_LUT stays 0).  k_gemm is MFMA-bound and its time does not move (C2: 43.89-43.99 ms with, 43.87-44.02
 // without), but its HBM traffic does: the packed stream no longer pushes the B-fragment slabs, which every row block re-reads, out of the L2s --
 // 15.0 GB per launch by the counters instead of 18.9 (12.8 algorithmic; FETCH_SIZE calibrated for the hinted stream too: factor 2.000,

@@ -1,4 +1,4 @@
-"""Solver twin: potrs_solve_gpu (blocked Cholesky: own diagonal-block kernel + rocBLAS trsm / syrk) and the sparse
+"""Solver twin: potrs_solve_gpu (blocked Cholesky: own diagonal-block kernel + own fp64 MFMA trsm / syrk building blocks, mxa_dense.hip; no vendor library is loaded) and the sparse
 triangular solves (own synchronisation-free kernel) through the C ABI, shaped like the reference's
 tests/solve/test.jl:67-140 (upper triangular, strictly diagonally dominant sparse matrix; dense exp(-|i-j|/n) matrix; B = randn + 5;
 X_sp = M^-1 (M^-T B); residual norms), with scipy / numpy as the CPU check and a far tighter tolerance than the reference's."""
