@@ -73,11 +73,20 @@ void get_compressed_freq(void *compressed, double *f);
  *   transcompressed in {T,t,Y,y}: C (nIdx x snps, ld Ldc) = S (nIdx x indiv) * Z, packed matrix = plink_transposed.
  * rowIdxB (nIdx + 1 entries) / colIdxB / B are ZERO-based CSR; C is zero-filled over Ldc x columns.  transsparse must be N
  * (the reference aborts otherwise; so does this).  Only the packed matrix that is used needs to be non-NULL.  Pointers may be
- * host or device.  Errors: message on stderr, C unwritten, mxa_last_error() != 0.
- * The neighbouring reference entry dgemm_plink (5codesAPI.c:112-130) is not provided: in the reference it ends in an
- * unconditional BUG abort for every input (plink256.cc:332), so there is no behaviour to be a drop-in for. */
+ * host or device.  Errors: message on stderr, C unwritten, mxa_last_error() != 0. */
 void sparse_times_plink(char *transsparse, char *transcompressed, char *plink, char *plink_transposed, int snps, int indiv,
                         int nIdx, int *rowIdxB, int *colIdxB, double *B, double *C, int Ldc);
+
+/* replaces src/miraculix/5codesAPI.c:112-130 (prototype 5codes.h:137-153 region; docs/genotype_matrix_multiplication.md) -> vectorGenoPlinkApi
+ * (5codesChar.cc:495-520).  One product straight from the PLINK matrices, no object kept: the DOCUMENTED semantics -- trans in {N,n}: C (indiv x n)
+ * = Zc B with B snps x n; {T,t,Y,y}: C (snps x n) = Zc^T B with B indiv x n; f != NULL: centred with the caller's frequencies, f == NULL: uncentred
+ * (whatever setOptions_compressed says) -- as the composition plink2compressed + dgemm_compressed + free_compressed of this library.
+ * PARITY UNPINNED: in the reference this entry ends in an unconditional BUG abort for every input (f != NULL: 5codesChar.cc:511-513; f == NULL:
+ * plink256.cc:332) and nothing binds it, so there is no reference output to compare with; results are checked against the dense oracle.  The reference's
+ * "indiv must be a multiple of 32" (5codesChar.cc:510) is not required.  Only the matrix the reference would read needs to be non-NULL ('N':
+ * plink_transposed, 'T': plink); when only plink_transposed is given it is transposed on the device first.  Host or device pointers.
+ * Errors: message on stderr, C unwritten, mxa_last_error() != 0. */
+void dgemm_plink(char *trans, char *plink, char *plink_transposed, int snps, int indiv, double *f, int n, double *B, int Ldb, double *C, int Ldc);
 
 /* replaces src/cuda/snp_multiply_cuda.cu:375-382 (prototype src/cuda/snp_multiply_cuda.h:113-114; Julia binding
  * src/bindings/Julia/crossproduct.jl:54-58, which passes the bool as Cint).

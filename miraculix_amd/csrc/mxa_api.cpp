@@ -333,6 +333,50 @@ static int reserve_small_routes(Handle *h, int n) {
 }
 
 thread_local int tl_single_override = -1;
+thread_local bool tl_no_warmup = false;   // one-shot objects (dgemm_plink) skip the warm-up products
+static thread_local bool tl_in_warmup = false;
+
+// First-call costs belong to plink2compressed, not to the first dgemm_compressed (round 6).  The phase clock of the reference's harness showed its FIRST product
+// through the plain ABI at 13.5-15.2 ms where the following ones take 4.0 (250k x 50k x 10): 7.2-9.3 ms inside the first device-to-host copy of C on the
+// object's stream (the runtime's staged pageable copy; independent of the size, not page faults), 0.8-1.5 ms in the first upload of B, 1.2-1.4 + 0.55 ms of
+// first launches of the kernels on the path (profiles/r06_harness_phase_clock.txt).  One 'N' and one 'T' product with max_n columns of zeros, operands where
+// the caller's matrices were (host scratch for a host caller: exactly the path its calls will take), pays all of that here -- bounded: the column count
+// is cut until a product is estimated below 12.5 ms, and objects whose single-column product is slower than that (HBM-bound at > 60 GB) are not warmed.
+// MXA_WARMUP=0 turns it off.  Nothing is timed or counted (timing = false).
+static int gemm_device(Handle *h, bool trans, int n, const double *dB, long ldb, double *dC, long ldc, long fill_rows, hipStream_t s, bool timing);
+static int warm_up(Handle *h, bool host_caller) {
+  const char *e = getenv("MXA_WARMUP");
+  if (tl_no_warmup || (e && atoi(e) == 0)) return 0;
+  if (options().centered && !h->has_f) return 0;
+  const double cells = (double)h->snps * (double)h->indiv;
+  auto est = [&](int nn) { return std::max(2.0 * cells * nn / 70e12, cells / 4.0 / 5e12); };
+  int n = h->max_n;
+  while (n > 1 && est(n) > 0.0125) n = n > 8 ? (n / 2 + 3) / 4 * 4 : n - 1;
+  if (est(n) > 0.0125) return 0;
+  const size_t cnt = (size_t)std::max(h->snps, h->indiv) * n;
+  int rc = 0;
+  tl_in_warmup = true;
+  if (host_caller) {
+    double *hb = (double *)calloc(cnt, sizeof(double)), *hc = (double *)malloc(cnt * sizeof(double));
+    if (hb && hc) {
+      rc = gemm_any(h, false, n, hb, h->snps, hc, h->indiv, h->indiv, true, false);
+      if (!rc) rc = gemm_any(h, true, n, hb, h->indiv, hc, h->snps, h->snps, true, false);
+    }
+    free(hb); free(hc);
+  } else {
+    Workspace &w = h->ws;
+    if (grow(&w.d_Bstage, &w.cap_Bstage, cnt) || grow(&w.d_Cstage, &w.cap_Cstage, cnt)) { tl_in_warmup = false; return 1; }
+    if (!check_hip(hipMemsetAsync(w.d_Bstage, 0, cnt * sizeof(double), h->stream), __func__, __LINE__)) { tl_in_warmup = false; return 1; }
+    rc = gemm_device(h, false, n, w.d_Bstage, h->snps, w.d_Cstage, h->indiv, h->indiv, h->stream, false);
+    if (!rc) rc = gemm_device(h, true, n, w.d_Bstage, h->indiv, w.d_Cstage, h->snps, h->snps, h->stream, false);
+    if (!rc && !check_hip(hipStreamSynchronize(h->stream), __func__, __LINE__)) rc = 1;
+  }
+  { std::lock_guard<std::mutex> lk(g_prof_mutex); last_geometry() = Geometry(); }   // mxa_last_path / mxa_last_geometry describe the CALLER'S products
+  harvest_profile(h);
+  h->prof = ObjectProfile();            // ... and so do the per-object counters
+  tl_in_warmup = false;
+  return rc;
+}
 
 int single_orientation_policy() {
   // Round 5: ONE packed copy (SNP-major) is the default -- both products read it at the rate two copies reach (fp64 MFMA: plain form = transposed form =
@@ -423,6 +467,7 @@ int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink
   if (!check_hip(hipMemcpyAsync(h->h_f, h->d_f, sizeof(double) * snps, hipMemcpyDeviceToHost, h->stream), __func__, __LINE__) ||
       !check_hip(hipStreamSynchronize(h->stream), __func__, __LINE__)) { destroy_handle(h); return 1; }
   if (ensure_workspace(h, h->max_n) || reserve_small_routes(h, h->max_n)) { destroy_handle(h); return 1; }
+  if (warm_up(h, src_dev0 < 0)) { destroy_handle(h); return 1; }
   *out = h;
   return 0;
 }
@@ -531,7 +576,8 @@ int end_handle(Handle *h) {
   MXA_HIP(hipMemcpyAsync(h->h_f, h->d_f, sizeof(double) * h->snps, hipMemcpyDeviceToHost, h->stream));   // (on the object's stream: see create_handle)
   MXA_HIP(hipStreamSynchronize(h->stream));
   h->staging = false;
-  return reserve_small_routes(h, h->max_n);
+  if (reserve_small_routes(h, h->max_n)) return 1;
+  return warm_up(h, false);
 }
 
 
@@ -1044,7 +1090,7 @@ int gemm_any(Handle *h, bool trans, int n, const double *B, long ldb, double *C,
   struct ClockScope {
     CallClock *prev; CallClock &c; bool trans; int n;
     ClockScope(CallClock &c_, bool t, int n_) : prev(tl_call_clock), c(c_), trans(t), n(n_) { tl_call_clock = &c; }
-    ~ClockScope() { char head[64]; snprintf(head, sizeof(head), "dgemm_compressed '%c' n=%d", trans ? 'T' : 'N', n); c.report(head); tl_call_clock = prev; }
+    ~ClockScope() { char head[96]; snprintf(head, sizeof(head), "dgemm_compressed '%c' n=%d%s", trans ? 'T' : 'N', n, tl_in_warmup ? " (warm-up inside plink2compressed)" : ""); c.report(head); tl_call_clock = prev; }
   } clock_scope(clk, trans, n);
   int b_devno = -1, c_devno = -1;
   const bool b_local = ptr_location(B, &b_devno) == 1 && b_devno == h->device;
@@ -1365,6 +1411,45 @@ void sparse_times_plink(char *transsparse, char *transcompressed, char *plink, c
   }
   (void)sparse_times_plink_impl(tc != 0, reinterpret_cast<const uint8_t *>(plink), reinterpret_cast<const uint8_t *>(plink_transposed), snps, indiv, nIdx,
                                 rowIdxB, colIdxB, B, C, Ldc);
+}
+
+// dgemm_plink (5codesAPI.c:112-130): the documented semantics as plink2compressed + dgemm_compressed + free_compressed; see the header (parity unpinned:
+// the reference aborts unconditionally there).
+void dgemm_plink(char *trans, char *plink, char *plink_transposed, int snps, int indiv, double *f, int n, double *B, int Ldb, double *C, int Ldc) {
+  clear_error();
+  const int t = trans_flag(trans);
+  if (snps <= 0 || indiv <= 0 || n < 0) { set_error(1, "dgemm_plink: snps and indiv must be positive"); return; }
+  if (n == 0) return;
+  if (!plink && !plink_transposed) { set_error(1, "dgemm_plink: plink and plink_transposed are both NULL"); return; }
+  if (select_device() < 0) return;
+  const size_t bps = ((size_t)indiv + 3) / 4, bpi = ((size_t)snps + 3) / 4;
+  DevBuf tmp;
+  const uint8_t *p_snp = reinterpret_cast<const uint8_t *>(plink);
+  if (!p_snp) {   // only the individual-major matrix was handed over ('N' in the reference's call shape): the SNP-major copy is made on the device
+    DevBuf src;
+    const uint8_t *pt = reinterpret_cast<const uint8_t *>(plink_transposed);
+    if (!is_device_ptr(pt)) {
+      if (src.alloc((size_t)indiv * bpi) || !check_hip(hipMemcpy(src.p, pt, (size_t)indiv * bpi, hipMemcpyHostToDevice), __func__, __LINE__)) return;
+      pt = static_cast<const uint8_t *>(src.p);
+    }
+    if (tmp.alloc((size_t)snps * bps) || launch_transpose_2bit(pt, indiv, snps, static_cast<uint8_t *>(tmp.p), nullptr) ||
+        !check_hip(hipDeviceSynchronize(), __func__, __LINE__)) return;
+    p_snp = static_cast<const uint8_t *>(tmp.p);
+  }
+  Options &o = options();
+  const Options saved = o;
+  o.gpu = true; o.centered = f != nullptr; o.set = true;
+  void *obj = nullptr;
+  tl_single_override = 1;                 // one product: the SNP-major copy serves it whichever way
+  tl_no_warmup = true;
+  const int rc = create_handle(p_snp, bps, nullptr, bpi, snps, indiv, f, n, &obj);
+  tl_single_override = -1; tl_no_warmup = false;
+  if (!rc && obj) {
+    Handle *h = reinterpret_cast<Handle *>(obj);
+    (void)gemm_any(h, t != 0, n, B, Ldb, C, Ldc, Ldc, true, true);
+    destroy_handle(h);
+  }
+  o = saved;
 }
 
 void get_compressed_freq(void *compressed, double *f) {

@@ -276,6 +276,31 @@ def dgemm_compressed_main(transpose, obj_ref, B, snps, indiv, out=None):
     return C
 
 
+def dgemm_plink(transpose, plink, plink_transposed, snps, indiv, f, B):
+    """The reference's dgemm_plink (src/miraculix/5codesAPI.c:112-130): one product straight from the PLINK matrices, no object kept.  transpose False ('N'):
+    C (indiv x n) = Zc B, B snps x n; True ('T'): C (snps x n) = Zc^T B, B indiv x n.  f None: uncentred, else centred with f.  Only the matrix the reference
+    would read has to be given ('N': plink_transposed, 'T': plink).  Parity unpinned: the reference aborts unconditionally there (include/miraculix_amd.h)."""
+    n_row, n_col = B.shape
+    if n_row != (indiv if transpose else snps):
+        raise ValueError(f"Matrix B is not compatible with genotype matrix of {snps} SNPs and {indiv} individuals")
+    Bc, ldb = _colmajor(B)
+    m = snps if transpose else indiv
+    if _lib.is_torch_tensor(B):
+        import torch
+        C = torch.zeros((n_col, m), dtype=torch.float64, device=B.device).t()
+    else:
+        C = np.zeros((m, n_col), dtype=np.float64, order="F")
+    _, ldc = _colmajor(C)
+    if f is not None and not _lib.is_torch_tensor(f):
+        f = np.ascontiguousarray(f, dtype=np.float64)
+    L = _lib.check_library_handle()
+    L.dgemm_plink(b"T" if transpose else b"N", _lib.ptr(plink), _lib.ptr(plink_transposed), int(snps), int(indiv), _lib.ptr(f), int(n_col), _lib.ptr(Bc), int(ldb),
+                  _lib.ptr(C), int(ldc))
+    if L.mxa_last_error():
+        raise RuntimeError("dgemm_plink failed: " + _lib.last_error()[1])
+    return C
+
+
 def sparse_times_plink(transcompressed, plink, plink_transposed, snps, indiv, row_idx, col_idx, values, ldc=None, out=None):
     """Mirror of the Fortran binding c_sparse_times_plink (src/bindings/Fortran/mod5codesapi.f90:84-100, caller
     tests/sparse_plink/test_sparse_plink.f90:99) with transsparse = 'N'.  (row_idx, col_idx, values): ZERO-based CSR of the sparse

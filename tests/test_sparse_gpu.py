@@ -4,7 +4,7 @@ import os
 import numpy as np
 import pytest
 
-from _util import Oracle, make_problem, random_csr
+from _util import Oracle, make_B, make_problem, random_csr
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sparse_golden.npz")
@@ -68,3 +68,35 @@ def test_sparse_device_operands_and_errors(dg):
     assert L.mxa_last_error() != 0
     dg.sparse_times_plink(False, prob["plink"], None, 1200, 640, ia, ja, a)      # the status describes the most recent call
     assert L.mxa_last_error() == 0
+
+
+@pytest.mark.parametrize("snps,indiv,n", [(1003, 501, 5), (2048, 640, 32), (777, 1301, 1)])
+@pytest.mark.parametrize("trans", [0, 1])
+@pytest.mark.parametrize("centered", [0, 1])
+def test_dgemm_plink_documented_semantics(snps, indiv, n, trans, centered):
+    """dgemm_plink (reference: src/miraculix/5codesAPI.c:112-130): one product straight from the PLINK matrices.  PARITY UNPINNED -- the reference aborts
+    unconditionally in this entry (f != NULL: 5codesChar.cc:511-513 BUG; f == NULL: plink256.cc:332 BUG), so the check is the documented semantics against the
+    dense oracle: 'N' = Zc B from plink_transposed alone, 'T' = Zc^T B from plink alone, f NULL = uncentred / given = centred, whatever the options say; no
+    object is left behind and the options singleton is restored."""
+    import miraculix_amd as mx
+    from _util import elementwise_bound
+    mx.load_shared_library()
+    dg = mx.dgemm_compressed
+    o = Oracle()
+    prob = make_problem(snps, indiv, n, seed=31 + n, missing_frac=0.03)
+    k, m = (indiv, snps) if trans else (snps, indiv)
+    B = make_B(k, n, seed=8)
+    dg.set_options(use_gpu=True, not_center=bool(centered), verbose=0)          # the OPPOSITE of what the call asks for: dgemm_plink decides by f alone
+    C = dg.dgemm_plink(bool(trans), prob["plink"] if trans else None, None if trans else prob["plink_t"], snps, indiv, prob["f"] if centered else None, np.asfortranarray(B.T))
+    ref = o.dgemm_dense(trans, prob, B, centered)[:, :m]
+    assert C.shape == (m, n)
+    assert np.abs(C.T - ref).max() <= 1e-11 * np.abs(ref).max()
+    assert np.all(np.abs(C.T - ref) <= elementwise_bound(o, trans, prob, B, centered))
+    # the options singleton is as the caller left it: a plain object multiplies with not_center = centered
+    obj = dg.init_compressed(prob["plink"], prob["plink_t"], snps, indiv, prob["f"], n)
+    try:
+        C2 = dg.dgemm_compressed_main(bool(trans), obj, np.asfortranarray(B.T), snps, indiv)
+        ref2 = o.dgemm_dense(trans, prob, B, 0 if centered else 1)[:, :m]
+        assert np.abs(C2.T - ref2).max() <= 1e-11 * np.abs(ref2).max()
+    finally:
+        dg.free_compressed(obj)
