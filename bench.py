@@ -230,7 +230,7 @@ def measure_traffic(args):
             d = os.path.join(tmp, ctr)
             cmd = [rocprof, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
                    "--snps", str(args.snps), "--indiv", str(args.indiv), "--ncol", str(args.ncol), "--centered", str(args.centered)]
-            r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True, timeout=600, env=dict(os.environ, TMPDIR=tmp))
+            r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True, timeout=600, env=dict(os.environ, TMPDIR=tmp, MXA_WARMUP="0"))   # (no warm-up products inside plink2compressed: the counters see the two launches of the workload only)
             src = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
             if r.returncode != 0 or not src:
                 return None, {"skipped": f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"}
