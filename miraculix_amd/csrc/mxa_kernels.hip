@@ -956,50 +956,68 @@ int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double 
 // 'N' (mode_trans=0): C[i,j] = sum_s P + (-2 * sum_k f_k B[k,j])            (x=f, y=1: dgemm_compressed_cuda.cu:426-459)
 // 'T' (mode_trans=1): C[s,j] = sum_s P + (-2 * sum_i B[i,j]) * f_s           (x=1, y=f)
 // rows m..fill_rows-1 of every column are zero-filled (plain ABI: fill_rows = ldc, like the reference CPU path, 5codesIntern.h:67).
-__global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, long m_pad, long p_rows, int n_pad, int splits, long m, int n,
+// Round 6: two consecutive rows per thread (16-byte loads of P; a 16-byte store where C's column is 16-byte aligned) and the tile index by shift where the
+// tile height is a power of two (k_gemm's row blocks: 128 / 256; a 64-bit division per element cost as much as the memory traffic: 220 us for the 512 MB
+// of a C2 product).  Same additions in the same order: bit-identical.
+__global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, long m_pad, long p_rows, int p_shift, int n_pad, int splits, long m, int n,
                                                 double *__restrict__ Cout, long ldc, long fill_rows, int mode_trans, int centered,
                                                 const double *__restrict__ sumB, const double *__restrict__ sumfB,
                                                 const double *__restrict__ f, const int *__restrict__ E, int back, int e_splits, int e_stride,
                                                 const int *__restrict__ run_if_set, const int *__restrict__ unscaled_if_set, int group) {
   const int j = blockIdx.y;
-  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long r0 = 2 * ((long)blockIdx.x * blockDim.x + threadIdx.x);
   if (run_if_set && *run_if_set == 0) return;
   if (unscaled_if_set && *unscaled_if_set != 0) E = nullptr;   // the MODE 0 fallback produced these partial sums: nothing to scale back
-  if (r >= fill_rows) return;
+  if (r0 >= fill_rows) return;
   // K-split GROUPS (products whose partial sums would not fit the device: gemm_grouped): `splits` partials of one group are added to the running
   // sum kept, unscaled and uncentred, in C itself -- bit 0: start from C instead of 0, bit 1: not the last group (store the raw sum).  The
   // additions run in the same ascending split order as one pass over all splits: bit-identical.
   const bool acc_in = group & 1, raw_out = group & 2;
-  double v = 0.0;
-  if (r < m && acc_in) v = Cout[r + (long)j * ldc];
-  if (r < m && raw_out) {
-    const size_t tile = (size_t)(r / p_rows), within = (size_t)(r % p_rows), ntiles = (size_t)(m_pad / p_rows);
-    for (int s = 0; s < splits; s++) v += __builtin_nontemporal_load(&P[(((size_t)s * ntiles + tile) * n_pad + j) * p_rows + within]);
-  } else
-  if (r < m) {
-    const size_t tile = (size_t)(r / p_rows), within = (size_t)(r % p_rows), ntiles = (size_t)(m_pad / p_rows);
-    if (E && e_splits > 0) {
-      // host-operand pipeline: B was scaled per K chunk (e_splits splits share one exponent row of E).  Every partial is scaled back
-      // BEFORE it is added, in the same ascending order: power-of-two scaling commutes with rounding, so the sum is bit-identical to the
-      // one-exponent path below
-      for (int s = 0; s < splits; s++) v += ldexp(__builtin_nontemporal_load(&P[(((size_t)s * ntiles + tile) * n_pad + j) * p_rows + within]), back + E[(size_t)(s / e_splits) * e_stride + j]);
-    } else {
-      for (int s = 0; s < splits; s++) v += __builtin_nontemporal_load(&P[(((size_t)s * ntiles + tile) * n_pad + j) * p_rows + within]);   // read once
-      if (E) v = ldexp(v, back + E[j]);          // undo the operand scaling of the denormal-operand mode (exact)
+  const bool two = r0 + 1 < fill_rows;
+  double *cp = Cout + r0 + (long)j * ldc;
+  double v0 = 0.0, v1 = 0.0;
+  if (acc_in) { if (r0 < m) v0 = cp[0]; if (two && r0 + 1 < m) v1 = cp[1]; }
+  if (r0 < m) {
+    // rows r0, r0 + 1 lie in one tile (r0 even, p_rows even: k_gemm's 128 / 256, the lookup kernel's m_pad -- a multiple of 512)
+    const size_t tile = p_shift >= 0 ? (size_t)(r0 >> p_shift) : (size_t)(r0 / p_rows), within = p_shift >= 0 ? (size_t)(r0 & (p_rows - 1)) : (size_t)(r0 % p_rows);
+    const size_t ntiles = p_shift >= 0 ? (size_t)(m_pad >> p_shift) : (size_t)(m_pad / p_rows);
+    const size_t sstride = ntiles * (size_t)n_pad * (size_t)p_rows;            // doubles between the splits
+    const double *pp = P + ((tile * n_pad + j) * (size_t)p_rows + within);
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const bool per_split_scale = !raw_out && E && e_splits > 0;
+    for (int s = 0; s < splits; s++) {
+      const v2d x = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(pp + (size_t)s * sstride));   // read once (the padding row of an odd m is there: m_pad is even)
+      if (per_split_scale) {
+        // host-operand pipeline: B was scaled per K chunk (e_splits splits share one exponent row of E).  Every partial is scaled back
+        // BEFORE it is added, in the same ascending order: power-of-two scaling commutes with rounding, so the sum is bit-identical to the
+        // one-exponent path below
+        const int ex = back + E[(size_t)(s / e_splits) * e_stride + j];
+        v0 += ldexp(x[0], ex); v1 += ldexp(x[1], ex);
+      } else { v0 += x[0]; v1 += x[1]; }
     }
-    if (centered) {
-      if (mode_trans) v = fma(-2.0 * sumB[j], f[r], v);
-      else v += -2.0 * sumfB[j];
+    if (!raw_out) {
+      if (E && !per_split_scale) { const int ex = back + E[j]; v0 = ldexp(v0, ex); v1 = ldexp(v1, ex); }   // undo the operand scaling of the denormal-operand mode (exact)
+      if (centered) {
+        if (mode_trans) { const double c = -2.0 * sumB[j]; v0 = fma(c, f[r0], v0); if (r0 + 1 < m) v1 = fma(c, f[r0 + 1], v1); }
+        else { const double c = -2.0 * sumfB[j]; v0 += c; v1 += c; }
+      }
     }
+    if (r0 + 1 >= m) v1 = 0.0;                                                  // row m (ld padding of the plain ABI) is zero
   }
-  Cout[r + (long)j * ldc] = v;
+  if (two && (reinterpret_cast<size_t>(cp) & 15) == 0) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<v2d *>(cp) = v2d{v0, v1};
+  } else { cp[0] = v0; if (two) cp[1] = v1; }
 }
 
 int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC, long ldc, long fill_rows, int mode_trans, bool centered,
                   const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s, const int *d_E, int e_splits, int e_stride, const int *run_if_set,
                   const int *unscaled_if_set, int group_splits, int group) {
-  dim3 grid((unsigned)((fill_rows + 255) / 256), n);
-  hipLaunchKernelGGL(k_finish, grid, dim3(256), 0, s, dP, p.m_pad, p.p_rows, p.n_pad, group_splits > 0 ? group_splits : p.splits, m, n, dC, ldc, fill_rows, mode_trans,
+  if ((p.p_rows & 1) || (p.m_pad & 1)) { set_error(4, "internal: k_finish wants even tile heights (p_rows %ld, m_pad %ld)", p.p_rows, p.m_pad); return 1; }
+  int p_shift = -1;
+  if ((p.p_rows & (p.p_rows - 1)) == 0) { p_shift = 0; while ((1L << p_shift) < p.p_rows) p_shift++; }
+  dim3 grid((unsigned)((fill_rows + 511) / 512), n);
+  hipLaunchKernelGGL(k_finish, grid, dim3(256), 0, s, dP, p.m_pad, p.p_rows, p_shift, p.n_pad, group_splits > 0 ? group_splits : p.splits, m, n, dC, ldc, fill_rows, mode_trans,
                      centered ? 1 : 0, d_sumB, d_sumfB, d_f, d_E, 1074 - kDenUp, e_splits, e_stride, run_if_set, unscaled_if_set, group);
   MXA_HIP(hipGetLastError());
   return 0;
