@@ -219,7 +219,7 @@ __device__ __forceinline__ void small_n_fp64_row(const SmallNFallback &a, const 
 // tn_map (k_gemm_i8_tn): K-step T covers 32 consecutive K indices, byte 4q+i of lane (h, col) = digit of B[32 T + 16 h + 4 i + q]
 __global__ void __launch_bounds__(256) k_slice_B(const double *__restrict__ B, long ldb, long k, int n, const int *__restrict__ E, int S, int nc, int NT,
                                                  long T_total, int ncols, uint32_t *__restrict__ Bs, long total, const int *__restrict__ skip_if_set,
-                                                 SliceFused fu, int tn_map, SmallNFallback fb) {
+                                                 SliceFused fu, int tn_map, SmallNFallback fb, int SG) {
   __shared__ int sE[kSmallNMaxCols], sflag, scls;
   __shared__ double sSum[2][kSmallNMaxCols];
   if (fu.part) {   // guarded small-n chain (n <= kSmallNMaxCols)
@@ -261,11 +261,15 @@ __global__ void __launch_bounds__(256) k_slice_B(const double *__restrict__ B, l
     }
     E = sE;
   } else if (skip_if_set && *skip_if_set) return;   // guarded route: B is not exactly representable, the fp64 fallback does this product
-  // one thread per (q, column cj = chunk*nc + jj, h, T): reads the 4 values k = 128(T/4) + 64h + 16(T%4) + 4i + q (i = 0..3), writes dword q of
-  // lane (h, col) for each slice.  q runs fastest, then the column: 16-byte lane records and 128-byte runs of doubles.
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int q = (int)(idx & 3);
-    const long rest = idx >> 2;
+  // one thread per (q, slice group sg, column cj = chunk*nc + jj, h, T): reads the 4 values k = 128(T/4) + 64h + 16(T%4) + 4i + q (i = 0..3), writes dword q of
+  // lane (h, col) for each slice of its group.  q runs fastest, then the group, then the column: 16-byte lane records and 128-byte runs of doubles.
+  // Slice groups (round 6): with many digits per column (n = 1: 32) a thread per (q, cj, h, T) walked all S slices -- 62 000 threads of ~1100 instructions each for the
+  // 250k-row operand of a CG step, 11-12 us; SG threads share the slices (each derives the digits of its four values itself: same integers, same bytes written).
+  const long total_sg = total * SG;
+  for (long idx0 = (long)blockIdx.x * blockDim.x + threadIdx.x; idx0 < total_sg; idx0 += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(idx0 & 3);
+    const int sg = (int)((idx0 >> 2) % SG);
+    const long rest = (idx0 >> 2) / SG;
     const int cj = (int)(rest % ncols);
     const long hT = rest / ncols;
     const int h = (int)(hT & 1);
@@ -277,7 +281,8 @@ __global__ void __launch_bounds__(256) k_slice_B(const double *__restrict__ B, l
       const long kk = tn_map ? 32 * T + 16 * h + 4 * i + q : 128 * (T >> 2) + 64 * h + 16 * (T & 3) + 4 * i + q;   // K order of the A operand: see k_gemm_i8 / k_gemm_i8_tn
       d[i] = (kk < k && cj < n) ? balanced_digits(B[kk + (long)cj * ldb], E[cj], S) : Digits9{0ull, 0u, 0};
     }
-    for (int s = 0; s < S; s++) {
+    const int per = (S + SG - 1) / SG, s_begin = sg * per, s_end = s_begin + per < S ? s_begin + per : S;
+    for (int s = s_begin; s < s_end; s++) {
       uint32_t w = 0;
 #pragma unroll
       for (int i = 0; i < 4; i++) w |= digit_of(d[i], S, s) << (8 * i);
@@ -1238,14 +1243,15 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
     const int ncols = p.nchunks * p.nc;
     const long total = (long)p.T_total * 2 * ncols * 4;
     SmallNFallback fb{};
-    long blocks = (total + 255) / 256;
+    const int SG = p.S >= 16 ? 4 : p.S >= 8 ? 2 : 1;   // threads sharing the slices of one (q, column, h, K-step)
+    long blocks = (total * SG + 255) / 256;
     if (fused && chain->first && chain->fp64_rows) {   // the fp64 rows of verdict class 2 ride in this launch: a thread per output row (n = 1; wider chains: gated fp64 launches of the caller)
       const PackedMatrix &GF = tn ? *G_tn : G;
       fb = SmallNFallback{GF.d, GF.nslabs, m, k, dC, ldc, fill_rows, tn ? 1 : 0, trans ? 1 : 0, centered ? 1 : 0, d_f};
       blocks = std::max(blocks, (fill_rows + 255) / 256);
     }
     hipLaunchKernelGGL(k_slice_B, dim3((unsigned)std::min<long>(blocks, 256L * 64)), dim3(256), 0, s, dB, ldb, k, n, d_E, p.S, p.nc, p.NT,
-                       p.T_total, ncols, reinterpret_cast<uint32_t *>(d_Bs), total, skip, fu, tn ? 1 : 0, fb);
+                       p.T_total, ncols, reinterpret_cast<uint32_t *>(d_Bs), total, skip, fu, tn ? 1 : 0, fb, SG);
   }
   MXA_HIP(hipGetLastError());
   if (ev0) MXA_HIP(hipEventRecord(ev0, s));
