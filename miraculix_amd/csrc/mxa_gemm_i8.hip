@@ -1243,7 +1243,9 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
     const int ncols = p.nchunks * p.nc;
     const long total = (long)p.T_total * 2 * ncols * 4;
     SmallNFallback fb{};
-    const int SG = p.S >= 16 ? 4 : p.S >= 8 ? 2 : 1;   // threads sharing the slices of one (q, column, h, K-step)
+    // threads sharing the slices of one (q, column, h, K-step).  Measured (profiles/r06_gram_step_kernel_timeline.txt): four threads per 32 slices take the 100k-row operand of a
+    // CG step from 11.5 to 10 us and the 250k-row one from 12 to 15 us (each group derives the digits of its four values again): one thread stays
+    const int SG = 1;
     long blocks = (total * SG + 255) / 256;
     if (fused && chain->first && chain->fp64_rows) {   // the fp64 rows of verdict class 2 ride in this launch: a thread per output row (n = 1; wider chains: gated fp64 launches of the caller)
       const PackedMatrix &GF = tn ? *G_tn : G;

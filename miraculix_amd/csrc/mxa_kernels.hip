@@ -958,7 +958,8 @@ int launch_lut(const PackedMatrix &G, const double *dB, long ldb, int n, double 
 // rows m..fill_rows-1 of every column are zero-filled (plain ABI: fill_rows = ldc, like the reference CPU path, 5codesIntern.h:67).
 // Round 6: two consecutive rows per thread (16-byte loads of P; a 16-byte store where C's column is 16-byte aligned) and the tile index by shift where the
 // tile height is a power of two (k_gemm's row blocks: 128 / 256; a 64-bit division per element cost as much as the memory traffic: 220 us for the 512 MB
-// of a C2 product).  Same additions in the same order: bit-identical.
+// of a C2 product: 184 us now).  Same additions in the same order: bit-identical.  (A block per partial-sum TILE walking the columns -- P read front to
+// back -- was measured too: 258 us; the scattered 1 KiB runs of C cost more than the strided reads of P.)
 __global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, long m_pad, long p_rows, int p_shift, int n_pad, int splits, long m, int n,
                                                 double *__restrict__ Cout, long ldc, long fill_rows, int mode_trans, int centered,
                                                 const double *__restrict__ sumB, const double *__restrict__ sumfB,
@@ -1010,68 +1011,12 @@ __global__ void __launch_bounds__(256) k_finish(const double *__restrict__ P, lo
   } else { cp[0] = v0; if (two) cp[1] = v1; }
 }
 
-// The same finish with the work laid out along P (round 6).  P is [split][tile][column][p_rows]: a block of k_finish above owns 512 rows of ONE column, so the
-// blocks in flight (x fastest) each pick a 1 KiB run out of every tile's 32 KiB and P is swept once per column -- 2.3-2.8 TB/s for the 512 MB of a C2 product.
-// Here a block owns ONE tile (p_rows = 128 / 256 rows, k_gemm's row block) and walks its columns: thread = (row pair, column lane), 256 / (p_rows / 2) column
-// lanes -- the block reads its tile's 32 KiB front to back (per split) and writes 1-2 KiB runs of C.  Per element the same additions in the same order.
-// Tiles beyond m (ld padding rows up to fill_rows) have no P: the tail rows are zero-filled by the blocks past the last tile.
-__global__ void __launch_bounds__(256) k_finish_tiled(const double *__restrict__ P, long m_pad, int p_shift, int n_pad, int splits, long m, int n,
-                                                      double *__restrict__ Cout, long ldc, long fill_rows, int mode_trans, int centered,
-                                                      const double *__restrict__ sumB, const double *__restrict__ sumfB,
-                                                      const double *__restrict__ f, const int *__restrict__ E, int back, int e_splits, int e_stride,
-                                                      const int *__restrict__ run_if_set, const int *__restrict__ unscaled_if_set, int group) {
-  if (run_if_set && *run_if_set == 0) return;
-  if (unscaled_if_set && *unscaled_if_set != 0) E = nullptr;
-  const long p_rows = 1L << p_shift;
-  const int pairs = (int)(p_rows >> 1), lanes_j = 256 / pairs;            // 64 row pairs x 4 column lanes, or 128 x 2
-  const int rp = (int)threadIdx.x % pairs, jl = (int)threadIdx.x / pairs;
-  const long tile = blockIdx.x;
-  const long r0 = tile * p_rows + 2 * rp;
-  if (r0 >= fill_rows) return;
-  const bool acc_in = group & 1, raw_out = group & 2;
-  const bool two = r0 + 1 < fill_rows;
-  const size_t ntiles = (size_t)(m_pad >> p_shift);
-  const size_t sstride = ntiles * (size_t)n_pad * (size_t)p_rows;
-  typedef double v2d __attribute__((ext_vector_type(2)));
-  const bool per_split_scale = !raw_out && E && e_splits > 0;
-  for (int j = jl; j < n; j += lanes_j) {
-    double *cp = Cout + r0 + (long)j * ldc;
-    double v0 = 0.0, v1 = 0.0;
-    if (acc_in) { if (r0 < m) v0 = cp[0]; if (two && r0 + 1 < m) v1 = cp[1]; }
-    if (r0 < m) {
-      const double *pp = P + (((size_t)tile * n_pad + j) * (size_t)p_rows + 2 * (size_t)rp);
-      for (int s = 0; s < splits; s++) {
-        const v2d x = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(pp + (size_t)s * sstride));
-        if (per_split_scale) { const int ex = back + E[(size_t)(s / e_splits) * e_stride + j]; v0 += ldexp(x[0], ex); v1 += ldexp(x[1], ex); }
-        else { v0 += x[0]; v1 += x[1]; }
-      }
-      if (!raw_out) {
-        if (E && !per_split_scale) { const int ex = back + E[j]; v0 = ldexp(v0, ex); v1 = ldexp(v1, ex); }
-        if (centered) {
-          if (mode_trans) { const double c = -2.0 * sumB[j]; v0 = fma(c, f[r0], v0); if (r0 + 1 < m) v1 = fma(c, f[r0 + 1], v1); }
-          else { const double c = -2.0 * sumfB[j]; v0 += c; v1 += c; }
-        }
-      }
-      if (r0 + 1 >= m) v1 = 0.0;
-    }
-    if (two && (reinterpret_cast<size_t>(cp) & 15) == 0) *reinterpret_cast<v2d *>(cp) = v2d{v0, v1};
-    else { cp[0] = v0; if (two) cp[1] = v1; }
-  }
-}
-
 int launch_finish(const double *dP, const GemmPlan &p, long m, int n, double *dC, long ldc, long fill_rows, int mode_trans, bool centered,
                   const double *d_sumB, const double *d_sumfB, const double *d_f, hipStream_t s, const int *d_E, int e_splits, int e_stride, const int *run_if_set,
                   const int *unscaled_if_set, int group_splits, int group) {
   if ((p.p_rows & 1) || (p.m_pad & 1)) { set_error(4, "internal: k_finish wants even tile heights (p_rows %ld, m_pad %ld)", p.p_rows, p.m_pad); return 1; }
   int p_shift = -1;
   if ((p.p_rows & (p.p_rows - 1)) == 0) { p_shift = 0; while ((1L << p_shift) < p.p_rows) p_shift++; }
-  if (p_shift >= 7 && p_shift <= 9 && n >= 4) {   // k_gemm's row blocks (128 / 256 rows): one block per tile, walking the columns
-    const long tiles = (fill_rows + p.p_rows - 1) >> p_shift;
-    hipLaunchKernelGGL(k_finish_tiled, dim3((unsigned)tiles), dim3(256), 0, s, dP, p.m_pad, p_shift, p.n_pad, group_splits > 0 ? group_splits : p.splits, m, n, dC, ldc, fill_rows,
-                       mode_trans, centered ? 1 : 0, d_sumB, d_sumfB, d_f, d_E, 1074 - kDenUp, e_splits, e_stride, run_if_set, unscaled_if_set, group);
-    MXA_HIP(hipGetLastError());
-    return 0;
-  }
   dim3 grid((unsigned)((fill_rows + 511) / 512), n);
   hipLaunchKernelGGL(k_finish, grid, dim3(256), 0, s, dP, p.m_pad, p.p_rows, p_shift, p.n_pad, group_splits > 0 ? group_splits : p.splits, m, n, dC, ldc, fill_rows, mode_trans,
                      centered ? 1 : 0, d_sumB, d_sumfB, d_f, d_E, 1074 - kDenUp, e_splits, e_stride, run_if_set, unscaled_if_set, group);
