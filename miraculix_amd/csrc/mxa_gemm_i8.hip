@@ -641,7 +641,12 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
     const size_t rb = (size_t)(st0 + stage);
 #pragma unroll
     for (int i = 0; i < Cfg::kPackedPerWave; i++) {
-      const int u = wave + i * Cfg::kWaves;                  // slab j = u >> 3, K-step u & 7
+      // Round 6: a wave fetches exactly the units it consumes -- K-steps 2 wave, 2 wave + 1 of both slabs -- so no other wave ever touches its part of the ring and the
+      // stage loop needs NO workgroup barrier: the wave's own vmcnt orders its DMA against its LDS reads.  (Until round 5 the units were dealt wave + 4 i and every
+      // stage ended in __syncthreads: the counters showed the kernel waiting for ISSUE, not for memory -- SQ_WAIT_INST_ANY 0.48, SQ_WAIT_ANY 0.20 against 0.10 / 0.68 of the
+      // plain kernel -- i.e. four waves in lockstep with the slowest one's loads, two workgroups per CU.)
+      static_assert(kTnSlabs == 2 && Cfg::kWaves == 4 && Cfg::kPackedPerWave == 4, "wave-local DMA units: 2 slabs x 2 K-steps per wave");
+      const int u = (i >> 1) * 8 + 2 * wave + (i & 1);       // slab j = u >> 3, K-step u & 7
       long sl = (long)strip * kTnSlabs + (u >> 3);
       if (sl >= nslabs_all) sl = nslabs_all - 1;             // individuals beyond the matrix: rows of P nobody reads
       idma16_stream(reinterpret_cast<const char *>(G) + (rb * (size_t)nslabs_all + (size_t)sl) * kTileBytes + (u & 7) * 1024, v_pack, base + (u >> 3) * kTnSlabStride + (u & 7) * 1024);
@@ -697,7 +702,7 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
         for (int kk = 0; kk < 2; kk++)
 #pragma unroll
           for (int tt = 0; tt < TT; tt++) asm volatile("" : "+v"(dig[u][kk][tt]));
-        __syncthreads();                                     // ... for every wave; and everybody is done with stage s - 1, whose buffer is refilled now
+        // (no barrier: the wave is done with its own part of stage s - 1, whose buffer it refills now)
         if (s + D < stages) { issue_packed(s + D, (s + D) % BUFS); issue_digits(s + D, dig[(u + D) % NSET]); }
         const char *bufp = smem + (s % BUFS) * Cfg::kBufBytes;
 #pragma unroll
