@@ -579,6 +579,9 @@ k_gemm_i8(const uint8_t *__restrict__ G, size_t pitch, const int8_t *__restrict_
 // (bank = dword of the column group (8) + 8 * khalf + 16 * slab).
 // Partial sums go to P[split][e][individual] like the operand-swapped plain instantiations: k_finish_i8_t finishes them (exact int64 over the splits).
 constexpr int kTnSlabStride = kTileBytes + 64;                // LDS bytes between the slab regions of a stage
+#ifndef MXA_TN_WAVE_LOCAL
+#define MXA_TN_WAVE_LOCAL 1                                   // 0: A/B build of the round-5 form (workgroup barrier per stage)
+#endif
 // Workgroup = a strip of 256 individuals (2 slabs) x a range of row blocks, 4 waves.  Only 16 column groups exist, so the byte-pair split sits in the lanes:
 // lane (cg = lane & 15, fh = (lane >> 4) & 1, khalf = lane >> 5) -- the two lanes of a column group read the same dword (an LDS broadcast) and gather
 // different byte pairs (the v_perm selector is per lane); MFMA group j multiplies the individuals 16 cg + 8 fh + j.  Wave w: K-steps {2 w, 2 w + 1}.
@@ -611,6 +614,7 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
   // the sums go to rows e_off .. e_off + 31 of P[split][e_pad][m_pad].  A product with several tiles (3 <= n <= 6, the opt-in engines) is one launch per tile.
   using Cfg = TnCfg<BUFS, TT>;
   constexpr int D = Cfg::kDepth, NSET = D + 1;
+  constexpr bool kWaveLocal = MXA_TN_WAVE_LOCAL && TT == 1;   // every wave fetches the DMA units it consumes: no workgroup barrier per stage (issue_packed)
   if (skip_if_set && *skip_if_set) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -641,12 +645,13 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
     const size_t rb = (size_t)(st0 + stage);
 #pragma unroll
     for (int i = 0; i < Cfg::kPackedPerWave; i++) {
-      // Round 6: a wave fetches exactly the units it consumes -- K-steps 2 wave, 2 wave + 1 of both slabs -- so no other wave ever touches its part of the ring and the
-      // stage loop needs NO workgroup barrier: the wave's own vmcnt orders its DMA against its LDS reads.  (Until round 5 the units were dealt wave + 4 i and every
-      // stage ended in __syncthreads: the counters showed the kernel waiting for ISSUE, not for memory -- SQ_WAIT_INST_ANY 0.48, SQ_WAIT_ANY 0.20 against 0.10 / 0.68 of the
-      // plain kernel -- i.e. four waves in lockstep with the slowest one's loads, two workgroups per CU.)
+      // Round 6, one-tile instantiation (TT = 1; two workgroups per CU): a wave fetches exactly the units it consumes -- K-steps 2 wave, 2 wave + 1 of both slabs -- so no
+      // other wave ever touches its part of the ring and the stage loop needs NO workgroup barrier: the wave's own vmcnt orders its DMA against its LDS reads.
+      // Measured on one box, alternating with the round-5 form (units dealt wave + 4 i, __syncthreads per stage; profiles/r06_tn_wave_local_ab.txt): n = 1 0.986 / 1.003 ms
+      // against 0.991 / 1.015, n = 2 and 3 equal within the noise -- a small gain; the TWO-tile instantiation (one workgroup per CU) LOSES 6-13 % without the barrier
+      // (n = 4: 1.60 against 1.41 ms: four waves drifting apart turn the stage's 16 KiB burst into 4 KiB requests) and keeps the lockstep form.
       static_assert(kTnSlabs == 2 && Cfg::kWaves == 4 && Cfg::kPackedPerWave == 4, "wave-local DMA units: 2 slabs x 2 K-steps per wave");
-      const int u = (i >> 1) * 8 + 2 * wave + (i & 1);       // slab j = u >> 3, K-step u & 7
+      const int u = kWaveLocal ? (i >> 1) * 8 + 2 * wave + (i & 1) : wave + i * Cfg::kWaves;       // slab j = u >> 3, K-step u & 7
       long sl = (long)strip * kTnSlabs + (u >> 3);
       if (sl >= nslabs_all) sl = nslabs_all - 1;             // individuals beyond the matrix: rows of P nobody reads
       idma16_stream(reinterpret_cast<const char *>(G) + (rb * (size_t)nslabs_all + (size_t)sl) * kTileBytes + (u & 7) * 1024, v_pack, base + (u >> 3) * kTnSlabStride + (u & 7) * 1024);
@@ -702,7 +707,8 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
         for (int kk = 0; kk < 2; kk++)
 #pragma unroll
           for (int tt = 0; tt < TT; tt++) asm volatile("" : "+v"(dig[u][kk][tt]));
-        // (no barrier: the wave is done with its own part of stage s - 1, whose buffer it refills now)
+        // wave-local units: no barrier -- the wave is done with its own part of stage s - 1, whose buffer it refills now; otherwise: for every wave
+        if (!kWaveLocal) __syncthreads();
         if (s + D < stages) { issue_packed(s + D, (s + D) % BUFS); issue_digits(s + D, dig[(u + D) % NSET]); }
         const char *bufp = smem + (s % BUFS) * Cfg::kBufBytes;
 #pragma unroll
