@@ -582,6 +582,7 @@ constexpr int kTnSlabStride = kTileBytes + 64;                // LDS bytes betwe
 #ifndef MXA_TN_WAVE_LOCAL
 #define MXA_TN_WAVE_LOCAL 1                                   // 0: A/B build of the round-5 form (workgroup barrier per stage)
 #endif
+
 // Workgroup = a strip of 256 individuals (2 slabs) x a range of row blocks, 4 waves.  Only 16 column groups exist, so the byte-pair split sits in the lanes:
 // lane (cg = lane & 15, fh = (lane >> 4) & 1, khalf = lane >> 5) -- the two lanes of a column group read the same dword (an LDS broadcast) and gather
 // different byte pairs (the v_perm selector is per lane); MFMA group j multiplies the individuals 16 cg + 8 fh + j.  Wave w: K-steps {2 w, 2 w + 1}.
@@ -1097,7 +1098,8 @@ static int launch_i8_t(const PackedMatrix &G, const int8_t *dBs, int *dP, const 
 // handle and only grows.
 // K splits of the transposed-operand kernel: workgroups = strips x splits on one resident workgroup per CU; the split count whose last round of
 // workgroups is fullest, counting a start-up worth a few stages per workgroup; at most 2047 stages per split (int32 accumulators)
-constexpr int kTnBufs = 4;   // 4 buffers x 2 workgroups per CU: 3 stages in flight (3 x 3 would need <= 170 VGPRs: the kernel holds 220)
+constexpr int kTnBufs = 4;   // 4 buffers x 2 workgroups per CU: 3 stages in flight.  (3 x 3 needs <= 168 VGPRs; the kernel holds 206, 128 of them accumulators: forcing the bound makes the
+                             // compiler spill 34 dwords inside the stage loop -- round 6 -- and scratch traffic shares the vmcnt the hand-written waits count: not an option without a smaller wave tile)
 // Items of the transposed-operand kernel: the first n_lo strips are cut into c_lo equal pieces of their K range, the other strips into c_lo + 1; the items of
 // the c_lo-piece strips (the longer ones) come first, piece-major.  Chosen so that the items fill whole rounds of the resident slots with (nearly) equal
 // lengths inside every round: cost = sum over the rounds of (longest item of the round + a few stages of start-up and flush), fewest pieces among equals.

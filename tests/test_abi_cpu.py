@@ -235,3 +235,21 @@ def test_rccl_bindings_are_typed_by_the_image_header_and_checked_at_compile_time
     assert "librccl" not in needed and "libamdhip64" in needed
     multi = open(os.path.join(ROOT, "miraculix_amd", "csrc", "mxa_multi.cpp")).read()
     assert "ncclFloat64, ncclSum" in multi and "kNcclFloat64" not in multi          # the call site uses the header's enumerators, no magic numbers
+
+
+def test_bench_compact_line_fits_the_driver_record():
+    """bench.py prints ONE line that the driver keeps whole: compact_line() of the committed detail file of the last GPU run stays below 4 KB, carries the contract's keys,
+    the roofline, both CPU baselines, the in-run oracle check and one key per BASELINE config leg"""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    detail = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_detail_n1.json")))
+    line = bench.compact_line(detail)
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) <= 4096, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline",
+              "cpu_baseline_port", "check", "world_size", "rccl_ranks", "c3_ms_i8", "c3_frac_i8", "c3_ms_f4", "c3_frac_f4", "c5_step_ms", "c5_TBps", "c4_full_TFLOPs", "detail"):
+        assert k in line, k
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-3
+    assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and line["cpu_baseline_port"]["kind"] == "port"
+    assert line["check"]["oracle_T_max_rel_err"] <= 1e-11 and line["check"]["oracle_N_max_rel_err"] <= 1e-11 and "model" not in line["config"]
