@@ -461,9 +461,8 @@ int create_handle(const uint8_t *plink, size_t plink_pitch, const uint8_t *plink
   } else {
     (void)hipMemset(h->d_f, 0, sizeof(double) * snps);
   }
-  // The host copy of the frequencies travels on the OBJECT'S stream: the first device-to-host copy a stream issues pays the runtime's lazy set-up of that
-  // path -- 7-9 ms, which the reference's harness otherwise meets inside its first dgemm_compressed call (the download of a 4 MB C took 7.2-9.3 ms on the
-  // device's own clock there, a 20 MB one later 0.4: profiles/r06_harness_phase_clock.txt).  Here it is part of plink2compressed.
+  // (the host copy of the frequencies travels on the object's stream; that alone does NOT pay the runtime's first staged device-to-host copy of a product --
+  // measured, "attempt 1" in profiles/r06_harness_phase_clock.txt -- the warm-up products below do)
   if (!check_hip(hipMemcpyAsync(h->h_f, h->d_f, sizeof(double) * snps, hipMemcpyDeviceToHost, h->stream), __func__, __LINE__) ||
       !check_hip(hipStreamSynchronize(h->stream), __func__, __LINE__)) { destroy_handle(h); return 1; }
   if (ensure_workspace(h, h->max_n) || reserve_small_routes(h, h->max_n)) { destroy_handle(h); return 1; }
