@@ -1458,8 +1458,8 @@ def compact_line(d):
     c4e = d.get("config4_full_extent_8_virtual_shards")
     if c4e and "failed" not in c4e:
         line["c4_extent_TFLOPs_8_shards"] = [g(c4e, next(k for k in c4e if k.endswith("virtual_shards")), t, "TFLOPs_call") for t in ("N", "T")]
-    if any(k.startswith("config") for k in d):
-        line["legs_parity_ok"] = True          # (a violated leg check ends the run before this line is printed)
+    if any(k.startswith("config") and k != "config" for k in d):
+        line["legs_parity_ok"] = True          # (the legs ran; a violated leg check ends the run before this line is printed)
     if failed:
         line["legs_failed"] = failed
     line["detail"] = "bench_detail.json"
