@@ -592,8 +592,7 @@ constexpr int kTnSlabStride = kTileBytes + 64;                // LDS bytes betwe
 // the ring holds BUFS - 1 = 3 stages in flight per workgroup (was 2) with two workgroups per CU: 96 KiB of packed bytes on their way per CU instead of 64 --
 // the kernel is bound by the packed stream's latency, not by its arithmetic (DMA ring alone: 0.93 ms where the full kernel took 1.03, profiles/r04).
 constexpr int kTnSlabs = 2;
-constexpr int kTnMaxPieces = 64;              // partial-sum slots per strip at most
-struct TnPieces { int c_lo, n_lo, nitems; };  // strips [0, n_lo): c_lo pieces each, the others c_lo + 1 (plan_i8_tn)
+// (which pieces of which strips a workgroup multiplies: TnSched, mxa_plan.h -- host-only code, swept on the CPU)
 template <int BUFS, int TT>
 struct TnCfg {
   static constexpr int kWaves = 4;
@@ -610,7 +609,7 @@ struct TnCfg {
 template <int BUFS, int TT>
 __global__ void __launch_bounds__(256, TT == 1 ? 2 : 1)
 k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__restrict__ Ad, int digit_tiles, int *__restrict__ P, long m_pad, int e_pad, int e_off,
-             int strips, int stages_total, TnPieces pc, const int *__restrict__ skip_if_set) {
+             TnSched sc, const int *__restrict__ skip_if_set) {
   // Ad: the digit fragments of THIS launch's tile of 32 expanded columns, K-steps digit_tiles KiB apart (k_slice_B interleaves the tiles of a K-step);
   // the sums go to rows e_off .. e_off + 31 of P[split][e_pad][m_pad].  A product with several tiles (3 <= n <= 6, the opt-in engines) is one launch per tile.
   using Cfg = TnCfg<BUFS, TT>;
@@ -622,12 +621,13 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fh = (lane >> 4) & 1;                             // field half
   const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
-  // PERSISTENT workgroups over a list of ITEMS = (strip, piece of its K range), longest first (round 5; TnPieces).  Integer sums are exact, so the result
-  // does not depend on where the cuts fall -- which frees them: strips are cut into c or c + 1 equal pieces such that the items fill whole rounds of the
-  // resident slots (391 strips x 5 equal splits on 512 slots took 4 rounds for 3.82 rounds of work; 307 strips x 5 + 84 x 6 pieces take 3 rounds of 195
-  // stages + 1 of 163), and a slot is never re-dispatched (a replaced workgroup cost ~10 us of idle slot).  The items of a round start together and sweep
-  // their K ranges in step: the digit fragments they share stay in the L2s (an even cut of the strip-major stage sequence, tried first, scattered the
-  // workgroups over all row blocks: 1.20 ms against 1.04).  A piece's sums go to slot = piece index of P[slot][e][individual].
+  // PERSISTENT workgroups over ITEMS = (strip, piece of its K range) (round 5).  Integer sums are exact, so the result does not depend on where the cuts
+  // fall -- which frees them; a slot is never re-dispatched (a replaced workgroup cost ~10 us of idle slot).  The schedule is TnSched's (mxa_plan.h), either
+  // mode 0 -- strips cut into c or c + 1 equal pieces such that the items fill whole rounds of the resident slots (391 strips x 5 equal splits on 512 slots took
+  // 4 rounds for 3.82 rounds of work; 298 strips x 5 + 93 x 6 pieces take 3 rounds of 195 stages + 1 of 163); the items of a round start together and sweep
+  // their K ranges in step, so the digit fragments they share stay in the L2s (an even cut of the strip-major stage sequence, tried first, scattered the
+  // workgroups over all row blocks: 1.20 ms against 1.04) -- or mode 1 (round 6): heads [0, la) of the strips on one class of workgroups, the tails dealt
+  // evenly to the others: 2.3 pieces per strip instead of 5.5, and every piece is 32 KiB of sums leaving for HBM.  A piece's sums go to P[slot][e][individual].
   int strip = 0, st0 = 0, stages = 0, slot = 0;
   // DMA: LDS granule `lane` of a packed unit takes the global granule sigma(lane): rows 16..31 land rotated by one row
   const int rho = (lane - 32) >> 1;
@@ -675,17 +675,14 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
   const int w_15 = (cg >> 3) * kTnSlabStride + (khalf ? 16 : 15) * kSlabBytes + (cg & 7) * 4;
   const uint32_t sel1 = fh ? 0x07030602u : 0x05010400u;     // first gather stage: byte pairs (2 fh, 2 fh + 1) of the two rows
 
-  for (int item = blockIdx.x; item < pc.nitems; item += gridDim.x) {
+  int item_i = 0;
+  int tail_g = 0;
+  TnItem item;
+  while (tn_next(sc, (int)blockIdx.x, item_i, tail_g, item)) {
   {
   // ---- one item: stages [st0, st0 + stages) of `strip`
-  {
-    int c, piece;
-    if (item < pc.n_lo * pc.c_lo) { c = pc.c_lo; piece = item / pc.n_lo; strip = item - piece * pc.n_lo; }                       // piece-major: the strips' p-th pieces are neighbours
-    else { const int j = item - pc.n_lo * pc.c_lo, n_hi = strips - pc.n_lo; c = pc.c_lo + 1; piece = j / n_hi; strip = pc.n_lo + j - piece * n_hi; }
-    st0 = (int)((long)piece * stages_total / c);
-    stages = (int)((long)(piece + 1) * stages_total / c) - st0;
-    slot = piece;
-  }
+  strip = __builtin_amdgcn_readfirstlane(item.strip); st0 = __builtin_amdgcn_readfirstlane(item.st0);
+  stages = __builtin_amdgcn_readfirstlane(item.stages); slot = __builtin_amdgcn_readfirstlane(item.slot);
 #pragma unroll
   for (int f = 0; f < 8; f++)
 #pragma unroll
@@ -738,9 +735,17 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
       }
     }
   }
-  // ---- add the accumulators of the four waves that split the K-steps through LDS, two MFMA groups per pass, and store P[split][e][individual]
+  // ---- add the accumulators of the four waves that split the K-steps through LDS, two MFMA groups per pass, and store P[split][e][individual].
+  // Round 6: the sums are collected in an LDS image of the strip's 32 x 256 block of P and leave as 16-byte-per-lane rows (a wave writes a whole 1 KiB row of one e per
+  // instruction).  Until then every lane stored its 4-byte sums where they fell -- 64 lanes = 32 individuals 32 B apart in each of two rows per instruction, eight instructions
+  // per cache line -- and the timing-only builds of this round showed what that cost: the kernel WITHOUT its partial-sum stores ran 0.92 ms where the whole one took 0.99-1.01
+  // (no MFMAs, no byte gather, no LDS reads: no change; profiles/r06_tn_ablation.txt): 72 MB of stores were 8 % of a 6.3 GB kernel, because a workgroup streams nothing while
+  // its epilogue drains.  The timing-only builds that followed (all items store into ONE 32 KiB region: 0.928 ms; no stores: 0.927; real: 1.017) showed that it is the
+  // HBM write traffic itself, not the store pattern: the answer is fewer pieces (TnSched mode 1), and these rows stay because they are no slower and simpler to read.
+  static_assert(Cfg::kLds >= 2 * 32768, "reduction buffer + the 32 x 256 image of P");
   __syncthreads();
   int *red = reinterpret_cast<int *>(smem);                  // [wave][group in pass (2)][reg (16)][lane (64)] ints = 8 KiB per wave
+  int *img = reinterpret_cast<int *>(smem + 32768);          // [e (32)][individual of the strip (256)]
 #pragma unroll
   for (int tt = 0; tt < TT; tt++) {
   int *Pb = P + ((size_t)slot * e_pad + e_off + 32 * tt) * m_pad;
@@ -755,7 +760,6 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
       const int gq = wave & 1, r0 = 8 * (wave >> 1);         // this wave finishes group gq, registers r0 .. r0 + 7
       const int f = 8 * fh + 2 * pass + gq;                  // field of the dword = individual 16 cg + f
       const int sh = (f & 3) == 3 ? 4 : 2 * (f & 3);         // the in-place field scale of the group: 4^g, 16 for the top field
-      const long indiv = (long)strip * (kTnSlabs * kSlabK) + 16 * cg + f;
 #pragma unroll
       for (int rr = 0; rr < 8; rr++) {
         const int r = r0 + rr;
@@ -763,11 +767,22 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
 #pragma unroll
         for (int w = 0; w < 4; w++) v += red[((w * 2 + gq) * 16 + r) * 64 + lane];
         const int e = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        Pb[(size_t)e * m_pad + indiv] = v >> sh;             // exact: every product carried the factor
+        img[e * 256 + 16 * cg + f] = v >> sh;                // exact: every product carried the factor
       }
     }
     __syncthreads();
   }
+  // the image leaves: wave w writes rows e = 8 w .. 8 w + 7, lane l the individuals 4 l .. 4 l + 3 of the strip (m_pad is a multiple of the strip: 16-byte aligned)
+  // (nontemporal: nobody reads them before the finish kernel -- 1.006-1.008 -> 0.983-0.984 ms on one box, profiles/r06_tn_nt_store.txt)
+  {
+    int *dst = Pb + (size_t)strip * (kTnSlabs * kSlabK) + 4 * lane;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int e = 8 * wave + i;
+      __builtin_nontemporal_store(*reinterpret_cast<const v4i *>(img + e * 256 + 4 * lane), reinterpret_cast<v4i *>(dst + (size_t)e * m_pad));
+    }
+  }
+  __syncthreads();                                           // (the next tile's sums / the next item's DMA reuse the image)
   }   // tiles of the pass
   }
   }   // items of this workgroup
@@ -879,11 +894,10 @@ constexpr int kFinTBlockRows = 64 * kFinTRows;
 __global__ void __launch_bounds__(256) k_finish_i8_t(const int *__restrict__ P, long m_pad, int e_pad, int splits, long m, int n, int S, int nc, int NT,
                                                      const int *__restrict__ E, const double *__restrict__ colmax_part, double *__restrict__ Cout, long ldc,
                                                      long fill_rows, int mode_trans, int centered, const double *__restrict__ sumB, const double *__restrict__ sumfB,
-                                                     const double *__restrict__ f, const int *__restrict__ skip_if_set, int tn_c_lo, int tn_n_lo) {
+                                                     const double *__restrict__ f, const int *__restrict__ skip_if_set, int tn, TnSched tn_sc) {
   if (skip_if_set && *skip_if_set) return;
-  // partial sums of the transposed-operand kernel (tn_c_lo > 0): this block's 256 rows are ONE strip of k_gemm_i8_tn, which was cut into c_lo pieces (strips
-  // [0, n_lo)) or c_lo + 1: one slot of P per piece
-  if (tn_c_lo > 0) splits = tn_c_lo + (((int)blockIdx.x >= tn_n_lo && (long)blockIdx.x < m_pad / kFinTBlockRows) ? 1 : 0);   // (blocks beyond the last strip: ld padding rows, zeros)
+  // partial sums of the transposed-operand kernel (tn): this block's 256 rows are ONE strip of k_gemm_i8_tn; one slot of P per piece the schedule cut it into
+  if (tn) splits = (long)blockIdx.x < tn_sc.strips ? tn_pieces(tn_sc, blockIdx.x) : 1;   // (blocks beyond the last strip: ld padding rows, zeros)
   const int j = blockIdx.y, chunk = j / nc, jj = j - chunk * nc;
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const long rbase = (long)blockIdx.x * kFinTBlockRows + lane;
@@ -1103,53 +1117,32 @@ constexpr int kTnBufs = 4;   // 4 buffers x 2 workgroups per CU: 3 stages in fli
 // Items of the transposed-operand kernel: the first n_lo strips are cut into c_lo equal pieces of their K range, the other strips into c_lo + 1; the items of
 // the c_lo-piece strips (the longer ones) come first, piece-major.  Chosen so that the items fill whole rounds of the resident slots with (nearly) equal
 // lengths inside every round: cost = sum over the rounds of (longest item of the round + a few stages of start-up and flush), fewest pieces among equals.
-static void plan_i8_tn(long indiv_slabs, long snp_rows, int wg_per_cu, int *strips_out, int *stages_out, TnPieces *pc) {
-  const int n = (int)((indiv_slabs + kTnSlabs - 1) / kTnSlabs), K = (int)((snp_rows + kTileRows - 1) / kTileRows);
-  *strips_out = n; *stages_out = K;
+static TnSched plan_i8_tn(long indiv_slabs, long snp_rows, int tiles_per_pass) {
   static const long cus = [] {
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) { (void)hipGetLastError(); return 256L; }
     return (long)prop.multiProcessorCount;
   }();
-  const long slots = cus * wg_per_cu;
-  const int c_min = std::max(1, (K + 2046) / 2047);               // int32 accumulators: at most 2047 stages per piece
-  const int c_max = std::max(c_min, std::min(kTnMaxPieces - 1, K / 24));   // pieces shorter than ~24 stages are mostly start-up
-  double best = -1.0; int best_c = c_min, best_nlo = n;
-  for (long R = 1; R <= 64; R++) {
-    const long T = R * slots;
-    int c = (int)std::min<long>(c_max, std::max<long>(c_min, T / n));
-    long n_hi = std::min<long>(n, std::max<long>(0, T - (long)n * c));
-    if (c >= c_max) n_hi = 0;
-    const long n_lo = n - n_hi, items_lo = n_lo * c, items = items_lo + n_hi * (c + 1);
-    const double len_lo = (double)K / c, len_hi = (double)K / (c + 1);
-    double cost = 0.0;
-    for (long i0 = 0; i0 < items; i0 += slots) cost += (i0 < items_lo ? len_lo : len_hi) + 20.0;   // a round lasts as long as its first (longest) item + ~20 stages of start-up and flush (fits the measured shapes)
-    cost += 0.35 * (double)(items) / (double)n;                                                    // the finish kernel reads one slot per piece
-    if (best < 0 || cost < best * 0.995) { best = cost; best_c = c; best_nlo = (int)n_lo; }
-    if (c >= c_max) break;
-  }
-  pc->c_lo = best_c; pc->n_lo = best_nlo; pc->nitems = best_nlo * best_c + (n - best_nlo) * (best_c + 1);
+  const char *e = getenv("MXA_TN_SCHED");                                  // A/B runs and tests: 0 / 1 = the mode, if the shape allows it (read per product:
+  const int force = e && *e ? atoi(e) : -1;                                // tools/ab_env.py alternates the two inside one process, on one clock)
+  return plan_i8_tn_host(indiv_slabs, snp_rows, cus * (tiles_per_pass == 1 ? 2 : 1), tiles_per_pass, force);
 }
 
 template <int BUFS, int TT>
-static int launch_i8_tn(const PackedMatrix &G_tn, const int8_t *d_Bs, int *d_P, const I8Plan &p, int strips, int stages, const TnPieces &pc, hipStream_t s, const int *skip) {
+static int launch_i8_tn(const PackedMatrix &G_tn, const int8_t *d_Bs, int *d_P, const I8Plan &p, const TnSched &sc, hipStream_t s, const int *skip) {
   static unsigned long long attr_tn = 0;
   if (ensure_dyn_lds(reinterpret_cast<const void *>(&k_gemm_i8_tn<BUFS, TT>), (TnCfg<BUFS, TT>::kLds), &attr_tn)) return 1;
-  static int per_dev[64] = {};
-  int dev = 0;
-  MXA_HIP(hipGetDevice(&dev));
-  if (!per_dev[dev & 63]) { hipDeviceProp_t prop; MXA_HIP(hipGetDeviceProperties(&prop, dev)); per_dev[dev & 63] = std::max(1, prop.multiProcessorCount); }
-  const unsigned grid = (unsigned)std::min(pc.nitems, (TT == 1 ? 2 : 1) * per_dev[dev & 63]);   // persistent: one workgroup per resident slot, fewer if there are fewer items
+  const unsigned grid = (unsigned)tn_grid(sc);   // persistent: one workgroup per resident slot (mode 0: fewer if there are fewer items)
   constexpr int lds = TnCfg<BUFS, TT>::kLds;
   for (int nt = 0; nt < p.NT; nt += TT)
     hipLaunchKernelGGL((k_gemm_i8_tn<BUFS, TT>), dim3(grid), dim3(256), lds, s, G_tn.d, G_tn.nslabs, d_Bs + (size_t)nt * 1024, p.NT, d_P, p.m_pad, p.e_pad,
-                       nt * 32, strips, stages, pc, skip);
+                       nt * 32, sc, skip);
   MXA_HIP(hipGetLastError());
   return 0;
 }
 
 // plan of one product (plain or transposed-operand form) and the bytes of workspace it needs; returns 2 when the transposed form declines
-struct I8Full { I8Plan p; bool tn; int tn_strips, tn_stages; TnPieces tn_pc; size_t part_bytes, e_bytes, bs_bytes, p_bytes, need; };
+struct I8Full { I8Plan p; bool tn; int tn_strips, tn_stages; TnSched tn_sc; size_t part_bytes, e_bytes, bs_bytes, p_bytes, need; };
 static int plan_i8_full(const PackedMatrix &G, int n, int S_override, const PackedMatrix *G_tn, I8Full &f) {
   const long m = G.rows, k = G.k;
   f.p = plan_i8(m, G.k_pad, n, S_override);
@@ -1164,14 +1157,15 @@ static int plan_i8_full(const PackedMatrix &G, int n, int S_override, const Pack
   f.tn = G_tn != nullptr;
   // host-side operand check before anything is enqueued: a kernel must never be handed the dimensions-only descriptor of a copy that is not stored
   if ((f.tn ? G_tn->d : G.d) == nullptr) { set_error(4, "internal: the int8 route was given a packed matrix that is not stored (single-orientation object)"); return 1; }
-  f.tn_strips = f.tn_stages = 0; f.tn_pc = TnPieces{1, 0, 0};
+  f.tn_strips = f.tn_stages = 0; f.tn_sc = TnSched{};
   if (f.tn) {
     if (G_tn->k != m || G_tn->rows != k) { set_error(4, "internal: transposed operand has the wrong shape"); return 1; }
-    plan_i8_tn(G_tn->nslabs, G_tn->rows, p.NT >= 2 ? 1 : 2, &f.tn_strips, &f.tn_stages, &f.tn_pc);
+    f.tn_sc = plan_i8_tn(G_tn->nslabs, G_tn->rows, p.NT >= 2 ? 2 : 1);
+    f.tn_strips = f.tn_sc.strips; f.tn_stages = f.tn_sc.K;
     if ((long)f.tn_stages * kTileRows > G_tn->rows_pad) { set_error(4, "internal: packed matrix smaller than the transposed i8 plan"); return 1; }
-    if ((f.tn_stages + f.tn_pc.c_lo - 1) / f.tn_pc.c_lo > 2047) return 2;   // K beyond 64 x 2047 row blocks (33.5 M SNPs in one object): the fp64 path
+    if (f.tn_sc.mode == 0 && (f.tn_stages + f.tn_sc.q1 - 1) / f.tn_sc.q1 > kTnMaxPieceStages) return 2;   // K beyond 64 x 2047 row blocks (33.5 M SNPs in one object): the fp64 path
     // splits = partial-sum slots per strip
-    p.T_total = (long)f.tn_stages * 8; p.splits = f.tn_pc.c_lo + (f.tn_pc.n_lo < f.tn_strips ? 1 : 0); p.m_pad = (long)f.tn_strips * kTnSlabs * kSlabK; p.e_pad = p.NT * 32;
+    p.T_total = (long)f.tn_stages * 8; p.splits = f.tn_sc.pslots; p.m_pad = (long)f.tn_strips * kTnSlabs * kSlabK; p.e_pad = p.NT * 32;
   }
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
   f.part_bytes = up(sizeof(double) * 128 * n); f.e_bytes = up(sizeof(int) * (n + 1));   // column maxima + minima; exponents
@@ -1213,7 +1207,6 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   }
   I8Plan &p = pf.p;
   const bool tn = pf.tn;
-  const int tn_strips = pf.tn_strips, tn_stages = pf.tn_stages;
   if (splits_out) *splits_out = p.splits;
   const size_t part_bytes = pf.part_bytes, e_bytes = pf.e_bytes, bs_bytes = pf.bs_bytes;
   if (chain && !chain->first && w.cap_i8 < pf.need) { set_error(4, "internal: the second chain of a guarded product outgrows the workspace (gemm_i8_reserve)"); return 1; }
@@ -1274,13 +1267,13 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   const bool small_tile = p.nchunks == 1 && p.NT == 1 && p.nc * p.S <= 32 && (p.nc == 1 || p.nc == 2);   // n <= 2: one tile
   I8Direct dir{};
   if (tn) {
-    if (p.NT >= 2 ? launch_i8_tn<6, 2>(*G_tn, d_Bs, d_P, p, tn_strips, tn_stages, pf.tn_pc, s, skip)
-                  : launch_i8_tn<kTnBufs, 1>(*G_tn, d_Bs, d_P, p, tn_strips, tn_stages, pf.tn_pc, s, skip)) return 1;
+    if (p.NT >= 2 ? launch_i8_tn<6, 2>(*G_tn, d_Bs, d_P, p, pf.tn_sc, s, skip)
+                  : launch_i8_tn<kTnBufs, 1>(*G_tn, d_Bs, d_P, p, pf.tn_sc, s, skip)) return 1;
     if (ev1) MXA_HIP(hipEventRecord(ev1, s));
     static_assert(kFinTBlockRows == kTnSlabs * kSlabK, "a block of k_finish_i8_t = one strip of k_gemm_i8_tn: it adds that strip's slots");
     dim3 grid((unsigned)((fill_rows + kFinTBlockRows - 1) / kFinTBlockRows), (unsigned)n);
     hipLaunchKernelGGL(k_finish_i8_t, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, d_part, dC, ldc, fill_rows, trans ? 1 : 0,
-                       centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip, pf.tn_pc.c_lo, pf.tn_pc.n_lo);
+                       centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip, 1, pf.tn_sc);
     MXA_HIP(hipGetLastError());
     return guard == 2 ? 3 : 0;
   }
@@ -1308,7 +1301,7 @@ int gemm_i8_device(const PackedMatrix &G, bool trans, int n, const double *dB, l
   } else if (p.NT >= 2 || swap1) {   // operand-swapped instantiations: transposed partial sums
     dim3 grid((unsigned)((fill_rows + kFinTBlockRows - 1) / kFinTBlockRows), (unsigned)n);
     hipLaunchKernelGGL(k_finish_i8_t, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, d_part, dC, ldc, fill_rows, trans ? 1 : 0,
-                       centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip, 0, 0);
+                       centered ? 1 : 0, d_sumB, d_sumfB, d_f, skip, 0, TnSched{});
   } else {
     dim3 grid((unsigned)((fill_rows + 31) / 32), p.nchunks);
     hipLaunchKernelGGL(k_finish_i8, grid, dim3(256), 0, s, d_P, p.m_pad, p.e_pad, p.splits, m, n, p.S, p.nc, p.NT, d_E, d_part, dC, ldc, fill_rows, trans ? 1 : 0,

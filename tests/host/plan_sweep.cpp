@@ -38,6 +38,46 @@ static void check_plan(const GemmPlan &p, long m, long k_pad, int n, bool lut) {
   CHECK(doubles < (1ull << 60), "partial sums %llu doubles: the byte count would overflow", doubles);   // (what does not fit the device runs in split groups: partial_budget)
 }
 
+// schedule of k_gemm_i8_tn: run every workgroup's item list and require that each strip's K range is covered exactly once, that a strip's pieces fill the
+// slots 0 .. tn_pieces(strip) - 1 exactly once each (k_finish_i8_t adds exactly those), and that no piece outgrows the int32 accumulators
+static void check_tn(long indiv, long snps, long slots, int tiles, int force) {
+  const long slabs = (indiv + 127) / 128;
+  const TnSched s = plan_i8_tn_host(slabs, snps, slots, tiles, force);
+  const long n = (slabs + 1) / 2, K = (snps + 255) / 256;
+  CHECK(s.strips == n && s.K == K && s.slots == slots && (force < 0 || s.mode == force || (force == 1 && s.mode == 0)), "indiv %ld snps %ld slots %ld: header", indiv, snps, slots);
+  CHECK(s.pslots >= 1 && s.pslots <= kTnMaxPieces, "indiv %ld snps %ld slots %ld mode %d: %d slots of P", indiv, snps, slots, s.mode, s.pslots);
+  std::vector<int> covered((size_t)n * K, 0), slot_used((size_t)n * kTnMaxPieces, 0);
+  const int grid = tn_grid(s);
+  CHECK(grid >= 1 && grid <= slots, "grid %d", grid);
+  long pieces = 0;
+  bool too_long = false;
+  for (int wg = 0; wg < grid; wg++) {
+    int i = 0, g = 0; TnItem it;
+    int guard = 0;
+    while (tn_next(s, wg, i, g, it)) {
+      if (++guard > 100000) { CHECK(false, "workgroup %d never ends", wg); break; }
+      pieces++;
+      const bool in = it.strip >= 0 && it.strip < n && it.st0 >= 0 && it.stages >= 1 && it.st0 + it.stages <= K && it.slot >= 0 && it.slot < s.pslots;
+      CHECK(in, "indiv %ld snps %ld slots %ld mode %d wg %d: item strip %d [%d, +%d) slot %d", indiv, snps, slots, s.mode, wg, it.strip, it.st0, it.stages, it.slot);
+      if (!in) continue;
+      if (it.stages > kTnMaxPieceStages) too_long = true;
+      for (int q = 0; q < it.stages; q++) covered[(size_t)it.strip * K + it.st0 + q]++;
+      slot_used[(size_t)it.strip * kTnMaxPieces + it.slot]++;
+    }
+  }
+  // (pieces beyond 2047 stages only where the caller refuses the product: K > c_lo x 2047 in mode 0)
+  CHECK(!too_long || (s.mode == 0 && (K + s.q1 - 1) / s.q1 > kTnMaxPieceStages), "indiv %ld snps %ld: a piece outgrows the accumulators", indiv, snps);
+  long bad_cover = 0, bad_slots = 0;
+  for (size_t q = 0; q < covered.size(); q++) bad_cover += covered[q] != 1;
+  for (long st = 0; st < n; st++) {
+    const int pc = tn_pieces(s, st);
+    if (pc < 1 || pc > s.pslots) { bad_slots++; continue; }
+    for (int q = 0; q < kTnMaxPieces; q++) bad_slots += slot_used[(size_t)st * kTnMaxPieces + q] != (q < pc ? 1 : 0);
+  }
+  CHECK(bad_cover == 0, "indiv %ld snps %ld slots %ld tiles %d mode %d: %ld stages not covered exactly once", indiv, snps, slots, tiles, s.mode, bad_cover);
+  CHECK(bad_slots == 0, "indiv %ld snps %ld slots %ld tiles %d mode %d: %ld slot mismatches", indiv, snps, slots, tiles, s.mode, bad_slots);
+}
+
 int main() {
   const long ms[] = {1, 3, 127, 128, 129, 500, 1000, 1003, 4096, 50000, 100000, 200000, 625000, 1000000, 2000000, 5000000, 33554432, 40000001};
   const long ks[] = {1, 100, 128, 129, 500, 1000, 12800, 25000, 50000, 100000, 200000, 1000000, 5000000, 40000000};
@@ -58,6 +98,20 @@ int main() {
           if (n <= 4 && cus == 256) check_plan(plan_lut_host(m, k_pad, n), m, k_pad, n, true);
         }
       }
+  // schedules of the transposed-operand int8 kernel, planner's choice and both modes forced
+  const long tn_indiv[] = {1, 200, 256, 257, 1301, 10000, 50000, 65536, 100000, 131072, 133000, 200000, 262144, 500000};
+  const long tn_snps[] = {1, 255, 256, 777, 6000, 10000, 50000, 250000, 524032, 524033, 1000000};
+  const long tn_slots[] = {512, 256, 208, 608, 8};
+  for (long slots : tn_slots)
+    for (long indiv : tn_indiv)
+      for (long snps : tn_snps) {
+        if ((indiv / 256 + 1) * (snps / 256 + 1) > 6000000) continue;
+        for (int force = -1; force <= 1; force++) check_tn(indiv, snps, slots, slots >= 500 ? 1 : 2, force);
+      }
+  {   // the headline shard takes the two-class schedule: 391 heads + 121 tail workgroups, three slots of P
+    const TnSched s = plan_i8_tn_host((100000 + 127) / 128, 250000, 512, 1);
+    CHECK(s.mode == 1 && s.q0 == 0 && s.q1 == 391 && s.q2 == 761 && s.pslots == 3, "headline schedule: mode %d whole %d rem %d la %d pslots %d", s.mode, s.q0, s.q1, s.q2, s.pslots);
+  }
   // SNP shards
   const long snps_list[] = {1, 3, 4, 5, 7, 8, 100, 1000, 1003, 625000, 1000000, 5000000, 2147483647L};
   for (long snps : snps_list)
