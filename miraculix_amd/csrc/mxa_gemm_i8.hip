@@ -633,13 +633,6 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
   const int rho = (lane - 32) >> 1;
   const uint32_t v_pack = lane < 32 ? (uint32_t)lane * 16 : (uint32_t)(2 * (16 + ((rho + 15) & 15)) + (lane & 1)) * 16;
   const uint32_t v_lin = (uint32_t)lane * 16;
-  v4i dig[NSET][2][TT];                                       // digit fragments of this wave's two K-steps (x TT tiles), one register set per stage in flight (+ the one in use)
-#pragma unroll
-  for (int i = 0; i < NSET; i++)
-#pragma unroll
-    for (int kk = 0; kk < 2; kk++)
-#pragma unroll
-      for (int tt = 0; tt < TT; tt++) dig[i][kk][tt] = v4i{0, 0, 0, 0};
   // all global traffic of one stage: 4 packed DMA units, then the two digit loads (asm: the compiler does not see the DMA, so it must not count vmcnt either)
   auto issue_packed = [&](int stage, int buf) {               // stage relative to st0
     const uint32_t base = lds0 + buf * Cfg::kBufBytes;
@@ -689,6 +682,16 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
     for (int tt = 0; tt < TT; tt++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[f][tt][r] = 0;
+  // digit fragments of this wave's two K-steps (x TT tiles), one register set per stage in flight (+ the one in use).  Declared and cleared PER ITEM: as values
+  // that live from one item to the next they crossed the epilogue, were spilled there (two tiles: all 256 registers are accumulators), and the compiler's own
+  // waits for those scratch accesses -- vmcnt(0..5), counted without the DMA it does not see -- landed in the stage loop: 1.86 ms where 1.45 had been measured.
+  v4i dig[NSET][2][TT];
+#pragma unroll
+  for (int i = 0; i < NSET; i++)
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+      for (int tt = 0; tt < TT; tt++) dig[i][kk][tt] = v4i{0, 0, 0, 0};
 #pragma unroll
   for (int i = 0; i < D; i++) if (i < stages) { issue_packed(i, i); issue_digits(i, dig[i]); }
   for (int s0 = 0; s0 < stages; s0 += NSET) {

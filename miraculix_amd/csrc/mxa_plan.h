@@ -249,11 +249,12 @@ inline TnSched plan_i8_tn_host(long indiv_slabs, long snp_rows, long slots, int 
           valid = most <= kTnMaxPieces;
         }
         // measured, both modes alternating inside one process (tools/ab_env.py; profiles/r06_tn_sched_ab.txt).  Two digit tiles per pass (one workgroup per CU,
-        // nobody hides a piece's start-up and flush): mode 1 won or tied on every shape tried, 0-11 %.  One tile per pass (two workgroups per CU): +0.5-2.4 % while the
-        // tails are 100-370 stages long and a tail workgroup has at most ~5 of them; it LOST 1-8 % with short tails in many pieces (120 000 individuals: 64 stages, 12
-        // pieces per workgroup; K = 123: 14 stages), with tails whose digit window outgrows the L2 (447 and 600 stages) and where most workgroups are tail workgroups (79 strips).
+        // nobody hides a piece's start-up and flush): mode 1 won or tied on twelve of thirteen shapes (0-16 %; 250 000 x 100 000, n = 4: 1.49 -> 1.44 ms) and lost
+        // 1.6 % on the one where under a third of the slots hold heads (79 strips).  One tile per pass (two workgroups per CU): +0.5-2.4 % while the tails are
+        // 100-370 stages long and a tail workgroup has at most ~5 of them; it LOST 1-8 % with short tails in many pieces (120 000 individuals: 64 stages, 12 pieces
+        // per workgroup; K = 123: 14 stages), with tails whose digit window outgrows the L2 (447 and 600 stages) and where most workgroups are tail workgroups.
         liked = Q >= (long)nb * 24 && la >= 24 && t.pslots <= 8 &&
-                (tiles_per_pass >= 2 || (tail >= kTnTailMinStages && tail * 8192L <= kTnTailWindowBytes && rem >= nb && rem <= 5L * nb));
+                (tiles_per_pass >= 2 ? 2L * rem >= nb : (tail >= kTnTailMinStages && tail * 8192L <= kTnTailWindowBytes && rem >= nb && rem <= 5L * nb));
         cost += std::max<double>((double)la + kTnPieceCost, (double)Q / nb + kTnPieceCost * (1.0 + (double)rem / nb));
         pieces += 2.0 * rem + nb;
       } else { cost += (double)la + kTnPieceCost; pieces += rem; }
