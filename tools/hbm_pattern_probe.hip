@@ -4,7 +4,7 @@
 //   tn     (k_gemm_i8_tn, 'N'):   persistent workgroups, 2 per CU, over items = (strip of 2 slabs, piece of the row blocks), piece-major as in the kernel; a stage = the two adjacent
 //                                 tiles (row block rb, slabs 2 strip, 2 strip + 1) = 16 KiB, the next stage is nslabs x 8 KiB further on; 3 stages in flight
 // Same bytes (the whole matrix once), same `nt` LDS-DMA units of 1 KiB, no arithmetic, no barrier.  The ratio of the two rates is what the transposed-operand kernel pays for reading the
-// SNP-major copy across its rows.   usage: hbm_pattern_probe [snps = 250000] [indiv = 100000] [reps = 5]
+// SNP-major copy across its rows.   usage: hbm_pattern_probe [snps = 250000] [indiv = 100000] [reps = 5] [only = -1: all seven patterns; 0 .. 6: that one alone -- with thousands of reps: a steady load for tools/power_trace.py hbm_*]
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) k_plain_dig(const char *__restrict__ G, l
 
 int main(int argc, char **argv) {
   const long snps = argc > 1 ? atol(argv[1]) : 250000, indiv = argc > 2 ? atol(argv[2]) : 100000;
-  const int reps = argc > 3 ? atoi(argv[3]) : 5;
+  const int reps = argc > 3 ? atoi(argv[3]) : 5, only = argc > 4 ? atoi(argv[4]) : -1;
   const long nslabs = (indiv + 127) / 128;
   const int rowblocks = (int)((snps + 255) / 256);
   const size_t bytes = (size_t)rowblocks * nslabs * kTile;
@@ -104,7 +104,9 @@ int main(int argc, char **argv) {
   printf("# hbm_pattern_probe: %ld SNPs x %ld individuals = %d row blocks x %ld slabs of 8 KiB tiles = %.2f GB; %d CUs; tn: %d strips x %d pieces\n", snps, indiv, rowblocks, nslabs, bytes / 1e9, cus, strips, pieces);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  int idx = 0;
   auto time_it = [&](const char *name, auto launch) {
+    if (only >= 0 && idx++ != only) return;
     launch();
     (void)hipDeviceSynchronize();
     float best = 1e30f, sum = 0.f;

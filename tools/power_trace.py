@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Power + clock trace of the GPU while one kernel family runs back to back (evidence for "power-bound").
 
-usage: power_trace.py <gemm|xprod_f4|xprod_i8|bare_f4|bare_i8|bare_f64|idle> [seconds] [operand pattern of the bare loops: geno|zero|rand]
+usage: power_trace.py <gemm|xprod_f4|xprod_i8|i8t<n>|i8tn<n>|gram|bare_f4|bare_i8|bare_f64|idle> [seconds] [operand pattern of the bare loops: geno|zero|rand]
 
 A sampler thread reads the card's hwmon / gpu_metrics files in sysfs every ~20 ms (falls back to `rocm-smi --showpower --showclocks --json`
 every ~0.5 s when sysfs is not readable) while the main thread keeps the GPU busy with ONE kernel family:
   gemm      k_gemm<8,8,3>   : C2 shape 1M x 50k x 32, 'N' + 'T' (fp64 MFMA)
   xprod_f4  k_crossprod_gang: 500k x 100k at reduced rows (200k SNPs x 50k individuals keeps a launch near 100 ms), FP4 MFMA
   xprod_i8  the same on the int8 MFMA
+  i8t<n> / i8tn<n> / gram   the int8 streaming kernels of a CG step ('T' on k_gemm_i8, 'N' of a one-copy object on k_gemm_i8_tn), or the whole step
+  hbm_plain / hbm_tn   the data movement of those two kernels alone (tools/hbm_pattern_probe: no arithmetic)
   bare_*    tools/mfma_power_probe: a bare stream of that MFMA instruction from registers, no memory traffic (child process) -- the rate the board sustains
 Prints: the samples (time, power W, sclk MHz, temperature) thinned to 10 per second, and the summary over the busy window
 (mean / p10 / p90 of power and clock, kernel time per launch)."""
@@ -107,6 +109,32 @@ def stage():
             dg.dgemm_compressed_main(False, obj, BN, snps, indiv, out=CN)
             dg.dgemm_compressed_main(True, obj, BT, snps, indiv, out=CT)
         return step, 2, f"k_gemm 1M x 50k x 32 'N' + 'T' (3.2 TFLOP per launch)"
+    if target.startswith("i8tn") or target.startswith("i8t") or target == "gram":
+        # i8tn<n>: the 'N' product of a one-copy object on k_gemm_i8_tn (n = 1: one digit tile per pass, n = 4 .. 6: two); i8t<n>: the 'T' product on the plain
+        # int8 kernel; gram: one CG step (mxa_gram_matvec, n = 1) = both.  Shape: TN_SNPS x TN_INDIV (default: the config-5 shard)
+        snps, indiv = int(os.environ.get("TN_SNPS", 250_000)), int(os.environ.get("TN_INDIV", 100_000))
+        n = 1 if target == "gram" else int(target[4:] or 1) if target.startswith("i8tn") else int(target[3:] or 1)
+        trans = target.startswith("i8t") and not target.startswith("i8tn")
+        plink = synth_genotypes_device(torch, snps, indiv, 42, dev)
+        f = mx.read_plink.calc_freq(plink, snps, indiv)
+        dg = mx.dgemm_compressed
+        dg.set_options(use_gpu=True, not_center=True, verbose=0)
+        obj = dg.init_compressed(plink, None, snps, indiv, f, n)
+        del plink
+        g = torch.Generator(device=dev); g.manual_seed(1)
+        kk, mm = (indiv, snps) if trans else (snps, indiv)
+        if target == "gram":
+            kk = mm = indiv
+        BN = torch.randn((n, kk), dtype=torch.float64, device=dev, generator=g).t()
+        CN = torch.zeros((n, mm), dtype=torch.float64, device=dev).t()
+
+        def step():
+            if target == "gram":
+                dg.gram_matvec(obj, BN, snps, indiv, out=CN, sync=False)
+            else:
+                dg.dgemm_compressed_main(trans, obj, BN, snps, indiv, out=CN)
+        what = "one CG step mxa_gram_matvec ('T' on k_gemm_i8 + 'N' on k_gemm_i8_tn)" if target == "gram" else ("k_gemm_i8 'T'" if trans else "k_gemm_i8_tn 'N'")
+        return step, (2 if target == "gram" else 1), f"{what} {snps} x {indiv} x {n} (one packed copy)"
     if target.startswith("xprod"):
         snps, indiv = int(os.environ.get("XP_SNPS", 200_000)), int(os.environ.get("XP_INDIV", 50_000))
         if target == "xprod_i8":
@@ -126,14 +154,20 @@ def power_cap(hw):
     return {k: (read_num(os.path.join(hw, k)) or 0) * 1e-6 for k in ("power1_cap", "power1_cap_max", "power1_cap_default") if hw and os.path.exists(os.path.join(hw, k))}
 
 
-if target.startswith("bare_"):
-    exe = os.path.join(ROOT, "tools", "mfma_power_probe")
-    pat = sys.argv[3] if len(sys.argv) > 3 else "geno"
+if target.startswith("bare_") or target.startswith("hbm_"):
+    # hbm_plain / hbm_tn: the DATA MOVEMENT of the two int8 kernels of a CG step alone (tools/hbm_pattern_probe, patterns 2 and 4: LDS DMA of the packed tiles +
+    # their digit traffic, no arithmetic), ~1 ms launches back to back for `seconds`
+    hbm = target.startswith("hbm_")
+    exe = os.path.join(ROOT, "tools", "hbm_pattern_probe" if hbm else "mfma_power_probe")
+    if hbm and not os.path.exists(exe):
+        subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-o", exe, exe + ".hip"])
+    pat = "-" if hbm else sys.argv[3] if len(sys.argv) > 3 else "geno"
+    argv = [exe, "250000", "100000", str(int(seconds * 1050)), "2" if target == "hbm_plain" else "4"] if hbm else [exe, target[5:], str(seconds), "1", pat]
     smp = Sampler()
     smp.start()
     time.sleep(1.0)
     t0 = time.perf_counter()
-    r = subprocess.run([exe, target[5:], str(seconds), "1", pat], capture_output=True, text=True, timeout=seconds + 120)
+    r = subprocess.run(argv, capture_output=True, text=True, timeout=seconds + 120)
     t1 = time.perf_counter()
     time.sleep(1.0)
     smp.stop = True
@@ -151,7 +185,7 @@ if target.startswith("bare_"):
         if x[0] - last >= 0.25:
             last = x[0]
             print(f"t={x[0]:6.2f}s power={x[1] if x[1] is None else round(x[1], 1)} W sclk={x[2] if x[2] is None else round(x[2])} MHz")
-    mean = [ln for ln in r.stdout.splitlines() if ln.startswith("mean over")]
+    mean = [ln for ln in r.stdout.splitlines() if ln.startswith("mean over") or " best " in ln]
     print(json.dumps({"target": target, "operands": pat, "sampler": smp.mode, "power_cap_W": power_cap(smp.hw), "busy_window_s": [b0, round(b1, 2)], "power_W": st(1), "sclk_MHz": st(2),
                       "rate": mean[0] if mean else None}))
     sys.exit(r.returncode)
