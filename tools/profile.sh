@@ -9,7 +9,8 @@
 #   pmc-mfma <gemm|i8|xprod_f4|xprod_i8>        SQ counter pass (MFMA busy, clock, waits) of one kernel family -> pmc_mfma_util_<t>.json
 #   pmc-traffic <gemm|i8|gram|xprod_f4|xprod_i8>  FETCH_SIZE / WRITE_SIZE passes (separate runs) -> pmc_traffic_<t>.txt
 #   harness [big]        the reference's benchmark.f90 (GPU mode, unmodified) with the phase clock of the plain ABI (PRINT_LEVEL=1)
-#   power [seconds]      power + clock trace: bare MFMA loops (f4, i8, f64), k_gemm, k_crossprod_gang FP4 / int8 (tools/power_trace.py)
+#   power [seconds]      power + clock trace: bare MFMA loops (f4, i8, f64), k_gemm, k_crossprod_gang FP4 / int8 (tools/power_trace.py); PT_TARGETS="i8t1 i8tn1 gram hbm_plain hbm_tn": the
+#                        int8 kernels of a CG step, the whole step, and their data movement alone
 #   gram                 CG step (config-5 shard): step time + kernel timeline of three steps
 #   xprod [snps indiv]   crossproduct kernel time at config 3, both engines
 #   gemm <snps indiv n reps>   k_gemm / k_gemm_i8 kernel time of one shape, 'N' and 'T'
