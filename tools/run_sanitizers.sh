@@ -6,7 +6,7 @@
 #     with libasan preloaded into the python process (leak detection off: the interpreter is not instrumented).
 set -e
 cd "$(dirname "$0")/.."
-out=profiles/r05_sanitizers.txt
+out=profiles/${MXA_ROUND:-r06}_sanitizers.txt
 {
   echo "# tools/run_sanitizers.sh  ($(gcc --version | head -1))"
   echo "## 1. planners under ASan + UBSan"
