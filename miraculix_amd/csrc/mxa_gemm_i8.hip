@@ -627,7 +627,7 @@ k_gemm_i8_tn(const uint8_t *__restrict__ G, long nslabs_all, const int8_t *__res
   // 4 rounds for 3.82 rounds of work; 298 strips x 5 + 93 x 6 pieces take 3 rounds of 195 stages + 1 of 163); the items of a round start together and sweep
   // their K ranges in step, so the digit fragments they share stay in the L2s (an even cut of the strip-major stage sequence, tried first, scattered the
   // workgroups over all row blocks: 1.20 ms against 1.04) -- or mode 1 (round 6): heads [0, la) of the strips on one class of workgroups, the tails dealt
-  // evenly to the others: 2.3 pieces per strip instead of 5.5, and every piece is 32 KiB of sums leaving for HBM.  A piece's sums go to P[slot][e][individual].
+  // evenly to the others: 2.3 pieces per strip instead of 5.2, and every piece is 32 KiB of sums leaving for HBM.  A piece's sums go to P[slot][e][individual].
   int strip = 0, st0 = 0, stages = 0, slot = 0;
   // DMA: LDS granule `lane` of a packed unit takes the global granule sigma(lane): rows 16..31 land rotated by one row
   const int rho = (lane - 32) >> 1;

@@ -142,7 +142,7 @@ inline GemmPlan plan_lut_host(long m, long k_pad, int n) {
 //  mode 1 (round 6), TWO CLASSES: every workgroup first takes `whole` whole strips (slot 0, in step).  Of the `rem` < slots strips left, workgroup w < rem takes
 //    the HEAD [0, la) of strip w (slot 0); the other nb = slots - rem workgroups share the TAILS [la, K) of those strips evenly as one strip-major sequence of
 //    rem * (K - la) stages (a tail piece: slot 1 + its workgroup's distance from the first workgroup of that tail).  rem + slots pieces instead of ~ rounds * slots:
-//    250 000 x 100 000 on 512 slots = 391 heads of 761 stages + 512 tail pieces (2.3 per strip, 3 slots of P) where mode 0 cut 2 159 pieces (5.5 per strip, 6 slots).
+//    250 000 x 100 000 on 512 slots = 391 heads of 761 stages + 512 tail pieces (2.3 per strip, 3 slots of P) where mode 0 cut 2 048 pieces (5.2 per strip, 6 slots).
 //    The tail workgroups start at different K positions -- they keep cycling over the tails' K window, which (with two workgroups per CU) has to stay
 //    L2-resident.  When mode 1 is taken: plan_i8_tn_host, from measurements.
 constexpr int kTnPieceCost = 20;
