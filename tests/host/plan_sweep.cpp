@@ -108,6 +108,16 @@ int main() {
         if ((indiv / 256 + 1) * (snps / 256 + 1) > 6000000) continue;
         for (int force = -1; force <= 1; force++) check_tn(indiv, snps, slots, slots >= 500 ? 1 : 2, force);
       }
+  {   // random shapes, slot counts up to 2048 (the 32-bit decode of mode 1 is admitted by the planner only while nb Q < 2^32: shapes near that edge are in here)
+    unsigned long long x = 88172645463325252ull;
+    auto rnd = [&](unsigned long long m) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (long)(x % m); };
+    for (int it = 0; it < 1500; it++) {
+      const long slots = 1 + rnd(2048), strips = 1 + rnd(it % 3 ? 3000 : 60), K = 1 + rnd(it % 5 ? 2047 : 6000);
+      if (strips * K > 4000000) continue;
+      const long indiv = strips * 256 - rnd(256), snps = K * 256 - rnd(256);
+      for (int force = -1; force <= 1; force++) check_tn(std::max(1L, indiv), std::max(1L, snps), slots, 1 + (int)rnd(2), force);
+    }
+  }
   {   // the headline shard takes the two-class schedule: 391 heads + 121 tail workgroups, three slots of P
     const TnSched s = plan_i8_tn_host((100000 + 127) / 128, 250000, 512, 1);
     CHECK(s.mode == 1 && s.q0 == 0 && s.q1 == 391 && s.q2 == 761 && s.pslots == 3, "headline schedule: mode %d whole %d rem %d la %d pslots %d", s.mode, s.q0, s.q1, s.q2, s.pslots);
